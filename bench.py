@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark of the RRTMG_LW hot path on MI355X:  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1e6 synthetic 72-layer columns,
+clouds with maximum-random overlap (icld=2 -> rtrnmr), sharded over the N GPUs of one node in contiguous column
+blocks (strong scaling: the total is fixed).  A "step" is one rrtmg_lw call over all columns with every input
+already resident in HBM (device-pointer entry of the C ABI); for N > 1 the step ends with the single RCCL
+all-gather of the packed flux/heating-rate block that reassembles the outputs on every rank (north_star).
+One JSON line is printed by rank 0.
+
+Extra objects in the line:
+  roofline      for the dominant kernel (largest total time among the kernels of the timed region), timed live with
+                HIP events on the launch stream; algorithmic bytes = 33.0 KB per column apportioned to a
+                band-chunk kernel by its share of the 140 g-points.
+  path          the same accounting for the whole step (all kernels).
+  cpu_baseline  the reference's own Fortran (oracle/_ref, "reference") or the C port ("port") on the host cores,
+                measured before the GPU is touched, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_COL_72 = 33.0e3      # 29.5 KB in + 3.5 KB out per 72-layer column (non-McICA API)
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algo_bytes_per_col(nlay, idrv):
+    n_in = 12 * nlay + 2 * (nlay + 1) + 1 + 16 + 5 * nlay + 16 * nlay + 16 * nlay
+    n_out = 4 * (nlay + 1) + 2 * nlay + (2 * (nlay + 1) if idrv else 0)
+    return 8.0 * (n_in + n_out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ncol", type=int, default=1_000_000, help="total columns over all GPUs")
+    ap.add_argument("--nlay", type=int, default=72)
+    ap.add_argument("--config", default="cloudy", choices=["clear", "cloudy", "aer_idrv"])
+    ap.add_argument("--batch", type=int, default=0, help="columns per internal batch (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cols-per-core", type=int, default=6000)
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N > 1)")
+    ap.add_argument("--check", action="store_true", help="compare 256 columns with the CPU oracle before timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    # ---- CPU baseline first: worker processes are spawned, which must happen before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import measure
+        cpu = measure(nlay=args.nlay, config=args.config, cols_per_core=args.cpu_cols_per_core)
+        cpu.pop("wall_s", None)
+
+    import torch
+    import torch.distributed as dist
+    from rrtmg_lw_amd import api
+    from rrtmg_lw_amd.synth import make_gcm_inputs
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the solver has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    api.rrtmg_lw_ini(1004.0, device=local_rank)
+    if args.batch:
+        api.set_batch(args.batch)
+
+    # contiguous column block of this rank
+    from rrtmg_lw_amd.shard import column_block, output_rows, output_views
+    col0, ncol, per = column_block(args.ncol, world, rank)
+    nlay = args.nlay
+    # inputs straight into HBM, generated in slabs to bound the temporaries
+    slab = 131072
+    parts = [make_gcm_inputs(min(slab, ncol - s), nlay, args.config, col0=col0 + s, backend="torch", device=dev)
+             for s in range(0, ncol, slab)]
+    d = dict(parts[0])
+    d["ncol"] = ncol
+    for k, v in parts[0].items():
+        if torch.is_tensor(v):
+            if len(parts) == 1:
+                continue
+            cdim = 1 if k == "taucld" else 0            # taucld is (16, ncol, nlay)
+            cat = torch.cat([p[k] for p in parts], dim=cdim)
+            nd = cat.dim()
+            d[k] = cat.permute(*reversed(range(nd))).contiguous().permute(*reversed(range(nd))) if nd > 1 else cat.contiguous()
+    del parts
+    idrv = d["idrv"]
+
+    # packed output block: rows = uflx, dflx, uflxc, dflxc, duflx_dt, duflxc_dt (nlay+1 each), hr, hrc (nlay each)
+    rows = output_rows(nlay)
+    outbuf = torch.zeros((rows, ncol), dtype=torch.float64, device=dev)
+    out = output_views(outbuf, nlay)
+    gathered = None
+    do_gather = world > 1 and not args.no_gather
+    if do_gather:
+        gathered = torch.empty((world * rows, per), dtype=torch.float64, device=dev)   # rank-major concatenation
+        if ncol != per:
+            raise SystemExit("--ncol must be divisible by --gpus for the all-gather")
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        api.rrtmg_lw_device(d, out, stream=stream)
+        if do_gather:
+            dist.all_gather_into_tensor(gathered, outbuf)
+
+    if args.check and rank == 0:
+        import numpy as np
+        from oracle.bindings import Oracle
+        step()
+        api.check(stream)
+        n = min(256, ncol)
+        dn = make_gcm_inputs(n, nlay, args.config, col0=col0)
+        ref = Oracle(kdata=api.default_kdata()).rrtmg_lw(n, nlay, dn["icld"], dn["idrv"], dn)
+        dfl = max(float(np.abs(out[k][:, :n].T.cpu().numpy() - ref[k]).max()) for k in ("uflx", "dflx", "uflxc", "dflxc"))
+        dhr = max(float(np.abs(out[k][:, :n].T.cpu().numpy() - ref[k]).max()) for k in ("hr", "hrc"))
+        print(f"# check vs oracle on {n} columns: max|dflux| = {dfl:.3e} W/m2, max|dhr| = {dhr:.3e} K/d", file=sys.stderr)
+
+    for _ in range(args.warmup):
+        step()
+    api.check(stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    buf = ctypes.create_string_buffer(1 << 16)
+    barrier()
+    api.lib().rrtmg_lw_hip_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    api.lib().rrtmg_lw_hip_profile_end(buf, len(buf))
+    api.check(stream)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = args.ncol / (dt / args.steps)
+        kern = {}
+        for line in buf.value.decode().splitlines():
+            nm, cnt, tot = line.rsplit(" ", 2)
+            kern[nm] = (int(cnt), float(tot))
+        bpc = algo_bytes_per_col(nlay, idrv)
+        roof = None
+        path = None
+        if kern:
+            dom = max(kern, key=lambda k: kern[k][1])
+            cnt, tot = kern[dom]
+            avg_ms = tot / cnt
+            cols_per_launch = ncol * args.steps / cnt
+            share = 1.0
+            if dom.startswith("k_band<"):
+                share = int(dom.split("<")[1].split(",")[1]) / 140.0      # NGC of k_band<B,NGC,MODE>@g0
+            ach = bpc * share * cols_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=round(avg_ms, 4),
+                        launches=cnt, columns_per_launch=cols_per_launch,
+                        algorithmic_bytes_per_launch=bpc * share * cols_per_launch)
+            ktot = sum(v[1] for v in kern.values())
+            pach = bpc * ncol * args.steps / (ktot * 1e-3) / 1e9
+            path = dict(kernels_ms_per_step=round(ktot / args.steps, 3), achieved=round(pach, 3), unit="GB/s",
+                        frac=round(pach / HBM_PEAK_GBS, 5), bytes_per_column=bpc,
+                        top=[dict(kernel=k, ms_per_step=round(v[1] / args.steps, 3)) for k, v in
+                             sorted(kern.items(), key=lambda kv: -kv[1][1])[:6]])
+            # PMC-derived HBM traffic of the dominant kernel, if a summary has been committed under profiles/
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get(dom)
+                except Exception:
+                    pass
+        res = dict(metric="columns/sec, 72-layer profiles" if nlay == 72 else f"columns/sec, {nlay}-layer profiles",
+                   value=round(value, 1), unit="columns/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
+                   dtype="f64", data="synthetic",
+                   config=dict(workload=f"{args.ncol} synthetic {nlay}-layer columns, config '{args.config}' "
+                                        f"(icld={d['icld']}: {'rtrnmr max-random overlap' if d['icld'] == 2 else 'clear'}, idrv={idrv}), "
+                                        f"sharded {world}x{per}",
+                               ncol_total=args.ncol, nlay=nlay, columns_per_gpu=per, parallelism=f"columns/{world}",
+                               gather="rccl all_gather" if do_gather else "none",
+                               kdata="stand-in (real k-data absent from the reference mount)" if api.kdata_is_standin() else "real"),
+                   roofline=roof, path=path, cpu_baseline=cpu)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+    api.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+/*
+ * rrtmg_lw_hip.h - C ABI of the MI355X-native RRTMG_LW column solver (librrtmg_lw_hip.so).
+ *
+ * Drop-in boundary for the reference's GCM entry points.  A host model keeps calling
+ *     use rrtmg_lw_init, only: rrtmg_lw_ini      (reference: src/rrtmg_lw_init.f90:47)
+ *     use rrtmg_lw_rad,  only: rrtmg_lw          (reference: src/rrtmg_lw_rad.nomcica.f90:99-108,
+ *                                                 McICA flavour src/rrtmg_lw_rad.f90:99-108)
+ * through the ISO_C_BINDING shim modules shipped in rrtmg_lw_amd/fortran/, which forward to the
+ * functions below.  Plain pointers and sizes only; every array is float64 in Fortran (column-major)
+ * order exactly as the reference declares it:
+ *     play,tlay,*vmr,cldfr,cicewp,cliqwp,reice,reliq  (ncol,nlay)      plev,tlev  (ncol,nlay+1)
+ *     tsfc (ncol)   emis (ncol,16)   taucld (16,ncol,nlay)   tauaer (ncol,nlay,16)
+ *     uflx,dflx,uflxc,dflxc,duflx_dt,duflxc_dt (ncol,nlay+1)   hr,hrc (ncol,nlay)
+ *     McICA: cldfmcl,taucmcl,ciwpmcl,clwpmcl (140,ncol,nlay)   reicmcl,relqmcl (ncol,nlay)
+ * Layer 1 is the surface layer; pressures in hPa.  The caller owns every array.
+ *
+ * Return value: 0 on success; non-zero = error, text available from rrtmg_lw_hip_last_error()
+ * (the reference `stop 'MESSAGE'`s instead - src/rrtmg_lw_cldprop.f90:212,217,228,244,272; the
+ * Fortran shim turns a non-zero code into `error stop` with the same text).
+ * There is no CPU fallback: every entry fails with RRTMG_LW_HIP_ENODEVICE when no GPU is usable.
+ */
+#ifndef RRTMG_LW_HIP_H
+#define RRTMG_LW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRTMG_LW_HIP_OK 0
+#define RRTMG_LW_HIP_EPHYSICS 1   /* the reference would `stop` (bad particle size / flag) */
+#define RRTMG_LW_HIP_EARG 2
+#define RRTMG_LW_HIP_ENODEVICE 3
+#define RRTMG_LW_HIP_ENOTINIT 4
+#define RRTMG_LW_HIP_EDATA 5      /* table / k-data file missing or malformed */
+#define RRTMG_LW_HIP_EHIP 6       /* HIP runtime error */
+
+#define RRTMG_LW_NBND 16
+#define RRTMG_LW_NGPT 140
+
+/* rrtmg_lw_ini(cpdair)  -  reference: src/rrtmg_lw_init.f90:47-194.
+ * Reads the static tables (lw_static.bin) and the absorption-coefficient file (RRLWBLOB k-data,
+ * original 16-g form; see rrtmg_lw_amd/kdata.py for the converters from rrtmg_lw_k_g.f90 and
+ * rrtmg_lw.nc), performs the 256->140 g-point reduction and the LUT build on the host, and uploads the
+ * packed, g-point-fastest tables to the device `device` (HIP ordinal of this process's GPU).
+ * cpdair in J kg-1 K-1 sets heatfac (src/rrtmg_lw_init.f90:298). */
+int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, double cpdair, int device);
+
+/* 1 if the loaded k-data is the synthetic stand-in (fluxes not physical), 0 if real, -1 if not initialised */
+int rrtmg_lw_hip_kdata_is_standin(void);
+
+void rrtmg_lw_hip_finalize(void);
+const char *rrtmg_lw_hip_last_error(void);
+
+/* rrtmg_lw, non-McICA  -  reference: src/rrtmg_lw_rad.nomcica.f90:99-588.  HOST pointers.
+ * icld is in/out (reset to 2 when outside [0,3], :456).  duflx_dt/duflxc_dt may be NULL unless idrv==1. */
+int rrtmg_lw_hip_run_nomcica(
+    int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt);
+
+/* Same contract with DEVICE pointers (a GPU-resident host model, and the benchmark's timed region).
+ * Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and the call
+ * returns without synchronising; physics errors are reported by rrtmg_lw_hip_check(stream). */
+int rrtmg_lw_hip_run_nomcica_device(
+    int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt, void *stream);
+
+/* Synchronise `stream` and return the physics-error status of the work enqueued so far. */
+int rrtmg_lw_hip_check(void *stream);
+
+/* Prepared-column entry (HOST pointers): the physics sequence of the reference's column driver,
+ * cldprop -> setcoef -> taumol -> rtrn|rtrnmr (src/rrtmg_lw.1col.f90:497-580), for `ncol` independent
+ * columns that all have `nlayers` layers.  This is the interface the golden OUTPUT_RRTM files pin
+ * (column amounts come from the input file, not from inatm's hydrostatic estimate).
+ * Arrays are column-fastest: pavel,tavel,coldry,wbrodl,cldfrac,ciwp,clwp,rei,rel (ncol,nlayers);
+ * pz,tz (ncol,0:nlayers); tbound,pwvcm (ncol); semiss (ncol,16); wkl (ncol,7,nlayers); wx (ncol,4,nlayers);
+ * tauc (ncol,16,nlayers); taua (ncol,nlayers,16); outputs (ncol,0:nlayers).
+ * istart..iend select the bands (1..16); istart==16 switches band 16 to the 2600-3250 cm-1 Planck table
+ * exactly as setcoef does (src/rrtmg_lw_setcoef.f90:233-252).  icld==1 -> rtrn, otherwise rtrnmr. */
+int rrtmg_lw_hip_run_columns(
+    int ncol, int nlayers, int istart, int iend, int icld, int idrv,
+    const double *pavel, const double *tavel, const double *pz, const double *tz, const double *tbound,
+    const double *semiss, const double *coldry, const double *wkl, const double *wbrodl, const double *wx,
+    const double *pwvcm, int inflag, int iceflag, int liqflag, const double *cldfrac, const double *tauc,
+    const double *ciwp, const double *clwp, const double *rei, const double *rel, const double *taua,
+    double *totuflux, double *totdflux, double *fnet, double *htr,
+    double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
+    double *dtotuflux_dt, double *dtotuclfl_dt);
+
+/* Tuning / introspection ------------------------------------------------------------------------- */
+/* Columns processed per internal batch (bounds the device workspace); default 131072. */
+int rrtmg_lw_hip_set_batch(int ncol_batch);
+/* Bytes of device workspace currently allocated. */
+long long rrtmg_lw_hip_workspace_bytes(void);
+/* Number of band-chunk kernels one column batch launches, and the name of chunk i's kernel
+ * (for matching rocprofv3 kernel traces). */
+int rrtmg_lw_hip_num_chunks(void);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py's roofline leg).
+ * profile_end synchronises the device and writes "<kernel> <launches> <total_ms>" lines into buf. */
+void rrtmg_lw_hip_profile_begin(void);
+int rrtmg_lw_hip_profile_end(char *buf, int len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+"""TEST/BENCH INFRASTRUCTURE: times the CPU side on the host cores for bench.py's `cpu_baseline` object.
+
+kind "reference": the reference's own Fortran rrtmg_lw (oracle/_ref/libref_nomcica.so, built from /root/reference
+by oracle/Makefile) - one process per core, columns split evenly, because the reference has no threading
+(SURVEY.md 1).  kind "port": the C restatement (oracle/liboracle.so) when the reference build is absent.
+Must run BEFORE the calling process initialises the GPU (workers are spawned interpreters).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+import multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _worker(args):
+    ncol, nlay, config, col0, kind = args
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle.bindings import Oracle, Reference
+    from rrtmg_lw_amd.synth import make_gcm_inputs
+    eng = Reference("nomcica") if kind == "reference" else Oracle()
+    d = make_gcm_inputs(ncol, nlay, config, col0=col0)
+    eng.rrtmg_lw(min(ncol, 8), nlay, d["icld"], d["idrv"], make_gcm_inputs(min(ncol, 8), nlay, config))   # warm-up
+    t0 = time.perf_counter()
+    eng.rrtmg_lw(ncol, nlay, d["icld"], d["idrv"], d)
+    return time.perf_counter() - t0
+
+
+def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None):
+    from oracle.bindings import Reference
+    kind = "reference" if Reference.available("nomcica") else "port"
+    if cores is None:
+        cores = len(os.sched_getaffinity(0))
+    jobs = [(cols_per_core, nlay, config, i * cols_per_core, kind) for i in range(cores)]
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
+        times = list(ex.map(_worker, jobs))
+    wall = time.perf_counter() - t0
+    total = cols_per_core * cores
+    tmax = max(times)
+    return dict(value=total / tmax, unit="columns/s", cores=cores, kind=kind,
+                sample=f"{total} synthetic {nlay}-layer '{config}' columns ({cols_per_core} per process, one process per core, "
+                       f"slowest process {tmax:.2f} s, {sum(times):.1f} core-seconds; single-core rate {cols_per_core / (sum(times) / cores):.0f} columns/s)",
+                wall_s=wall)
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(measure(cols_per_core=int(sys.argv[1]) if len(sys.argv) > 1 else 2000)))

@@ -1,0 +1,181 @@
+"""Python host-side mirror of the reference's GCM interface, over the C ABI of librrtmg_lw_hip.so.
+
+    rrtmg_lw_ini(cpdair)                         reference: src/rrtmg_lw_init.f90:47
+    rrtmg_lw(ncol, nlay, icld, idrv, play, ...)  reference: src/rrtmg_lw_rad.nomcica.f90:99-108
+
+Same names, argument order and meaning as the Fortran; arrays are numpy float64 in Fortran order (or anything
+convertible).  Outputs are returned in a dict instead of being written into caller arrays.  There is no CPU
+path: importing works anywhere, but every call raises unless the HIP library is built and a GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrtmg_lw_hip.so")
+STATIC_BLOB = os.path.join(_HERE, "data", "lw_static.bin")
+STANDIN_KDATA = os.path.join(_HERE, "data", "standin.kdata.bin")
+REAL_KDATA = os.path.join(os.path.dirname(_HERE), "data", "rrtmg_lw.kdata.bin")
+NBND, NGPT = 16, 140
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+_initialised = False
+
+
+class RrtmgLwError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librrtmg_lw_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RrtmgLwError(f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rrtmg_lw_hip_last_error.restype = C.c_char_p
+        _lib.rrtmg_lw_hip_workspace_bytes.restype = C.c_longlong
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RrtmgLwError(f"rrtmg_lw_hip error {rc}: {lib().rrtmg_lw_hip_last_error().decode()}")
+
+
+def default_kdata():
+    """Real absorption coefficients if they have been converted into data/rrtmg_lw.kdata.bin
+    (rrtmg_lw_amd/kdata.py), otherwise the synthetic stand-in tables."""
+    return REAL_KDATA if os.path.exists(REAL_KDATA) else STANDIN_KDATA
+
+
+def rrtmg_lw_ini(cpdair=1004.0, kdata=None, device=None, static=STATIC_BLOB):
+    """rrtmg_lw_ini(cpdair): one-time table setup on this process's GPU (reference src/rrtmg_lw_init.f90:47)."""
+    global _initialised
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    kdata = kdata or default_kdata()
+    _check(lib().rrtmg_lw_hip_init(static.encode(), kdata.encode(), C.c_double(cpdair), C.c_int(device)))
+    _initialised = True
+
+
+def kdata_is_standin():
+    return lib().rrtmg_lw_hip_kdata_is_standin() == 1
+
+
+def set_batch(n):
+    _check(lib().rrtmg_lw_hip_set_batch(C.c_int(int(n))))
+
+
+def _f(a, shape):
+    a = np.asfortranarray(a, dtype=np.float64)
+    if tuple(a.shape) != tuple(shape):
+        raise ValueError(f"array has shape {a.shape}, interface declares {shape}")
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def rrtmg_lw(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr,
+             cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp,
+             cliqwp, reice, reliq, tauaer):
+    """Non-McICA rrtmg_lw with host arrays.  Returns dict(uflx, dflx, hr, uflxc, dflxc, hrc[, duflx_dt, duflxc_dt], icld)."""
+    a2 = [_f(x, (ncol, nlay)) for x in (play,)] + [_f(plev, (ncol, nlay + 1)), _f(tlay, (ncol, nlay)),
+                                                  _f(tlev, (ncol, nlay + 1)), _f(tsfc, (ncol,))]
+    gases = [_f(x, (ncol, nlay)) for x in (h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr)]
+    em = _f(emis, (ncol, NBND))
+    cld = [_f(cldfr, (ncol, nlay)), _f(taucld, (NBND, ncol, nlay)), _f(cicewp, (ncol, nlay)), _f(cliqwp, (ncol, nlay)),
+           _f(reice, (ncol, nlay)), _f(reliq, (ncol, nlay)), _f(tauaer, (ncol, nlay, NBND))]
+    out = {k: np.empty((ncol, nlay + 1), order="F") for k in ("uflx", "dflx", "uflxc", "dflxc")}
+    out["hr"] = np.empty((ncol, nlay), order="F")
+    out["hrc"] = np.empty((ncol, nlay), order="F")
+    if idrv == 1:
+        out["duflx_dt"] = np.empty((ncol, nlay + 1), order="F")
+        out["duflxc_dt"] = np.empty((ncol, nlay + 1), order="F")
+    icld_c = C.c_int(int(icld))
+    null = C.cast(None, _dp)
+    args = [C.c_int(ncol), C.c_int(nlay), C.byref(icld_c), C.c_int(int(idrv))]
+    args += [_p(x) for x in a2] + [_p(x) for x in gases] + [_p(em)]
+    args += [C.c_int(int(inflglw)), C.c_int(int(iceflglw)), C.c_int(int(liqflglw))]
+    args += [_p(x) for x in cld]
+    args += [_p(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")]
+    args += [_p(out["duflx_dt"]) if idrv == 1 else null, _p(out["duflxc_dt"]) if idrv == 1 else null]
+    _check(lib().rrtmg_lw_hip_run_nomcica(*args))
+    out["icld"] = icld_c.value
+    return out
+
+
+_GCM_ORDER = ("play", "plev", "tlay", "tlev", "tsfc", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr",
+              "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr", "emis")
+_CLD_ORDER = ("cldfr", "taucld", "cicewp", "cliqwp", "reice", "reliq", "tauaer")
+
+
+def rrtmg_lw_from_dict(d, icld=None, idrv=None):
+    """Convenience: call rrtmg_lw with the dictionaries produced by rrtmg_lw_amd.synth.make_gcm_inputs."""
+    icld = d["icld"] if icld is None else icld
+    idrv = d["idrv"] if idrv is None else idrv
+    return rrtmg_lw(d["ncol"], d["nlay"], icld, idrv, *[d[k] for k in _GCM_ORDER], d["inflglw"], d["iceflglw"],
+                    d["liqflglw"], *[d[k] for k in _CLD_ORDER])
+
+
+def rrtmg_lw_device(d, out, icld=None, idrv=None, stream=None):
+    """Device-resident call: `d` holds torch CUDA tensors laid out column-fastest (synth.make_gcm_inputs(backend="torch")),
+    `out` a dict of preallocated output tensors (uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt).
+    Enqueues on `stream` (an integer hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream) and returns
+    immediately; call check(stream) to synchronise and collect physics errors."""
+    icld = d["icld"] if icld is None else icld
+    idrv = d["idrv"] if idrv is None else idrv
+    icld_c = C.c_int(int(icld))
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    args = [C.c_int(d["ncol"]), C.c_int(d["nlay"]), C.byref(icld_c), C.c_int(int(idrv))]
+    args += [ptr(d[k]) for k in _GCM_ORDER]
+    args += [C.c_int(int(d["inflglw"])), C.c_int(int(d["iceflglw"])), C.c_int(int(d["liqflglw"]))]
+    args += [ptr(d[k]) for k in _CLD_ORDER]
+    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")]
+    args.append(C.c_void_p(stream or 0))
+    _check(lib().rrtmg_lw_hip_run_nomcica_device(*args))
+    return icld_c.value
+
+
+def check(stream=None):
+    _check(lib().rrtmg_lw_hip_check(C.c_void_p(stream or 0)))
+
+
+def run_columns(cols, istart=1, iend=16, icld=None, idrv=None):
+    """Prepared-column entry for a list of column dicts (rrtmg_lw_amd.io_rrtm.read_input_rrtm) that share nlayers
+    and cloud flags.  Returns dict of arrays (ncol, 0:nlayers)."""
+    n = len(cols)
+    nl = int(cols[0]["nlayers"])
+    icld = int(cols[0]["icld"]) if icld is None else icld
+    idrv = int(cols[0]["idrv"]) if idrv is None else idrv
+    st = lambda key, shape: _f(np.stack([np.asarray(c[key], dtype=np.float64).reshape(shape[1:], order="F") for c in cols]), shape)
+    a = dict(pavel=st("pavel", (n, nl)), tavel=st("tavel", (n, nl)), pz=st("pz", (n, nl + 1)), tz=st("tz", (n, nl + 1)),
+             tbound=_f(np.array([float(c["tbound"]) for c in cols]), (n,)), semiss=st("semiss", (n, NBND)),
+             coldry=st("coldry", (n, nl)), wkl=st("wkl", (n, 7, nl)), wbrodl=st("wbrodl", (n, nl)), wx=st("wx", (n, 4, nl)),
+             pwvcm=_f(np.array([float(c["pwvcm"]) for c in cols]), (n,)), cldfrac=st("cldfrac", (n, nl)),
+             tauc=st("tauc", (n, NBND, nl)), ciwp=st("ciwp", (n, nl)), clwp=st("clwp", (n, nl)), rei=st("rei", (n, nl)),
+             rel=st("rel", (n, nl)), taua=st("tauaer", (n, nl, NBND)))
+    names = ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc", "dtotuflux_dt", "dtotuclfl_dt")
+    out = {k: np.zeros((n, nl + 1), order="F") for k in names}
+    c0 = cols[0]
+    args = [C.c_int(n), C.c_int(nl), C.c_int(istart), C.c_int(iend), C.c_int(icld), C.c_int(idrv)]
+    args += [_p(a[k]) for k in ("pavel", "tavel", "pz", "tz", "tbound", "semiss", "coldry", "wkl", "wbrodl", "wx", "pwvcm")]
+    args += [C.c_int(int(c0["inflag"])), C.c_int(int(c0["iceflag"])), C.c_int(int(c0["liqflag"]))]
+    args += [_p(a[k]) for k in ("cldfrac", "tauc", "ciwp", "clwp", "rei", "rel", "taua")]
+    args += [_p(out[k]) for k in names]
+    _check(lib().rrtmg_lw_hip_run_columns(*args))
+    return out
+
+
+def finalize():
+    global _initialised
+    if _lib is not None:
+        _lib.rrtmg_lw_hip_finalize()
+    _initialised = False

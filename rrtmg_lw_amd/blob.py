@@ -15,7 +15,7 @@ Layout (little endian):
     payloads, each 64-byte aligned, stored in Fortran (column-major) element order
 
 The same file is read by the C oracle (oracle/rrlw_blob.h), the C++ product loader
-(rrtmg_lw_amd/csrc/blob.hpp), the Fortran reference harness (oracle/ref_harness.f90) and this module.
+(rrtmg_lw_amd/csrc/tables.hpp), the Fortran reference harness (oracle/ref_harness.f90) and this module.
 """
 from __future__ import annotations
 

@@ -1,0 +1,499 @@
+// C-ABI implementation (include/rrtmg_lw_hip.h): device state, workspace, batching, kernel dispatch.
+// Replaces the serial `do iplon = 1, ncol` loop of the reference's rrtmg_lw
+// (src/rrtmg_lw_rad.nomcica.f90:472-586) with batched launches of the kernels in kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtmg_lw_hip.h"
+#include "kernels.hip"
+
+namespace {
+
+using namespace rrlw;
+
+constexpr int NGCMAX = 8;
+constexpr int BLOCK = 256;
+
+struct Chunk { int band, ngc, g0; };
+// band chunks: even sizes and even starts keep every table row access 16-byte aligned
+const Chunk kChunks[] = {
+    {1, 6, 0}, {1, 4, 6}, {2, 6, 0}, {2, 6, 6}, {3, 8, 0}, {3, 8, 8}, {4, 8, 0}, {4, 6, 8}, {5, 8, 0}, {5, 8, 8},
+    {6, 8, 0}, {7, 6, 0}, {7, 6, 6}, {8, 8, 0}, {9, 6, 0}, {9, 6, 6}, {10, 6, 0}, {11, 8, 0}, {12, 8, 0},
+    {13, 4, 0}, {14, 2, 0}, {15, 2, 0}, {16, 2, 0}};
+constexpr int NCHUNK = sizeof(kChunks) / sizeof(kChunks[0]);
+
+struct State {
+    bool init = false;
+    int device = -1;
+    HostTables H;
+    DevTables D;
+    double *d_ktab = nullptr, *d_stat = nullptr;
+    // workspace
+    Workspace W{};
+    void *ws_base = nullptr;
+    size_t ws_bytes = 0;
+    int ws_nlay = 0, ws_ncolb = 0;
+    bool ws_cloud = false;
+    int *d_err = nullptr;
+    int batch = 131072;
+    // host-entry staging
+    void *stage_base = nullptr;
+    size_t stage_bytes = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool profile = false;
+    struct ProfRec { const char *name; hipEvent_t a, b; };
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> evpool;
+};
+State G;
+std::mutex g_mu;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    G.err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const char *physics_message(int code)
+{
+    switch (code) {   // texts of the reference's `stop` statements, src/rrtmg_lw_cldprop.f90:212,217,228,244,272
+    case E_ICE_SMALL: return "ICE RADIUS TOO SMALL";
+    case E_ICE_BOUNDS: return "ICE RADIUS OUT OF BOUNDS";
+    case E_ICE_GEN_BOUNDS: return "ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS";
+    case E_LIQ_BOUNDS: return "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS";
+    case E_BAD_FLAG: return "INVALID CLOUD PROPERTY FLAG";
+    default: return "unknown physics error";
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+hipEvent_t get_event()
+{
+    if (!G.evpool.empty()) { hipEvent_t e = G.evpool.back(); G.evpool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// launch wrapper: brackets the kernel with events when profiling is on
+#define LAUNCH(NAME, KERNEL, GRID, BLOCKDIM, STREAM, ...)                                        \
+    do {                                                                                         \
+        if (G.profile) {                                                                         \
+            State::ProfRec r_{NAME, get_event(), get_event()};                                   \
+            (void)hipEventRecord(r_.a, STREAM);                                                  \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, 0, STREAM, __VA_ARGS__);                  \
+            (void)hipEventRecord(r_.b, STREAM);                                                  \
+            G.prof.push_back(r_);                                                                \
+        } else {                                                                                 \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, 0, STREAM, __VA_ARGS__);                  \
+        }                                                                                        \
+    } while (0)
+
+// (re)allocate the per-batch workspace
+int ensure_workspace(int nlay, int ncolb, bool cloud)
+{
+    if (G.ws_base && G.ws_nlay == nlay && G.ws_ncolb >= ncolb && (G.ws_cloud || !cloud)) return 0;
+    if (G.ws_base) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.ws_base)); G.ws_base = nullptr; }
+    ncolb = std::max(ncolb, G.ws_nlay == nlay ? G.ws_ncolb : 0);
+    cloud = cloud || G.ws_cloud;
+    const size_t n = (size_t)ncolb, L = (size_t)nlay;
+    struct Item { void **p; size_t bytes; };
+    Workspace &W = G.W;
+    std::vector<Item> items = {
+        {(void **)&W.f, (size_t)NFIELD * L * n * 8},
+        {(void **)&W.planklay, 16 * L * n * 8},
+        {(void **)&W.planklev, 16 * (L + 1) * n * 8},
+        {(void **)&W.percol, (size_t)NPERCOL * n * 8},
+        {(void **)&W.scr[0], (size_t)NGCMAX * L * n * 8},
+        {(void **)&W.scr[1], (size_t)NGCMAX * L * n * 8},
+        {(void **)&W.idx, L * n * 4},
+        {(void **)&W.laytrop, n * 4},
+        {(void **)&W.ncbands, n * 4},
+        {(void **)&W.cflag, (L + 2) * n * 4},
+    };
+    if (cloud) {
+        items.push_back({(void **)&W.scr[2], (size_t)NGCMAX * L * n * 8});
+        items.push_back({(void **)&W.scr[3], (size_t)NGCMAX * L * n * 8});
+        items.push_back({(void **)&W.taucloud, 16 * L * n * 8});
+        items.push_back({(void **)&W.odcld, 16 * L * n * 8});
+        items.push_back({(void **)&W.efcl, 16 * L * n * 8});
+        items.push_back({(void **)&W.mrfac, (size_t)NMRFAC * (L + 2) * n * 8});
+    } else {
+        W.scr[2] = W.scr[3] = W.taucloud = W.odcld = W.efcl = W.mrfac = nullptr;
+    }
+    size_t total = 0;
+    for (auto &it : items) total += align_up(it.bytes, 256);
+    HIP_TRY(hipMalloc(&G.ws_base, total));
+    size_t off = 0;
+    for (auto &it : items) { *it.p = (char *)G.ws_base + off; off += align_up(it.bytes, 256); }
+    W.ncolb = ncolb;
+    W.nlay = nlay;
+    W.err = G.d_err;
+    G.ws_bytes = total;
+    G.ws_nlay = nlay;
+    G.ws_ncolb = ncolb;
+    G.ws_cloud = cloud;
+    return 0;
+}
+
+template <int MODE>
+void launch_chunks(hipStream_t s, int nb, int istart, int iend, BandArgs a, const FluxOut &out)
+{
+    const dim3 grid((nb + BLOCK - 1) / BLOCK), block(BLOCK);
+#define CH(B, NGC, G0)                                                                      \
+    if (B >= istart && B <= iend) {                                                         \
+        a.g0 = G0;                                                                          \
+        LAUNCH(MODE == 0 ? "k_band<" #B "," #NGC ",0>@g" #G0 : (MODE == 1 ? "k_band<" #B "," #NGC ",1>@g" #G0 : "k_band<" #B "," #NGC ",2>@g" #G0), \
+               (k_band<B, NGC, MODE>), grid, block, s, G.D, G.W, a, out);                   \
+    }
+    CH(1, 6, 0) CH(1, 4, 6) CH(2, 6, 0) CH(2, 6, 6) CH(3, 8, 0) CH(3, 8, 8) CH(4, 8, 0) CH(4, 6, 8) CH(5, 8, 0) CH(5, 8, 8)
+    CH(6, 8, 0) CH(7, 6, 0) CH(7, 6, 6) CH(8, 8, 0) CH(9, 6, 0) CH(9, 6, 6) CH(10, 6, 0) CH(11, 8, 0) CH(12, 8, 0)
+    CH(13, 4, 0) CH(14, 2, 0) CH(15, 2, 0) CH(16, 2, 0)
+#undef CH
+}
+
+// one column batch, everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr
+template <bool GCM>
+int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
+              const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out)
+{
+    const dim3 grid((nb + BLOCK - 1) / BLOCK), block(BLOCK);
+    LAUNCH("k_prep", (k_prep<GCM>), grid, block, s, G.D, G.W, g, c, out, nb, col0, nct, idrv, istart);
+    if (mode != 0)
+        LAUNCH("k_cloud", (k_cloud<GCM>), grid, block, s, G.D, G.W, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+    BandArgs a;
+    a.ncol = nb; a.col0 = col0; a.nct = nct; a.g0 = 0; a.idrv = idrv;
+    a.emis = GCM ? g.emis : c.semiss;
+    a.tauaer = GCM ? g.tauaer : c.taua;
+    a.cldfrac = GCM ? g.cldfr : c.cldfrac;
+    if (mode == 0) launch_chunks<0>(s, nb, istart, iend, a, out);
+    else if (mode == 1) launch_chunks<1>(s, nb, istart, iend, a, out);
+    else launch_chunks<2>(s, nb, istart, iend, a, out);
+    LAUNCH("k_final", k_final, grid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct, nlay, idrv, mode == 0 ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int read_physics_error(hipStream_t s)
+{
+    int code = 0;
+    HIP_TRY(hipMemcpyAsync(&code, G.d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (code != 0) {
+        int zero = 0;
+        HIP_TRY(hipMemcpy(G.d_err, &zero, sizeof(int), hipMemcpyHostToDevice));
+        return fail(RRTMG_LW_HIP_EPHYSICS, "%s", physics_message(code));
+    }
+    return 0;
+}
+
+int ensure_stage(size_t bytes)
+{
+    if (G.stage_bytes >= bytes) return 0;
+    if (G.stage_base) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.stage_base)); G.stage_base = nullptr; G.stage_bytes = 0; }
+    HIP_TRY(hipMalloc(&G.stage_base, bytes));
+    G.stage_bytes = bytes;
+    return 0;
+}
+
+int check_common(int ncol, int nlay)
+{
+    if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
+    if (ncol < 1 || nlay < 1 || nlay > 603) return fail(RRTMG_LW_HIP_EARG, "bad dimensions ncol=%d nlay=%d", ncol, nlay);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rrtmg_lw_hip_last_error(void) { return G.err.c_str(); }
+
+int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, double cpdair, int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(RRTMG_LW_HIP_ENODEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RRTMG_LW_HIP_EARG, "device %d out of range (0..%d)", device, ndev - 1);
+    if (!static_tables_path || !kdata_path) return fail(RRTMG_LW_HIP_EARG, "null table path");
+    std::string err;
+    if (!build_tables(static_tables_path, kdata_path, cpdair, G.H, err)) return fail(RRTMG_LW_HIP_EDATA, "%s", err.c_str());
+    HIP_TRY(hipSetDevice(device));
+    if (G.d_ktab) { (void)hipFree(G.d_ktab); G.d_ktab = nullptr; }
+    if (G.d_stat) { (void)hipFree(G.d_stat); G.d_stat = nullptr; }
+    HIP_TRY(hipMalloc((void **)&G.d_ktab, G.H.ktab.size() * 8));
+    HIP_TRY(hipMalloc((void **)&G.d_stat, G.H.stat.size() * 8));
+    HIP_TRY(hipMemcpy(G.d_ktab, G.H.ktab.data(), G.H.ktab.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(G.d_stat, G.H.stat.data(), G.H.stat.size() * 8, hipMemcpyHostToDevice));
+    if (!G.d_err) {
+        HIP_TRY(hipMalloc((void **)&G.d_err, sizeof(int)));
+    }
+    HIP_TRY(hipMemset(G.d_err, 0, sizeof(int)));
+    if (!G.stream) HIP_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+    DevTables &D = G.D;
+    D.ktab = G.d_ktab;
+    D.stat = G.d_stat;
+    for (int b = 0; b < NBND; b++) {
+        D.band[b] = G.H.band[b];
+        D.delwave[b] = G.H.delwave[b];
+        for (int k = 0; k < 6; k++) D.refrat[b][k] = G.H.refrat[b][k];
+    }
+    D.sl = G.H.sl;
+    D.absice0[0] = G.H.absice0[0]; D.absice0[1] = G.H.absice0[1];
+    D.abscld1 = G.H.abscld1; D.absliq0 = G.H.absliq0;
+    D.heatfac = G.H.heatfac; D.fluxfac = G.H.fluxfac; D.oneminus = G.H.oneminus; D.bpade = G.H.bpade;
+    G.device = device;
+    G.init = true;
+    G.err.clear();
+    return 0;
+}
+
+int rrtmg_lw_hip_kdata_is_standin(void) { return G.init ? (G.H.standin ? 1 : 0) : -1; }
+
+void rrtmg_lw_hip_finalize(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!G.init) return;
+    (void)hipDeviceSynchronize();
+    if (G.ws_base) (void)hipFree(G.ws_base);
+    if (G.stage_base) (void)hipFree(G.stage_base);
+    if (G.d_ktab) (void)hipFree(G.d_ktab);
+    if (G.d_stat) (void)hipFree(G.d_stat);
+    if (G.d_err) (void)hipFree(G.d_err);
+    if (G.stream) (void)hipStreamDestroy(G.stream);
+    G = State();
+}
+
+int rrtmg_lw_hip_set_batch(int ncol_batch)
+{
+    if (ncol_batch < 64) return fail(RRTMG_LW_HIP_EARG, "batch must be >= 64 columns");
+    G.batch = ncol_batch;
+    return 0;
+}
+
+long long rrtmg_lw_hip_workspace_bytes(void) { return (long long)(G.ws_bytes + G.stage_bytes); }
+int rrtmg_lw_hip_num_chunks(void) { return NCHUNK; }
+
+void rrtmg_lw_hip_profile_begin(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &r : G.prof) { G.evpool.push_back(r.a); G.evpool.push_back(r.b); }
+    G.prof.clear();
+    G.profile = true;
+}
+
+// Stops event collection, synchronises the device and writes one line per kernel name:
+// "<name> <launches> <total_ms>\n".  Returns the number of bytes written (truncated to len-1).
+int rrtmg_lw_hip_profile_end(char *buf, int len)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    G.profile = false;
+    (void)hipDeviceSynchronize();
+    std::vector<std::string> names;
+    std::vector<double> total;
+    std::vector<int> count;
+    for (auto &r : G.prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
+        size_t k = 0;
+        for (; k < names.size(); k++) if (names[k] == r.name) break;
+        if (k == names.size()) { names.push_back(r.name); total.push_back(0.0); count.push_back(0); }
+        total[k] += ms;
+        count[k] += 1;
+        G.evpool.push_back(r.a);
+        G.evpool.push_back(r.b);
+    }
+    G.prof.clear();
+    std::string out;
+    for (size_t k = 0; k < names.size(); k++) {
+        char line[160];
+        snprintf(line, sizeof line, "%s %d %.6f\n", names[k].c_str(), count[k], total[k]);
+        out += line;
+    }
+    if (buf && len > 0) {
+        const size_t n = std::min(out.size(), (size_t)len - 1);
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+        return (int)n;
+    }
+    return 0;
+}
+
+int rrtmg_lw_hip_check(void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
+    return read_physics_error((hipStream_t)stream);
+}
+
+int rrtmg_lw_hip_run_nomcica_device(
+    int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(ncol, nlay)) return rc;
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.nomcica.f90:456
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);      // :546-560 (icld=0 -> rtrnmr clear branch)
+    const int nbmax = std::min(ncol, G.batch);
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
+    GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
+            ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
+    ColIn c{};
+    FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
+    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
+        const int nb = std::min(nbmax, ncol - col0);
+        if (int rc = run_batch<true>((hipStream_t)stream, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out))
+            return rc;
+    }
+    return 0;
+}
+
+int rrtmg_lw_hip_run_nomcica(
+    int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(ncol, nlay)) return rc;
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (*icld < 0 || *icld > 3) *icld = 2;
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);
+    const bool cloud = *icld >= 1;          // inatm copies the cloud arrays only when icld >= 1 (:893-910)
+    const int nbmax = std::min(ncol, G.batch);
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
+    const size_t n = (size_t)nbmax, L = (size_t)nlay;
+    // staging layout (doubles): 15 x (n,L), 2 x (n,L+1), tsfc n, emis 16n, tauaer 16 n L, [5 x (n,L) + 16 n L], outputs 6 x (n,L+1) + 2 x (n,L)
+    const size_t in_d = 15 * n * L + 2 * n * (L + 1) + n + 16 * n + 16 * n * L + (cloud ? 5 * n * L + 16 * n * L : 0);
+    const size_t out_d = 6 * n * (L + 1) + 2 * n * L;
+    if (int rc = ensure_stage((in_d + out_d) * 8 + 4096)) return rc;
+    double *p = (double *)G.stage_base;
+    auto take = [&](size_t cnt) { double *q = p; p += cnt; return q; };
+    double *d2[15];
+    for (auto &q : d2) q = take(n * L);
+    double *d_plev = take(n * (L + 1)), *d_tlev = take(n * (L + 1)), *d_tsfc = take(n), *d_emis = take(16 * n);
+    double *d_tauaer = take(16 * n * L);
+    double *d_cld[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *d_taucld = nullptr;
+    if (cloud) { for (auto &q : d_cld) q = take(n * L); d_taucld = take(16 * n * L); }
+    double *d_o1[6];
+    for (auto &q : d_o1) q = take(n * (L + 1));
+    double *d_hr = take(n * L), *d_hrc = take(n * L);
+    hipStream_t s = G.stream;
+    const double *h2[15] = {play, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, nullptr, nullptr, nullptr};
+    const double *hcld[5] = {cldfr, cicewp, cliqwp, reice, reliq};
+    double *hout1[6] = {uflx, dflx, uflxc, dflxc, duflx_dt, duflxc_dt};
+    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
+        const int nb = std::min(nbmax, ncol - col0);
+        const size_t w = (size_t)nb * 8, sp = (size_t)ncol * 8;
+        for (int k = 0; k < 12; k++)
+            HIP_TRY(hipMemcpy2DAsync(d2[k], w, h2[k] + col0, sp, w, L, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(d_plev, w, plev + col0, sp, w, L + 1, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(d_tlev, w, tlev + col0, sp, w, L + 1, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_tsfc, tsfc + col0, w, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(d_emis, w, emis + col0, sp, w, 16, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(d_tauaer, w, tauaer + col0, sp, w, L * 16, hipMemcpyHostToDevice, s));
+        if (cloud) {
+            for (int k = 0; k < 5; k++)
+                HIP_TRY(hipMemcpy2DAsync(d_cld[k], w, hcld[k] + col0, sp, w, L, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpy2DAsync(d_taucld, 16 * w, taucld + (size_t)16 * col0, 16 * sp, 16 * w, L, hipMemcpyHostToDevice, s));
+        }
+        GcmIn g{d2[0], d_plev, d2[1], d_tlev, d_tsfc, d2[2], d2[3], d2[4], d2[5], d2[6], d2[7], d2[8], d2[9], d2[10], d2[11],
+                d_emis, d_cld[0], d_taucld, d_cld[1], d_cld[2], d_cld[3], d_cld[4], d_tauaer};
+        ColIn c{};
+        FluxOut out{d_o1[0], d_o1[1], d_hr, d_o1[2], d_o1[3], d_hrc, d_o1[4], d_o1[5], nullptr, nullptr};
+        if (int rc = run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out)) return rc;
+        const int nout = idrv == 1 ? 6 : 4;
+        for (int k = 0; k < nout; k++)
+            HIP_TRY(hipMemcpy2DAsync(hout1[k] + col0, sp, d_o1[k], w, w, L + 1, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpy2DAsync(hr + col0, sp, d_hr, w, w, L, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpy2DAsync(hrc + col0, sp, d_hrc, w, w, L, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return read_physics_error(s);
+}
+
+int rrtmg_lw_hip_run_columns(
+    int ncol, int nlayers, int istart, int iend, int icld, int idrv,
+    const double *pavel, const double *tavel, const double *pz, const double *tz, const double *tbound,
+    const double *semiss, const double *coldry, const double *wkl, const double *wbrodl, const double *wx,
+    const double *pwvcm, int inflag, int iceflag, int liqflag, const double *cldfrac, const double *tauc,
+    const double *ciwp, const double *clwp, const double *rei, const double *rel, const double *taua,
+    double *totuflux, double *totdflux, double *fnet, double *htr,
+    double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
+    double *dtotuflux_dt, double *dtotuclfl_dt)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(ncol, nlayers)) return rc;
+    if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
+    if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns handles at most one batch (%d columns)", G.batch);
+    const int mode = icld == 0 ? 0 : (icld == 1 ? 1 : 2);
+    if (int rc = ensure_workspace(nlayers, ncol, true)) return rc;
+    const size_t n = (size_t)ncol, L = (size_t)nlayers;
+    struct In { const double *h; size_t cnt; double *d; };
+    In ins[] = {{pavel, n * L, 0}, {tavel, n * L, 0}, {pz, n * (L + 1), 0}, {tz, n * (L + 1), 0}, {tbound, n, 0}, {semiss, 16 * n, 0},
+                {coldry, n * L, 0}, {wkl, 7 * n * L, 0}, {wbrodl, n * L, 0}, {wx, 4 * n * L, 0}, {pwvcm, n, 0}, {cldfrac, n * L, 0},
+                {tauc, 16 * n * L, 0}, {ciwp, n * L, 0}, {clwp, n * L, 0}, {rei, n * L, 0}, {rel, n * L, 0}, {taua, 16 * n * L, 0}};
+    size_t tot = 0;
+    for (auto &i : ins) tot += i.cnt;
+    const size_t out_d = 10 * n * (L + 1);
+    if (int rc = ensure_stage((tot + out_d) * 8 + 4096)) return rc;
+    double *p = (double *)G.stage_base;
+    hipStream_t s = G.stream;
+    for (auto &i : ins) {
+        i.d = p; p += i.cnt;
+        HIP_TRY(hipMemcpyAsync(i.d, i.h, i.cnt * 8, hipMemcpyHostToDevice, s));
+    }
+    double *o[10];
+    for (auto &q : o) { q = p; p += n * (L + 1); }
+    ColIn c{ins[0].d, ins[1].d, ins[2].d, ins[3].d, ins[4].d, ins[5].d, ins[6].d, ins[7].d, ins[8].d, ins[9].d, ins[10].d,
+            ins[11].d, ins[12].d, ins[13].d, ins[14].d, ins[15].d, ins[16].d, ins[17].d};
+    GcmIn g{};
+    // o: 0 uflx 1 dflx 2 fnet 3 htr 4 uclfl 5 dclfl 6 fnetc 7 htrc 8 duflx 9 duclfl ; htr arrays hold (ncol, 0:nlayers), top level = 0
+    HIP_TRY(hipMemsetAsync(o[3], 0, n * (L + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(o[7], 0, n * (L + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(o[8], 0, n * (L + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(o[9], 0, n * (L + 1) * 8, s));
+    FluxOut out{o[0], o[1], o[3], o[4], o[5], o[7], o[8], o[9], o[2], o[6]};
+    if (int rc = run_batch<false>(s, ncol, 0, ncol, nlayers, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out)) return rc;
+    double *ho[10] = {totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, dtotuflux_dt, dtotuclfl_dt};
+    for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(ho[k], o[k], n * (L + 1) * 8, hipMemcpyDeviceToHost, s));
+    return read_physics_error(s);
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure).  Built by __graft_entry__.build() / `make -C oracle liboracle.so`."""
+    from oracle.bindings import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library, initialised on cuda:0 with the stand-in k-data.  Fails loudly if it is not built."""
+    from rrtmg_lw_amd import api
+    api.rrtmg_lw_ini(1004.0, kdata=api.STANDIN_KDATA, device=0)
+    yield api
+    api.finalize()

@@ -1,0 +1,47 @@
+"""The C-ABI library must load on a machine without a GPU and export every symbol include/rrtmg_lw_hip.h declares;
+without a device every entry point must fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "rrtmg_lw_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rrtmg_lw_hip_\w+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from rrtmg_lw_amd import api
+    lib = api.lib()
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rrtmg_lw_hip.h but not exported"
+
+
+def test_no_device_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rrtmg_lw_amd import api
+    with pytest.raises(api.RrtmgLwError, match="no HIP device|ENODEVICE|error 3"):
+        api.rrtmg_lw_ini(1004.0, device=0)
+    lib = api.lib()
+    lib.rrtmg_lw_hip_last_error.restype = ctypes.c_char_p
+    assert lib.rrtmg_lw_hip_kdata_is_standin() == -1
+    assert lib.rrtmg_lw_hip_check(None) == 4          # RRTMG_LW_HIP_ENOTINIT
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import, load or link oracle/."""
+    pkg = os.path.join(ROOT, "rrtmg_lw_amd")
+    bad = re.compile(r"^\s*(from|import)\s+oracle\b|liboracle|libref_|#include\s+\"[^\"]*oracle", re.M)
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".f90", ".h")):
+                assert not bad.search(open(os.path.join(dp, f), errors="ignore").read()), (dp, f)

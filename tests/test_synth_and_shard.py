@@ -1,0 +1,100 @@
+"""Synthetic-input generator (numpy and torch backends agree, shards are reproducible) and the multi-GPU plumbing:
+column blocks + the packed output block reassembled by ONE all-gather, exercised with world_size 2 on gloo (CPU).
+The per-rank "compute" in the gloo test is the CPU oracle - the point is the sharding/packing/collective logic that
+bench.py uses over RCCL, not the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from rrtmg_lw_amd.shard import column_block, output_rows, output_views, unpack_gathered
+from rrtmg_lw_amd.synth import base_profile, make_gcm_inputs
+
+
+def test_base_profile_regrid():
+    p = base_profile(72)
+    assert p["plev"].shape == (73,) and abs(p["plev"][0] - 1013.0) < 1e-9 and abs(p["plev"][-1] - 0.067) < 1e-9
+    assert np.all(np.diff(p["plev"]) < 0) and np.all((p["play"] < p["plev"][:-1]) & (p["play"] > p["plev"][1:]))
+    assert 150 < p["tlay"].min() and p["tlay"].max() < 320 and p["vmr"].shape == (7, 72)
+
+
+@pytest.mark.parametrize("config", ["clear", "cloudy", "aer_idrv"])
+def test_numpy_and_torch_backends_agree(config):
+    import torch
+    a = make_gcm_inputs(37, 72, config, col0=123456)
+    b = make_gcm_inputs(37, 72, config, col0=123456, backend="torch", device=torch.device("cpu"))
+    for k, v in a.items():
+        if isinstance(v, np.ndarray):
+            t = b[k]
+            assert tuple(t.shape) == v.shape
+            assert np.array_equal(t.numpy(), v), k
+            # column index fastest in memory
+            assert t.stride()[0 if k != "taucld" else 1] in (1, 16), k
+    assert (a["icld"], a["idrv"]) == (b["icld"], b["idrv"])
+
+
+def test_shards_are_reproducible():
+    full = make_gcm_inputs(100, 40, "cloudy", col0=0)
+    part = make_gcm_inputs(30, 40, "cloudy", col0=50)
+    for k in ("tlay", "h2ovmr", "cldfr", "cliqwp", "tsfc", "emis"):
+        assert np.array_equal(full[k][50:80], part[k]), k
+    assert np.array_equal(full["taucld"][:, 50:80], part["taucld"])
+    assert (full["cldfr"].sum(axis=1) == 0).mean() > 0.15          # ~30 % of the columns are cloud-free
+
+
+def test_column_blocks_cover_everything():
+    for ncol, world in ((1000000, 8), (10, 4), (7, 8), (1, 1)):
+        seen = []
+        for r in range(world):
+            c0, n, per = column_block(ncol, world, r)
+            seen += list(range(c0, c0 + n))
+            assert n <= per
+        assert seen == list(range(ncol))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, ncol, nlay, q):
+    import torch
+    import torch.distributed as dist
+    from oracle.bindings import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    col0, n, per = column_block(ncol, world, rank)
+    d = make_gcm_inputs(n, nlay, "cloudy", col0=col0)
+    o = Oracle().rrtmg_lw(n, nlay, d["icld"], d["idrv"], d)
+    buf = torch.zeros((output_rows(nlay), per), dtype=torch.float64)
+    views = output_views(buf, nlay)
+    for k in ("uflx", "dflx", "uflxc", "dflxc", "hr", "hrc"):
+        views[k][:, :n] = torch.from_numpy(np.ascontiguousarray(o[k].T))
+    gathered = torch.empty((world * output_rows(nlay), per), dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, buf)
+    if rank == 0:
+        res = unpack_gathered(gathered.view(world, output_rows(nlay), per), nlay, ncol)
+        q.put({k: v.numpy() for k, v in res.items()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allgather_matches_single_process(oracle):
+    import torch.multiprocessing as mp
+    ncol, nlay, world = 22, 30, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, ncol, nlay, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=0)
+    ref = oracle.rrtmg_lw(ncol, nlay, d["icld"], d["idrv"], d)
+    for k in ("uflx", "dflx", "uflxc", "dflxc", "hr", "hrc"):
+        assert np.array_equal(got[k], ref[k]), k

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_*.npz: outputs of the REFERENCE's own Fortran (oracle/_ref, built from /root/reference
+by oracle/Makefile) on small seeded inputs with the stand-in k-tables.  Runs only in the build container (needs
+/root/reference for the flang build); the resulting arrays are data and travel with the repo so that
+tests/test_oracle_vs_ref.py can pin the C oracle on machines without the reference.
+
+Conventions of the reference build: flang -O2 -fdefault-real-8 -fdefault-double-8 -fdefault-integer-8 (the shipped
+makefiles' -r8 -i8), rtrnmr's faccmb* zero-initialised (the reference reads them uninitialised).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.bindings import Reference  # noqa: E402
+from rrtmg_lw_amd.io_rrtm import read_input_rrtm  # noqa: E402
+from rrtmg_lw_amd.synth import make_gcm_inputs  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+OUT_KEYS = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")
+GCM_CASES = [  # name, config, ncol, nlay, icld
+    ("clear72", "clear", 4, 72, 0), ("clear51_rtrn", "clear", 3, 51, 1), ("cloudy72_mr", "cloudy", 24, 72, 2),
+    ("cloudy72_rnd", "cloudy", 24, 72, 1), ("aer137", "aer_idrv", 8, 137, 2), ("aer40_rnd", "aer_idrv", 8, 40, 1),
+    ("cloudy72_icld9", "cloudy", 6, 72, 9),
+]
+COL_CASES = [  # name, input, cloud file, aerosol file
+    ("MLS-clr", "input_rrtm_MLS-clr", None, None), ("MLS-clr-aer12", "input_rrtm_MLS-clr-aer12", None, "in_aer_rrtm-aer12"),
+    ("MLS-clr-idrv1", "input_rrtm_MLS-clr-idrv1", None, None), ("MLS-clr-xsec", "input_rrtm_MLS-clr-xsec", None, None),
+    ("MLS-cld5-icld2", "input_rrtm_MLS-cld-imca0-icld2", "in_cld_rrtm-cld5", None),
+    ("MLS-cld7-icld2", "input_rrtm_MLS-cld-imca0-icld2", "in_cld_rrtm-cld7", None),
+    ("MLW-clr", "input_rrtm_MLW-clr", None, None), ("SAW-clr", "input_rrtm_SAW-clr", None, None), ("TROP-clr", "input_rrtm_TROP-clr", None, None),
+]
+
+
+def main():
+    ref = Reference("nomcica")
+    for name, cfg, ncol, nlay, icld in GCM_CASES:
+        d = make_gcm_inputs(ncol, nlay, cfg, col0=4242)
+        o = ref.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+        np.savez_compressed(os.path.join(G, f"ref_gcm_{name}.npz"), config=cfg, ncol=ncol, nlay=nlay, icld=icld, col0=4242,
+                            icld_out=o["icld"], **{k: o[k] for k in OUT_KEYS})
+    for name, inp, cld, aer in COL_CASES:
+        col = read_input_rrtm(os.path.join(G, inp), os.path.join(G, cld) if cld else None, os.path.join(G, aer) if aer else None)
+        if col["imca"] == 1:
+            col["imca"] = 0
+        o = ref.column(col)
+        bands = {}
+        if col["iout"] == 99:       # per-band blocks as the column driver produces them (istart = iend = band, iout = 99)
+            for b in (1, 3, 6, 8, 13, 16):
+                ob = ref.column(col, b, b, 99)
+                bands[f"b{b}_up"] = ob["totuflux"]
+                bands[f"b{b}_dn"] = ob["totdflux"]
+                bands[f"b{b}_htr"] = ob["htr"]
+        np.savez_compressed(os.path.join(G, f"ref_col_{name}.npz"), inp=inp, cld=cld or "", aer=aer or "",
+                            taug=o["taug"], fracs=o["fracs"], ncbands=o["ncbands"],
+                            **{k: o[k] for k in ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc",
+                                                 "dtotuflux_dt", "dtotuclfl_dt")}, **bands)
+    print("wrote fixtures to", G)
+
+
+if __name__ == "__main__":
+    main()
