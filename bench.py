@@ -186,7 +186,9 @@ def main():
             path = dict(kernels_ms_per_step=round(ktot / args.steps, 3), achieved=round(pach, 3), unit="GB/s",
                         frac=round(pach / HBM_PEAK_GBS, 5), bytes_per_column=bpc,
                         top=[dict(kernel=k, ms_per_step=round(v[1] / args.steps, 3)) for k, v in
-                             sorted(kern.items(), key=lambda kv: -kv[1][1])[:6]])
+                             sorted(kern.items(), key=lambda kv: -kv[1][1])[:6]],
+                        families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
+                                  for fam in ("k_colprep", "k_cloud", "k_layer", "k_sweep", "k_flux", "k_rates")})
             # PMC-derived HBM traffic of the dominant kernel, if a summary has been committed under profiles/
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):

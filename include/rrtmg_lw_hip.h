@@ -101,12 +101,11 @@ int rrtmg_lw_hip_run_columns(
     double *dtotuflux_dt, double *dtotuclfl_dt);
 
 /* Tuning / introspection ------------------------------------------------------------------------- */
-/* Columns processed per internal batch (bounds the device workspace); default 131072. */
+/* Columns processed per internal batch (bounds the device workspace); default 32768. */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
 /* Bytes of device workspace currently allocated. */
 long long rrtmg_lw_hip_workspace_bytes(void);
-/* Number of band-chunk kernels one column batch launches, and the name of chunk i's kernel
- * (for matching rocprofv3 kernel traces). */
+/* Number of g-point chunks the sweep kernel distributes over threads (one partial flux slab each). */
 int rrtmg_lw_hip_num_chunks(void);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py's roofline leg).

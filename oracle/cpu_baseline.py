@@ -52,4 +52,5 @@ def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None):
 
 if __name__ == "__main__":
     import json
-    print(json.dumps(measure(cols_per_core=int(sys.argv[1]) if len(sys.argv) > 1 else 2000)))
+    print(json.dumps(measure(cols_per_core=int(sys.argv[1]) if len(sys.argv) > 1 else 2000,
+                             cores=int(sys.argv[2]) if len(sys.argv) > 2 else None)))

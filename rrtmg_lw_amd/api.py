@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrtmg_lw_hip.so")
+LIB_PATH = os.environ.get("RRTMG_LW_HIP_LIB", os.path.join(_HERE, "librrtmg_lw_hip.so"))   # env override: tuning builds
 STATIC_BLOB = os.path.join(_HERE, "data", "lw_static.bin")
 STANDIN_KDATA = os.path.join(_HERE, "data", "standin.kdata.bin")
 REAL_KDATA = os.path.join(os.path.dirname(_HERE), "data", "rrtmg_lw.kdata.bin")

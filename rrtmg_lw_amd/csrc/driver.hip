@@ -16,16 +16,7 @@ namespace {
 
 using namespace rrlw;
 
-constexpr int NGCMAX = 8;
 constexpr int BLOCK = 256;
-
-struct Chunk { int band, ngc, g0; };
-// band chunks: even sizes and even starts keep every table row access 16-byte aligned
-const Chunk kChunks[] = {
-    {1, 6, 0}, {1, 4, 6}, {2, 6, 0}, {2, 6, 6}, {3, 8, 0}, {3, 8, 8}, {4, 8, 0}, {4, 6, 8}, {5, 8, 0}, {5, 8, 8},
-    {6, 8, 0}, {7, 6, 0}, {7, 6, 6}, {8, 8, 0}, {9, 6, 0}, {9, 6, 6}, {10, 6, 0}, {11, 8, 0}, {12, 8, 0},
-    {13, 4, 0}, {14, 2, 0}, {15, 2, 0}, {16, 2, 0}};
-constexpr int NCHUNK = sizeof(kChunks) / sizeof(kChunks[0]);
 
 struct State {
     bool init = false;
@@ -40,7 +31,7 @@ struct State {
     int ws_nlay = 0, ws_ncolb = 0;
     bool ws_cloud = false;
     int *d_err = nullptr;
-    int batch = 131072;
+    int batch = 32768;
     // host-entry staging
     void *stage_base = nullptr;
     size_t stage_bytes = 0;
@@ -118,27 +109,28 @@ int ensure_workspace(int nlay, int ncolb, bool cloud)
     const size_t n = (size_t)ncolb, L = (size_t)nlay;
     struct Item { void **p; size_t bytes; };
     Workspace &W = G.W;
+    W = Workspace{};
     std::vector<Item> items = {
-        {(void **)&W.f, (size_t)NFIELD * L * n * 8},
-        {(void **)&W.planklay, 16 * L * n * 8},
-        {(void **)&W.planklev, 16 * (L + 1) * n * 8},
         {(void **)&W.percol, (size_t)NPERCOL * n * 8},
-        {(void **)&W.scr[0], (size_t)NGCMAX * L * n * 8},
-        {(void **)&W.scr[1], (size_t)NGCMAX * L * n * 8},
-        {(void **)&W.idx, L * n * 4},
+        {(void **)&W.scr[S_ATR], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
+        {(void **)&W.scr[S_BBD], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
+        {(void **)&W.scr[S_BBU], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
+        {(void **)&W.rad0, (size_t)2 * NQUAD * 4 * n * 8},
+        {(void **)&W.pdn, (size_t)NQUAD * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.pup, (size_t)NQUAD * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.dpart, (size_t)NQUAD * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.laytrop, n * 4},
         {(void **)&W.ncbands, n * 4},
         {(void **)&W.cflag, (L + 2) * n * 4},
     };
     if (cloud) {
-        items.push_back({(void **)&W.scr[2], (size_t)NGCMAX * L * n * 8});
-        items.push_back({(void **)&W.scr[3], (size_t)NGCMAX * L * n * 8});
+        items.push_back({(void **)&W.scr[S_ATOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        items.push_back({(void **)&W.scr[S_BBDTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        items.push_back({(void **)&W.scr[S_BBUTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
         items.push_back({(void **)&W.taucloud, 16 * L * n * 8});
         items.push_back({(void **)&W.odcld, 16 * L * n * 8});
         items.push_back({(void **)&W.efcl, 16 * L * n * 8});
         items.push_back({(void **)&W.mrfac, (size_t)NMRFAC * (L + 2) * n * 8});
-    } else {
-        W.scr[2] = W.scr[3] = W.taucloud = W.odcld = W.efcl = W.mrfac = nullptr;
     }
     size_t total = 0;
     for (auto &it : items) total += align_up(it.bytes, 256);
@@ -155,40 +147,37 @@ int ensure_workspace(int nlay, int ncolb, bool cloud)
     return 0;
 }
 
-template <int MODE>
-void launch_chunks(hipStream_t s, int nb, int istart, int iend, BandArgs a, const FluxOut &out)
-{
-    const dim3 grid((nb + BLOCK - 1) / BLOCK), block(BLOCK);
-#define CH(B, NGC, G0)                                                                      \
-    if (B >= istart && B <= iend) {                                                         \
-        a.g0 = G0;                                                                          \
-        LAUNCH(MODE == 0 ? "k_band<" #B "," #NGC ",0>@g" #G0 : (MODE == 1 ? "k_band<" #B "," #NGC ",1>@g" #G0 : "k_band<" #B "," #NGC ",2>@g" #G0), \
-               (k_band<B, NGC, MODE>), grid, block, s, G.D, G.W, a, out);                   \
-    }
-    CH(1, 6, 0) CH(1, 4, 6) CH(2, 6, 0) CH(2, 6, 6) CH(3, 8, 0) CH(3, 8, 8) CH(4, 8, 0) CH(4, 6, 8) CH(5, 8, 0) CH(5, 8, 8)
-    CH(6, 8, 0) CH(7, 6, 0) CH(7, 6, 6) CH(8, 8, 0) CH(9, 6, 0) CH(9, 6, 6) CH(10, 6, 0) CH(11, 8, 0) CH(12, 8, 0)
-    CH(13, 4, 0) CH(14, 2, 0) CH(15, 2, 0) CH(16, 2, 0)
-#undef CH
-}
-
 // one column batch, everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr
 template <bool GCM>
 int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
               const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out)
 {
     const dim3 grid((nb + BLOCK - 1) / BLOCK), block(BLOCK);
-    LAUNCH("k_prep", (k_prep<GCM>), grid, block, s, G.D, G.W, g, c, out, nb, col0, nct, idrv, istart);
+    LAUNCH("k_colprep", (k_colprep<GCM>), grid, block, s, G.D, G.W, g, c, nb, col0, nct, idrv, istart);
     if (mode != 0)
         LAUNCH("k_cloud", (k_cloud<GCM>), grid, block, s, G.D, G.W, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
-    BandArgs a;
-    a.ncol = nb; a.col0 = col0; a.nct = nct; a.g0 = 0; a.idrv = idrv;
-    a.emis = GCM ? g.emis : c.semiss;
-    a.tauaer = GCM ? g.tauaer : c.taua;
-    a.cldfrac = GCM ? g.cldfr : c.cldfrac;
-    if (mode == 0) launch_chunks<0>(s, nb, istart, iend, a, out);
-    else if (mode == 1) launch_chunks<1>(s, nb, istart, iend, a, out);
-    else launch_chunks<2>(s, nb, istart, iend, a, out);
-    LAUNCH("k_final", k_final, grid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct, nlay, idrv, mode == 0 ? 1 : 0);
+    LayerArgs la;
+    la.ncol = nb; la.col0 = col0; la.nct = nct; la.idrv = idrv; la.istart = istart; la.iend = iend;
+    la.ktab_bytes = (int)(G.H.ktab.size() * 8);
+    la.tauaer = GCM ? g.tauaer : c.taua;
+    const unsigned gx = (nb + BLOCK - 1) / BLOCK;
+    const dim3 lgrid(gx, nlay);
+#define LAYER_GROUP(GR)                                                                                              \
+    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, false, GR>), lgrid, block, s, G.D, G.W, g, c, la);     \
+    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, true, GR>), lgrid, block, s, G.D, G.W, g, c, la);
+    LAYER_GROUP(0) LAYER_GROUP(1) LAYER_GROUP(2) LAYER_GROUP(3) LAYER_GROUP(4) LAYER_GROUP(5)
+#undef LAYER_GROUP
+    SweepArgs sa;
+    sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
+    sa.emis = GCM ? g.emis : c.semiss;
+    sa.cldfrac = GCM ? g.cldfr : c.cldfrac;
+    const dim3 sgrid(gx, NQUAD);
+    if (mode == 0) LAUNCH("k_sweep<0>", (k_sweep<0>), sgrid, block, s, G.D, G.W, sa);
+    else if (mode == 1) LAUNCH("k_sweep<1>", (k_sweep<1>), sgrid, block, s, G.D, G.W, sa);
+    else LAUNCH("k_sweep<2>", (k_sweep<2>), sgrid, block, s, G.D, G.W, sa);
+    const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
+    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, G.W, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);
+    LAUNCH("k_rates", k_rates, rgrid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -263,6 +252,7 @@ int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, do
     D.absice0[0] = G.H.absice0[0]; D.absice0[1] = G.H.absice0[1];
     D.abscld1 = G.H.abscld1; D.absliq0 = G.H.absliq0;
     D.heatfac = G.H.heatfac; D.fluxfac = G.H.fluxfac; D.oneminus = G.H.oneminus; D.bpade = G.H.bpade;
+    if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; }
     G.device = device;
     G.init = true;
     G.err.clear();
@@ -293,7 +283,7 @@ int rrtmg_lw_hip_set_batch(int ncol_batch)
 }
 
 long long rrtmg_lw_hip_workspace_bytes(void) { return (long long)(G.ws_bytes + G.stage_bytes); }
-int rrtmg_lw_hip_num_chunks(void) { return NCHUNK; }
+int rrtmg_lw_hip_num_chunks(void) { return NQUAD; }
 
 void rrtmg_lw_hip_profile_begin(void)
 {

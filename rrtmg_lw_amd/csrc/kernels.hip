@@ -2,16 +2,19 @@
 //
 // Mapping (DESIGN.md "Kernels"): the caller's arrays are (ncol, nlay) with the COLUMN index fastest
 // (reference: src/rrtmg_lw_rad.nomcica.f90:219-276), so lanes = consecutive columns makes every load and
-// store of profile, workspace, scratch and flux data a full-width coalesced access.  Spectral work is
-// split into "band chunks": one thread owns NGC (2..8) consecutive g-points of one band for one column and
-// keeps their optical depths, Planck fractions and radiances in registers, so the g-point reduction of the
-// fluxes is an in-register sum in the reference's own order and needs no cross-lane traffic.
+// store of profile, scratch and flux data a full-width coalesced access.  The work is split where the
+// reference's data dependence allows it:
 //
-//   k_prep   inatm + setcoef (+ Planck sources, diffusivity secants)          1 thread / column
-//   k_cloud  cldprop + cloud-overlap factors of rtrnmr                         1 thread / column
-//   k_band   taumol for the chunk's g-points fused with the rtrn/rtrnmr down- and up-sweeps
-//                                                                              1 thread / (column, chunk)
-//   k_final  flux scaling, net flux, heating rates                            1 thread / column
+//   k_colprep  per-column scalars: laytrop, precipitable water -> diffusivity secants, surface Planck
+//              terms                                                    1 thread / column
+//   k_cloud    cldprop + cloud-overlap factors of rtrnmr (serial in the vertical)
+//                                                                       1 thread / column
+//   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for all 16 bands / 140 g-points,
+//              then each cell's transmittance and Planck sources (the exp/LUT part of rtrn)
+//                                                                       1 thread / (column, layer)
+//   k_sweep    the only vertically serial part: the down/up recurrences of rtrn / rtrnmr, streaming the
+//              per-cell terms written by k_layer                        1 thread / (column, g-chunk)
+//   k_final    band-chunk partial fluxes -> fluxes, net flux, heating rates   1 thread / column
 //
 // Reference lines are cited per routine.  No CPU fallback exists anywhere in this file.
 #include <hip/hip_runtime.h>
@@ -34,7 +37,7 @@ struct DevTables {
     double heatfac, fluxfac, oneminus, bpade;
 };
 
-// per-(layer, column) double fields of the workspace, each [nlay][ncolb]
+// setcoef quantities of one (layer, column) - indices into LayerCoef::f
 enum Field {
     F_FAC00, F_FAC01, F_FAC10, F_FAC11,
     F_COLH2O, F_COLCO2, F_COLO3, F_COLN2O, F_COLCO, F_COLCH4, F_COLO2, F_COLBRD,
@@ -47,14 +50,21 @@ enum PerCol { PC_PLANKBND = 0, PC_DPLANKBND = 16, PC_SECDIFF = 32, NPERCOL = 48 
 // rtrnmr overlap factors, each [(nlay+2)][ncolb], level index 0..nlay+1
 enum MrFac { MR_FACCLD1, MR_FACCLD2, MR_FACCLR1, MR_FACCLR2, MR_FACCMB1, MR_FACCMB2,
              MR_FACCLD1D, MR_FACCLD2D, MR_FACCLR1D, MR_FACCLR2D, MR_FACCMB1D, MR_FACCMB2D, NMRFAC };
+// per-cell terms handed from k_layer to k_sweep, each [NQUAD][nlay][ncolb][4]
+enum Scr { S_ATR, S_BBD, S_BBU, S_ATOT, S_BBDTOT, S_BBUTOT, NSCR };
+// per-quad partial fluxes, each [quad][level][column] of {total-sky, clear-sky}: downward, upward, d(upward)/dT
+struct alignas(16) Part2 { double a, b; };
+
+// storage type of the per-cell terms handed from k_layer to k_sweep (all arithmetic stays float64)
+#ifdef RRLW_SCR_DOUBLE
+typedef double scr_t;
+#else
+typedef float scr_t;     // measured on MI355X: max |dflux| vs the oracle 6.66e-6 W m-2 (6.55e-6 with double), |dhr| unchanged
+#endif
 
 struct Workspace {
     int ncolb;          // column stride (batch capacity)
     int nlay;
-    double *f;          // [NFIELD][nlay][ncolb]
-    int *idx;           // [nlay][ncolb]   jp | jt<<6 | jt1<<9 | indself<<12 | indfor<<16 | indminor<<18
-    double *planklay;   // [16][nlay][ncolb]
-    double *planklev;   // [16][nlay+1][ncolb]
     double *percol;     // [NPERCOL][ncolb]
     int *laytrop;       // [ncolb]
     int *ncbands;       // [ncolb]
@@ -63,7 +73,10 @@ struct Workspace {
     double *efcl;       // [16][nlay][ncolb]   rtrn: (1 - exp(-odcld)) * cldfrac
     double *mrfac;      // [NMRFAC][nlay+2][ncolb]
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcld, bit2 istcldd; cflag[0] bit3 = column has cloud
-    double *scr[4];     // [NGCMAX][nlay][ncolb]: atrans, bbugas, atot, bbutot
+    scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
+    double *rad0;       // [2][4*NQUAD][ncolb]  fracs(1,g)*plankbnd, fracs(1,g)*dplankbnd_dt
+    Part2 *pdn, *pup;   // [NQUAD][nlay+1][ncolb]
+    Part2 *dpart;       // [NQUAD][nlay+1][ncolb]  (idrv = 1)
     int *err;           // [1] first physics error code
 };
 
@@ -85,196 +98,65 @@ struct FluxOut {
 
 enum ErrCode { E_NONE = 0, E_ICE_SMALL = 1, E_ICE_BOUNDS = 2, E_ICE_GEN_BOUNDS = 3, E_LIQ_BOUNDS = 4, E_BAD_FLAG = 5 };
 
-#define WS_F(F, lev) W.f[((size_t)(F) * W.nlay + ((lev)-1)) * W.ncolb + col]
-
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------------------
-// k_prep : inatm (src/rrtmg_lw_rad.nomcica.f90:591-919) + setcoef (src/rrtmg_lw_setcoef.f90:50-434)
-//          + secdiff (src/rrtmg_lw_rtrn.f90:280-288); also zeroes the flux accumulators.
+// k_colprep : the per-column reductions of inatm (src/rrtmg_lw_rad.nomcica.f90:785-870: amttl, wvttl ->
+//             pwvcm), setcoef's laytrop count and surface Planck terms (src/rrtmg_lw_setcoef.f90:173-215,
+//             :312-313) and the diffusivity secants (src/rrtmg_lw_rtrn.f90:265-288).
 // ------------------------------------------------------------------------------------------------
 template <bool GCM>
-__global__ __launch_bounds__(256) void k_prep(DevTables T, Workspace W, GcmIn g, ColIn c, FluxOut out, int ncol, int col0,
-                                              int nct, int idrv, int istart)
+__global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int idrv, int istart)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
-    const size_t gc = (size_t)col0 + col;       // index into caller arrays
+    const size_t gc = (size_t)col0 + col;
     const int nlay = W.nlay;
     const double *S = T.stat;
     const double *totplnk = S + T.sl.totplnk, *totplnkd = S + T.sl.totplnkderiv;
     const double *totplk16 = S + T.sl.totplk16, *totplk16d = S + T.sl.totplk16deriv;
-    const double *preflog = S + T.sl.preflog, *tref = S + T.sl.tref;
-
     const double amd = 28.9660, amw = 18.0160, avogad = 6.02214199e+23, grav = 9.8066;
-    const double stpfac = 296. / 1013.;
 
-    double tbound, pz0, tz0, pwvcm = 0.0;
-    double semiss[NBND];
-    if (GCM) {
-        tbound = g.tsfc[gc];
-        pz0 = g.plev[gc];
-        tz0 = g.tlev[gc];
-#pragma unroll
-        for (int b = 0; b < NBND; b++) semiss[b] = g.emis[gc + (size_t)nct * b];
-    } else {
-        tbound = c.tbound[gc];
-        pz0 = c.pz[gc];
-        tz0 = c.tz[gc];
-        pwvcm = c.pwvcm[gc];
-#pragma unroll
-        for (int b = 0; b < NBND; b++) semiss[b] = c.semiss[gc + (size_t)nct * b];
-    }
-
-    // surface / level-0 Planck terms: setcoef :173-215
+    const double tbound = GCM ? g.tsfc[gc] : c.tbound[gc];
+    const double pz0 = GCM ? g.plev[gc] : c.pz[gc];
     const int indbound = clampi((int)(tbound - 159.), 1, 180);
     const double tbndfrac = tbound - 159. - (double)indbound;
-    const int indlev0 = clampi((int)(tz0 - 159.), 1, 180);
-    const double t0frac = tz0 - 159. - (double)indlev0;
 #pragma unroll
     for (int b = 0; b < NBND; b++) {
-        const double *tp = totplnk + 181 * b;
-        double pb, pl0, dpb = 0.0;
-        if (b == 15 && istart == 16) {      // :233-247 (band 16 alone: 2600-3250 cm-1 table; level 0 mixes tables)
-            pb = semiss[b] * (totplk16[indbound - 1] + tbndfrac * (totplk16[indbound] - totplk16[indbound - 1]));
-            if (idrv == 1) dpb = semiss[b] * (totplk16d[indbound - 1] + tbndfrac * (totplk16d[indbound] - totplk16d[indbound - 1]));
-            pl0 = totplk16[indlev0 - 1] + t0frac * (tp[indlev0] - tp[indlev0 - 1]);
-        } else {
-            pb = semiss[b] * (tp[indbound - 1] + tbndfrac * (tp[indbound] - tp[indbound - 1]));
-            if (idrv == 1) {
-                const double *td = totplnkd + 181 * b;
-                dpb = semiss[b] * (td[indbound - 1] + tbndfrac * (td[indbound] - td[indbound - 1]));
-            }
-            pl0 = tp[indlev0 - 1] + t0frac * (tp[indlev0] - tp[indlev0 - 1]);
-        }
+        const double semiss = GCM ? g.emis[gc + (size_t)nct * b] : c.semiss[gc + (size_t)nct * b];
+        const double *tp = (b == 15 && istart == 16) ? totplk16 : totplnk + 181 * b;        // :233-242
+        const double *td = (b == 15 && istart == 16) ? totplk16d : totplnkd + 181 * b;
+        const double pb = semiss * (tp[indbound - 1] + tbndfrac * (tp[indbound] - tp[indbound - 1]));
+        double dpb = 0.0;
+        if (idrv == 1) dpb = semiss * (td[indbound - 1] + tbndfrac * (td[indbound] - td[indbound - 1]));
         W.percol[(size_t)(PC_PLANKBND + b) * W.ncolb + col] = pb;
         W.percol[(size_t)(PC_DPLANKBND + b) * W.ncolb + col] = dpb;
-        W.planklev[((size_t)b * (nlay + 1) + 0) * W.ncolb + col] = pl0;
     }
-
-    double amttl = 0.0, wvttl = 0.0;
-    double pzlo = pz0;
+    double amttl = 0.0, wvttl = 0.0, pzlo = pz0;
     int laytrop = 0;
     for (int lay = 1; lay <= nlay; lay++) {
         const size_t gi = gc + (size_t)nct * (lay - 1);
-        double pavel, tavel, tzl, coldry, wbrodl, w1, w2, w3, w4, w5, w6, w7, x1, x2, x3, x4;
+        const double pavel = GCM ? g.play[gi] : c.pavel[gi];
+        if (!(log(pavel) <= 4.56)) laytrop++;
         if (GCM) {
-            // inatm :785-870
-            pavel = g.play[gi];
-            tavel = g.tlay[gi];
+            const double w1v = g.h2ovmr[gi];
             const double pzl = g.plev[gc + (size_t)nct * lay];
-            tzl = g.tlev[gc + (size_t)nct * lay];
-            w1 = g.h2ovmr[gi]; w2 = g.co2vmr[gi]; w3 = g.o3vmr[gi]; w4 = g.n2ovmr[gi];
-            w5 = 0.0; w6 = g.ch4vmr[gi]; w7 = g.o2vmr[gi];
-            const double amm = (1. - w1) * amd + w1 * amw;
-            coldry = (pzlo - pzl) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + w1));
+            const double amm = (1. - w1v) * amd + w1v * amw;
+            const double coldry = (pzlo - pzl) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + w1v));
             pzlo = pzl;
-            double summol = 0.0;
-            summol = summol + w2; summol = summol + w3; summol = summol + w4;
-            summol = summol + w5; summol = summol + w6; summol = summol + w7;
-            wbrodl = coldry * (1. - summol);
-            w1 = coldry * w1; w2 = coldry * w2; w3 = coldry * w3; w4 = coldry * w4;
-            w5 = coldry * w5; w6 = coldry * w6; w7 = coldry * w7;
+            const double w1 = coldry * w1v;
             amttl = amttl + coldry + w1;
             wvttl = wvttl + w1;
-            x1 = coldry * g.ccl4vmr[gi] * 1.e-20;
-            x2 = coldry * g.cfc11vmr[gi] * 1.e-20;
-            x3 = coldry * g.cfc12vmr[gi] * 1.e-20;
-            x4 = coldry * g.cfc22vmr[gi] * 1.e-20;
-        } else {
-            pavel = c.pavel[gi];
-            tavel = c.tavel[gi];
-            tzl = c.tz[gc + (size_t)nct * lay];
-            coldry = c.coldry[gi];
-            wbrodl = c.wbrodl[gi];
-            const size_t wi = gc + (size_t)nct * 7 * (lay - 1);       // wkl (ncol,7,nlayers)
-            w1 = c.wkl[wi]; w2 = c.wkl[wi + (size_t)nct]; w3 = c.wkl[wi + (size_t)nct * 2];
-            w4 = c.wkl[wi + (size_t)nct * 3]; w5 = c.wkl[wi + (size_t)nct * 4]; w6 = c.wkl[wi + (size_t)nct * 5];
-            w7 = c.wkl[wi + (size_t)nct * 6];
-            const size_t xi = gc + (size_t)nct * 4 * (lay - 1);       // wx (ncol,4,nlayers)
-            x1 = c.wx[xi]; x2 = c.wx[xi + (size_t)nct]; x3 = c.wx[xi + (size_t)nct * 2]; x4 = c.wx[xi + (size_t)nct * 3];
         }
-
-        // Planck functions at layer and level temperatures: setcoef :189-269
-        const int indlay = clampi((int)(tavel - 159.), 1, 180);
-        const double tlayfrac = tavel - 159. - (double)indlay;
-        const int indlev = clampi((int)(tzl - 159.), 1, 180);
-        const double tlevfrac = tzl - 159. - (double)indlev;
-#pragma unroll
-        for (int b = 0; b < NBND; b++) {
-            const double *tp = (b == 15 && istart == 16) ? totplk16 : totplnk + 181 * b;
-            W.planklay[((size_t)b * nlay + (lay - 1)) * W.ncolb + col] = tp[indlay - 1] + tlayfrac * (tp[indlay] - tp[indlay - 1]);
-            W.planklev[((size_t)b * (nlay + 1) + lay) * W.ncolb + col] = tp[indlev - 1] + tlevfrac * (tp[indlev] - tp[indlev - 1]);
-        }
-
-        // pressure / temperature interpolation: setcoef :276-306
-        const double plog = log(pavel);
-        const int jp = clampi((int)(36. - 5 * (plog + 0.04)), 1, 58);
-        const double fp = 5. * (preflog[jp - 1] - plog);
-        const int jt = clampi((int)(3. + (tavel - tref[jp - 1]) / 15.), 1, 4);
-        const double ft = ((tavel - tref[jp - 1]) / 15.) - (double)(jt - 3);
-        const int jt1 = clampi((int)(3. + (tavel - tref[jp]) / 15.), 1, 4);
-        const double ft1 = ((tavel - tref[jp]) / 15.) - (double)(jt1 - 3);
-        const double water = w1 / coldry;
-        const double scalefac = pavel * stpfac / tavel;
-        int indself = 0, indfor, indminor;
-        double forfac, forfrac, selffac, selffrac = 0.0, factor;
-        if (!(plog <= 4.56)) {            // :312-334
-            laytrop++;
-            forfac = scalefac / (1. + water);
-            factor = (332.0 - tavel) / 36.0;
-            indfor = min(2, max(1, (int)factor));
-            forfrac = factor - (double)indfor;
-            selffac = water * forfac;
-            factor = (tavel - 188.0) / 7.2;
-            indself = min(9, max(1, (int)factor - 7));
-            selffrac = factor - (double)(indself + 7);
-        } else {                          // :369-377
-            forfac = scalefac / (1. + water);
-            factor = (tavel - 188.0) / 36.0;
-            indfor = 3;
-            forfrac = factor - 1.0;
-            selffac = water * forfac;
-        }
-        const double scaleminor = pavel / tavel;
-        const double scaleminorn2 = (pavel / tavel) * (wbrodl / (coldry + w1));
-        factor = (tavel - 180.8) / 7.2;
-        indminor = min(18, max(1, (int)factor));
-        const double minorfrac = factor - (double)indminor;
-
-        double colh2o = 1.e-20 * w1, colco2 = 1.e-20 * w2, colo3 = 1.e-20 * w3, coln2o = 1.e-20 * w4;
-        double colco = 1.e-20 * w5, colch4 = 1.e-20 * w6, colo2 = 1.e-20 * w7;
-        if (colco2 == 0.) colco2 = 1.e-32 * coldry;
-        if (colo3 == 0.) colo3 = 1.e-32 * coldry;
-        if (coln2o == 0.) coln2o = 1.e-32 * coldry;
-        if (colco == 0.) colco = 1.e-32 * coldry;
-        if (colch4 == 0.) colch4 = 1.e-32 * coldry;
-        const double colbrd = 1.e-20 * wbrodl;
-        const double compfp = 1. - fp;     // :421-429
-        WS_F(F_FAC10, lay) = compfp * ft;
-        WS_F(F_FAC00, lay) = compfp * (1. - ft);
-        WS_F(F_FAC11, lay) = fp * ft1;
-        WS_F(F_FAC01, lay) = fp * (1. - ft1);
-        WS_F(F_SELFFAC, lay) = colh2o * selffac;
-        WS_F(F_FORFAC, lay) = colh2o * forfac;
-        WS_F(F_SELFFRAC, lay) = selffrac;
-        WS_F(F_FORFRAC, lay) = forfrac;
-        WS_F(F_MINORFRAC, lay) = minorfrac;
-        WS_F(F_SCALEMINOR, lay) = scaleminor;
-        WS_F(F_SCALEMINORN2, lay) = scaleminorn2;
-        WS_F(F_COLH2O, lay) = colh2o; WS_F(F_COLCO2, lay) = colco2; WS_F(F_COLO3, lay) = colo3;
-        WS_F(F_COLN2O, lay) = coln2o; WS_F(F_COLCO, lay) = colco; WS_F(F_COLCH4, lay) = colch4;
-        WS_F(F_COLO2, lay) = colo2; WS_F(F_COLBRD, lay) = colbrd; WS_F(F_COLDRY, lay) = coldry;
-        WS_F(F_PAVEL, lay) = pavel;
-        WS_F(F_WX1, lay) = x1; WS_F(F_WX2, lay) = x2; WS_F(F_WX3, lay) = x3; WS_F(F_WX4, lay) = x4;
-        W.idx[(size_t)(lay - 1) * W.ncolb + col] = jp | (jt << 6) | (jt1 << 9) | (indself << 12) | (indfor << 16) | (indminor << 18);
     }
     W.laytrop[col] = laytrop;
+    double pwvcm;
     if (GCM) {
-        const double wvsh = (amw * wvttl) / (amd * amttl);      // inatm :869-870
+        const double wvsh = (amw * wvttl) / (amd * amttl);
         pwvcm = wvsh * (1.e3 * pz0) / (1.e2 * grav);
+    } else {
+        pwvcm = c.pwvcm[gc];
     }
-    // diffusivity secants: rtrn :265-288
     const double a0[16] = {1.66, 1.55, 1.58, 1.66, 1.54, 1.454, 1.89, 1.33, 1.668, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66};
     const double a1[16] = {0.00, 0.25, 0.22, 0.00, 0.13, 0.446, -0.10, 0.40, -0.006, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
     const double a2[16] = {0.00, -12.0, -11.7, 0.00, -0.72, -0.243, 0.19, -0.062, 0.414, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
@@ -290,12 +172,6 @@ __global__ __launch_bounds__(256) void k_prep(DevTables T, Workspace W, GcmIn g,
     }
     W.ncbands[col] = 1;
     W.cflag[col] = 0;
-    // flux accumulators
-    for (int lev = 0; lev <= nlay; lev++) {
-        const size_t o = gc + (size_t)nct * lev;
-        out.uflx[o] = 0.0; out.dflx[o] = 0.0; out.uflxc[o] = 0.0; out.dflxc[o] = 0.0;
-        if (idrv == 1) { out.duflx_dt[o] = 0.0; out.duflxc_dt[o] = 0.0; }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,43 +548,14 @@ BAND_TRAITS(16, 2,
     R1(K_SINGLE, CH4, 0, 0, false, false, -1, false, 0, {NOM, NOM, NOM}, 0, {0, 0}, C_NONE, 0))
 #undef R1
 
-__device__ const double kMult4[14] = {1, 1, 1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.88, 0.943};   // taumol :1028-1034
-__device__ const double kMult7[12] = {1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.855, 1};             // taumol :1664-1669
+__device__ const double kMult4[16] = {1, 1, 1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.88, 0.943, 1, 1};   // taumol :1028-1034
+__device__ const double kMult7[12] = {1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.855, 1};                  // taumol :1664-1669
 
-// load NGC consecutive doubles (16-byte aligned when NGC is even: rows have even length and g0 is even)
-template <int NGC>
-__device__ __forceinline__ void ldrow(const double *__restrict__ p, double (&v)[NGC])
-{
-    if constexpr (NGC % 2 == 0) {
-        const double2 *q = reinterpret_cast<const double2 *>(p);
-#pragma unroll
-        for (int j = 0; j < NGC / 2; j++) { const double2 t = q[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NGC; j++) v[j] = p[j];
-    }
-}
-
-// acc[j] = first ? w * row[j] : acc[j] + w * row[j]
-template <int NGC>
-__device__ __forceinline__ void axpy(double (&acc)[NGC], double w, const double *__restrict__ row, bool first)
-{
-    double v[NGC];
-    ldrow<NGC>(row, v);
-#pragma unroll
-    for (int j = 0; j < NGC; j++) acc[j] = first ? w * v[j] : acc[j] + w * v[j];
-}
-
-// out[j] = r0[j] + frac * (r1[j] - r0[j]),  r1 = r0 + stride
-template <int NGC>
-__device__ __forceinline__ void lerp_rows(double (&o)[NGC], const double *__restrict__ r0, int stride, double frac)
-{
-    double a[NGC], b[NGC];
-    ldrow<NGC>(r0, a);
-    ldrow<NGC>(r0 + stride, b);
-#pragma unroll
-    for (int j = 0; j < NGC; j++) o[j] = a[j] + frac * (b[j] - a[j]);
-}
+// setcoef results of one (layer, column), kept in registers by k_layer
+struct LayerCoef {
+    double f[NFIELD];
+    int jp, jt, jt1, indself, indfor, indminor;
+};
 
 struct Spec { double speccomb, specparm, fs; int js; };
 __device__ __forceinline__ Spec spec_calc(double cola, double rat, double colb, double mult, double oneminus)
@@ -743,199 +590,240 @@ __device__ __forceinline__ void stencil6(double specparm, double fs, double fa, 
     }
 }
 
-// Gaseous optical depth and Planck fraction of NGC g-points (g0 .. g0+NGC-1 of band B) for one layer.
-template <int B, int NGC, bool LOWER>
-__device__ __forceinline__ void taumol_layer(const DevTables &T, const Workspace &W, int lay, int col, int g0, int packed,
-                                             double (&tau)[NGC], double (&frac)[NGC])
+// ------------------------------------------------------------------------------------------------
+// taumol as a sparse linear combination.  For one (layer, column) and band, the gaseous optical depth of
+// every g-point is   tau(g) = sum_i  w_i * K[off_i + g]   over a handful of table rows: the P/T(/mixture)
+// interpolation stencil of the key species, the two self- and two foreign-continuum rows, 2 or 4 rows per
+// minor gas, one row per halocarbon (src/rrtmg_lw_taumol.f90:299-3164).  rows_prep
+// turns the layer's setcoef quantities into the (off_i, w_i) list once; rows_eval then needs only the g-offset.
+// The weights are algebraically those of the reference (e.g. selffac*(1-selffrac), selffac*selffrac for
+// selffac*(s0 + selffrac*(s1-s0))); products are associated differently, i.e. results differ at rounding level.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int region_nrows(const Region &R, bool lower)
+{
+    int n = 0;
+    if (R.key == K_SINGLE) n += 4;
+    else if (R.key == K_BINARY) n += lower ? 12 : 8;
+    if (R.self_) n += 2;
+    if (R.for_) n += 2;
+    for (int i = 0; i < R.nm; i++) n += R.m[i].two_d ? 4 : 2;
+    n += R.ncfc;
+    return n;
+}
+
+__host__ __device__ constexpr int region_major_rows(const Region &R, bool lower)
+{
+    return R.key == K_SINGLE ? 4 : (R.key == K_BINARY ? (lower ? 12 : 8) : 0);
+}
+__host__ __device__ constexpr int region_minor_base(const Region &R, bool lower, int im)
+{
+    int n = region_major_rows(R, lower) + (R.self_ ? 2 : 0) + (R.for_ ? 2 : 0);
+    for (int i = 0; i < im; i++) n += R.m[i].two_d ? 4 : 2;
+    return n;
+}
+
+template <int N>
+struct Rows {
+    unsigned off[N > 0 ? N : 1];   // element offsets into the packed k-table buffer (row start, g = 0)
+    double w[N > 0 ? N : 1];
+    unsigned foff;                 // Planck-fraction row
+    double fpl;                    // interpolation weight to the next fraction row (binary-key regions)
+};
+
+// one minor gas: rows IBASE.. of the list
+template <int B, bool LOWER, int N, int IM>
+__device__ __forceinline__ void rows_prep_minor(const DevTables &T, const LayerCoef &C, Rows<N> &rw)
 {
     constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
-    constexpr int ng = BT<B>::ng;
+    constexpr unsigned ng = BT<B>::ng;
+    constexpr Minor M = R.m[IM];
+    constexpr int I0 = region_minor_base(R, LOWER, IM);
+    const BandLayout &L = T.band[B - 1];
+    const double mf = C.f[F_MINORFRAC];
+    double amount;
+    if constexpr (M.amt == A_COL) amount = C.f[F_COLH2O + M.sp];
+    else if constexpr (M.amt == A_BRD_N2) amount = C.f[F_COLBRD] * C.f[F_SCALEMINORN2];
+    else if constexpr (M.amt == A_O2) amount = C.f[F_COLO2] * C.f[F_SCALEMINOR];
+    else if constexpr (M.amt == A_BRD) amount = C.f[F_COLBRD] * C.f[F_SCALEMINOR];
+    else {                                              // A_ADJ: taumol :547-554
+        const double colx = C.f[F_COLH2O + M.sp], coldry = C.f[F_COLDRY];
+        const double chiref = M.chiconst > 0. ? M.chiconst : (T.stat + T.sl.chi)[M.sp * 59 + C.jp];     // chi_mls(sp+1, jp+1)
+        const double chi = colx / coldry;
+        const double ratx = 1.e20 * chi / chiref;
+        amount = colx;
+        if (ratx > M.thr) amount = (M.base + pow(ratx - M.base, M.expo)) * chiref * coldry * 1.e-20;
+    }
+    const unsigned slot = (unsigned)(LOWER ? L.minor_lo[IM] : L.minor_up[IM]);
+    if constexpr (M.two_d) {                            // taumol :635-639
+        constexpr unsigned nj = LOWER ? 9 : 5;
+        const Spec sm = spec_calc(C.f[F_COLH2O + R.a], T.refrat[B - 1][M.refslot], C.f[F_COLH2O + R.b], LOWER ? 8. : 4., T.oneminus);
+        const unsigned r = slot + ((unsigned)(C.indminor - 1) * nj + (unsigned)(sm.js - 1)) * ng;
+        rw.off[I0] = r;                    rw.w[I0] = amount * ((1. - mf) * (1. - sm.fs));
+        rw.off[I0 + 1] = r + ng;           rw.w[I0 + 1] = amount * ((1. - mf) * sm.fs);
+        rw.off[I0 + 2] = r + nj * ng;      rw.w[I0 + 2] = amount * (mf * (1. - sm.fs));
+        rw.off[I0 + 3] = r + nj * ng + ng; rw.w[I0 + 3] = amount * (mf * sm.fs);
+    } else {
+        const unsigned r = slot + (unsigned)(C.indminor - 1) * ng;
+        rw.off[I0] = r;          rw.w[I0] = amount * (1. - mf);
+        rw.off[I0 + 1] = r + ng; rw.w[I0 + 1] = amount * mf;
+    }
+}
+
+template <int B, bool LOWER, int N>
+__device__ __forceinline__ void rows_prep(const DevTables &T, const LayerCoef &C, Rows<N> &rw)
+{
+    constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
+    constexpr unsigned ng = BT<B>::ng;
+    const BandLayout &L = T.band[B - 1];
+    const int jp = C.jp, jt = C.jt, jt1 = C.jt1;
+    const double *rat_tab = T.stat + T.sl.rat;
+    rw.foff = (unsigned)((LOWER || R.frac_from_a) ? L.fracrefa : L.fracrefb);
+    rw.fpl = 0.0;
+    if constexpr (R.key == K_ZERO) return;
+
+    double corradj = 1.;
+    if constexpr (R.corr == C_B1LO) { if (C.f[F_PAVEL] < 250.) corradj = 1. - 0.15 * (250. - C.f[F_PAVEL]) / 154.4; }
+    else if constexpr (R.corr == C_B1UP) corradj = 1. - 0.15 * (C.f[F_PAVEL] / 95.6);
+    else if constexpr (R.corr == C_B2LO) corradj = 1. - .05 * (C.f[F_PAVEL] - 100.) / 900.;
+
+    if constexpr (R.key == K_SINGLE) {                      // taumol :356-360
+        const unsigned r0 = LOWER ? ((jp - 1) * 5 + (jt - 1)) : ((jp - 13) * 5 + (jt - 1));
+        const unsigned r1 = LOWER ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
+        const unsigned tab = (unsigned)(LOWER ? L.absa : L.absb);
+        const double colk = C.f[F_COLH2O + R.a];
+        rw.off[0] = tab + r0 * ng;       rw.w[0] = colk * C.f[F_FAC00];
+        rw.off[1] = tab + (r0 + 1) * ng; rw.w[1] = colk * C.f[F_FAC10];
+        rw.off[2] = tab + r1 * ng;       rw.w[2] = colk * C.f[F_FAC01];
+        rw.off[3] = tab + (r1 + 1) * ng; rw.w[3] = colk * C.f[F_FAC11];
+    } else if constexpr (R.key == K_BINARY) {
+        const double cola = C.f[F_COLH2O + R.a], colb = C.f[F_COLH2O + R.b];
+        const double rat = rat_tab[R.rat * 59 + (jp - 1)], rat_1 = rat_tab[R.rat * 59 + jp];
+        constexpr double mult = LOWER ? 8. : 4.;
+        const Spec s = spec_calc(cola, rat, colb, mult, T.oneminus);
+        const Spec s1 = spec_calc(cola, rat_1, colb, mult, T.oneminus);
+        if constexpr (LOWER) {                              // taumol :563-663
+            const unsigned tab = (unsigned)L.absa;
+            const int ind0 = ((jp - 1) * 5 + (jt - 1)) * 9 + s.js - 1;      // 0-based row
+            const int ind1 = (jp * 5 + (jt1 - 1)) * 9 + s1.js - 1;
+            int so;
+            double w6[6];
+            stencil6(s.specparm, s.fs, C.f[F_FAC00], C.f[F_FAC10], so, w6);
+            unsigned r = tab + (unsigned)(ind0 + so) * ng;
+            rw.off[0] = r;           rw.w[0] = s.speccomb * w6[0];
+            rw.off[1] = r + ng;      rw.w[1] = s.speccomb * w6[1];
+            rw.off[2] = r + 2 * ng;  rw.w[2] = s.speccomb * w6[2];
+            rw.off[3] = r + 9 * ng;  rw.w[3] = s.speccomb * w6[3];
+            rw.off[4] = r + 10 * ng; rw.w[4] = s.speccomb * w6[4];
+            rw.off[5] = r + 11 * ng; rw.w[5] = s.speccomb * w6[5];
+            stencil6(s1.specparm, s1.fs, C.f[F_FAC01], C.f[F_FAC11], so, w6);
+            r = tab + (unsigned)(ind1 + so) * ng;
+            rw.off[6] = r;            rw.w[6] = s1.speccomb * w6[0];
+            rw.off[7] = r + ng;       rw.w[7] = s1.speccomb * w6[1];
+            rw.off[8] = r + 2 * ng;   rw.w[8] = s1.speccomb * w6[2];
+            rw.off[9] = r + 9 * ng;   rw.w[9] = s1.speccomb * w6[3];
+            rw.off[10] = r + 10 * ng; rw.w[10] = s1.speccomb * w6[4];
+            rw.off[11] = r + 11 * ng; rw.w[11] = s1.speccomb * w6[5];
+        } else {                                            // taumol :749-771
+            const unsigned tab = (unsigned)L.absb;
+            const unsigned ind0 = ((jp - 13) * 5 + (jt - 1)) * 5 + s.js - 1;
+            const unsigned ind1 = ((jp - 12) * 5 + (jt1 - 1)) * 5 + s1.js - 1;
+            unsigned r = tab + ind0 * ng;
+            rw.off[0] = r;          rw.w[0] = s.speccomb * ((1. - s.fs) * C.f[F_FAC00]);
+            rw.off[1] = r + ng;     rw.w[1] = s.speccomb * (s.fs * C.f[F_FAC00]);
+            rw.off[2] = r + 5 * ng; rw.w[2] = s.speccomb * ((1. - s.fs) * C.f[F_FAC10]);
+            rw.off[3] = r + 6 * ng; rw.w[3] = s.speccomb * (s.fs * C.f[F_FAC10]);
+            r = tab + ind1 * ng;
+            rw.off[4] = r;          rw.w[4] = s1.speccomb * ((1. - s1.fs) * C.f[F_FAC01]);
+            rw.off[5] = r + ng;     rw.w[5] = s1.speccomb * (s1.fs * C.f[F_FAC01]);
+            rw.off[6] = r + 5 * ng; rw.w[6] = s1.speccomb * ((1. - s1.fs) * C.f[F_FAC11]);
+            rw.off[7] = r + 6 * ng; rw.w[7] = s1.speccomb * (s1.fs * C.f[F_FAC11]);
+        }
+        // Planck fractions interpolated in the mixture: taumol :556-561, :692-693
+        const Spec sp = spec_calc(cola, T.refrat[B - 1][R.planck_slot], colb, mult, T.oneminus);
+        rw.foff += (unsigned)(sp.js - 1) * ng;
+        rw.fpl = sp.fs;
+    }
+    constexpr int IS = region_major_rows(R, LOWER);
+    if constexpr (R.self_) {                                // taumol :350-351
+        const unsigned r = (unsigned)L.selfref + (unsigned)(C.indself - 1) * ng;
+        rw.off[IS] = r;          rw.w[IS] = C.f[F_SELFFAC] * (1. - C.f[F_SELFFRAC]);
+        rw.off[IS + 1] = r + ng; rw.w[IS + 1] = C.f[F_SELFFAC] * C.f[F_SELFFRAC];
+    }
+    constexpr int IF = IS + (R.self_ ? 2 : 0);
+    if constexpr (R.for_) {                                 // taumol :352-353
+        const unsigned r = (unsigned)L.forref + (unsigned)(C.indfor - 1) * ng;
+        rw.off[IF] = r;          rw.w[IF] = C.f[F_FORFAC] * (1. - C.f[F_FORFRAC]);
+        rw.off[IF + 1] = r + ng; rw.w[IF + 1] = C.f[F_FORFAC] * C.f[F_FORFRAC];
+    }
+    if constexpr (R.nm > 0) rows_prep_minor<B, LOWER, N, 0>(T, C, rw);
+    if constexpr (R.nm > 1) rows_prep_minor<B, LOWER, N, 1>(T, C, rw);
+    if constexpr (R.nm > 2) rows_prep_minor<B, LOWER, N, 2>(T, C, rw);
+    constexpr int IC = region_minor_base(R, LOWER, R.nm);   // halocarbons: taumol :1254, :1381-1382, :1753-1754
+    if constexpr (R.ncfc > 0) { rw.off[IC] = (unsigned)L.vec[0]; rw.w[IC] = C.f[F_WX1 + R.cfc_wx[0] - 1]; }
+    if constexpr (R.ncfc > 1) { rw.off[IC + 1] = (unsigned)L.vec[1]; rw.w[IC + 1] = C.f[F_WX1 + R.cfc_wx[1] - 1]; }
+    static_assert(IC + R.ncfc == N, "row count");
+    if constexpr (R.corr != C_NONE) {
+#pragma unroll
+        for (int i = 0; i < N; i++) rw.w[i] = corradj * rw.w[i];
+    }
+}
+
+// 16-byte table load through a buffer descriptor: 32-bit per-lane byte offset, no 64-bit address arithmetic,
+// and the hardware range check returns zeros for anything outside the table buffer.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned elem_off)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(elem_off * 8u), 0, 0);
+    double2 d;
+    __builtin_memcpy(&d, &v, 16);
+    return d;
+}
+
+// tau and Planck fraction of the four g-points g0..g0+3 of band B
+template <int B, bool LOWER, int N>
+__device__ __forceinline__ void rows_eval(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, unsigned g0, double (&tau)[4], double (&frac)[4])
+{
+    constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
+    constexpr unsigned ng = BT<B>::ng;
     if constexpr (R.key == K_ZERO) {
 #pragma unroll
-        for (int j = 0; j < NGC; j++) { tau[j] = 0.0; frac[j] = 0.0; }
+        for (int j = 0; j < 4; j++) { tau[j] = 0.0; frac[j] = 0.0; }
         return;
     } else {
-        const BandLayout &L = T.band[B - 1];
-        const double *__restrict__ kt = T.ktab + g0;
-        const int jp = packed & 63, jt = (packed >> 6) & 7, jt1 = (packed >> 9) & 7;
-        const int indself = (packed >> 12) & 15, indfor = (packed >> 16) & 3, indminor = (packed >> 18) & 31;
-        const double minorfrac = (R.nm > 0) ? WS_F(F_MINORFRAC, lay) : 0.0;
-        const double *rat_tab = T.stat + T.sl.rat;
-        const double *chi_tab = T.stat + T.sl.chi;
-
-        // ---- key species --------------------------------------------------------------------------------
-        if constexpr (R.key == K_SINGLE) {
-            const double fac00 = WS_F(F_FAC00, lay), fac01 = WS_F(F_FAC01, lay), fac10 = WS_F(F_FAC10, lay), fac11 = WS_F(F_FAC11, lay);
-            const int r0 = LOWER ? ((jp - 1) * 5 + (jt - 1)) : ((jp - 13) * 5 + (jt - 1));
-            const int r1 = LOWER ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
-            const double *tab = kt + (LOWER ? L.absa : L.absb);
-            double acc[NGC];
-            axpy<NGC>(acc, fac00, tab + (size_t)r0 * ng, true);
-            axpy<NGC>(acc, fac10, tab + (size_t)(r0 + 1) * ng, false);
-            axpy<NGC>(acc, fac01, tab + (size_t)r1 * ng, false);
-            axpy<NGC>(acc, fac11, tab + (size_t)(r1 + 1) * ng, false);
-            const double colk = WS_F(F_COLH2O + R.a, lay);
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = colk * acc[j];
-        } else if constexpr (R.key == K_BINARY) {
-            const double fac00 = WS_F(F_FAC00, lay), fac01 = WS_F(F_FAC01, lay), fac10 = WS_F(F_FAC10, lay), fac11 = WS_F(F_FAC11, lay);
-            const double cola = WS_F(F_COLH2O + R.a, lay), colb = WS_F(F_COLH2O + R.b, lay);
-            const double rat = rat_tab[R.rat * 59 + (jp - 1)], rat_1 = rat_tab[R.rat * 59 + jp];
-            constexpr double mult = LOWER ? 8. : 4.;
-            const Spec s = spec_calc(cola, rat, colb, mult, T.oneminus);
-            const Spec s1 = spec_calc(cola, rat_1, colb, mult, T.oneminus);
-            double acc[NGC];
-            if constexpr (LOWER) {
-                const double *tab = kt + L.absa;
-                const int ind0 = ((jp - 1) * 5 + (jt - 1)) * 9 + s.js - 1;      // 0-based row
-                const int ind1 = (jp * 5 + (jt1 - 1)) * 9 + s1.js - 1;
-                int off;
-                double w[6];
-                stencil6(s.specparm, s.fs, fac00, fac10, off, w);
-                const double *r = tab + (size_t)(ind0 + off) * ng;
-                axpy<NGC>(acc, w[0], r, true);
-                axpy<NGC>(acc, w[1], r + ng, false);
-                axpy<NGC>(acc, w[2], r + 2 * ng, false);
-                axpy<NGC>(acc, w[3], r + 9 * ng, false);
-                axpy<NGC>(acc, w[4], r + 10 * ng, false);
-                axpy<NGC>(acc, w[5], r + 11 * ng, false);
-#pragma unroll
-                for (int j = 0; j < NGC; j++) tau[j] = s.speccomb * acc[j];
-                stencil6(s1.specparm, s1.fs, fac01, fac11, off, w);
-                r = tab + (size_t)(ind1 + off) * ng;
-                axpy<NGC>(acc, w[0], r, true);
-                axpy<NGC>(acc, w[1], r + ng, false);
-                axpy<NGC>(acc, w[2], r + 2 * ng, false);
-                axpy<NGC>(acc, w[3], r + 9 * ng, false);
-                axpy<NGC>(acc, w[4], r + 10 * ng, false);
-                axpy<NGC>(acc, w[5], r + 11 * ng, false);
-#pragma unroll
-                for (int j = 0; j < NGC; j++) tau[j] = tau[j] + s1.speccomb * acc[j];
-            } else {                                                              // taumol :751-771
-                const double *tab = kt + L.absb;
-                const int ind0 = ((jp - 13) * 5 + (jt - 1)) * 5 + s.js - 1;
-                const int ind1 = ((jp - 12) * 5 + (jt1 - 1)) * 5 + s1.js - 1;
-                const double *r = tab + (size_t)ind0 * ng;
-                axpy<NGC>(acc, (1. - s.fs) * fac00, r, true);
-                axpy<NGC>(acc, s.fs * fac00, r + ng, false);
-                axpy<NGC>(acc, (1. - s.fs) * fac10, r + 5 * ng, false);
-                axpy<NGC>(acc, s.fs * fac10, r + 6 * ng, false);
-#pragma unroll
-                for (int j = 0; j < NGC; j++) tau[j] = s.speccomb * acc[j];
-                r = tab + (size_t)ind1 * ng;
-                axpy<NGC>(acc, (1. - s1.fs) * fac01, r, true);
-                axpy<NGC>(acc, s1.fs * fac01, r + ng, false);
-                axpy<NGC>(acc, (1. - s1.fs) * fac11, r + 5 * ng, false);
-                axpy<NGC>(acc, s1.fs * fac11, r + 6 * ng, false);
-#pragma unroll
-                for (int j = 0; j < NGC; j++) tau[j] = tau[j] + s1.speccomb * acc[j];
-            }
-            // Planck fractions interpolated in the mixture: taumol :556-561, :692-693
-            const Spec sp = spec_calc(cola, T.refrat[B - 1][R.planck_slot], colb, mult, T.oneminus);
-            lerp_rows<NGC>(frac, kt + (LOWER ? L.fracrefa : L.fracrefb) + (size_t)(sp.js - 1) * ng, ng, sp.fs);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = 0.0;
+        for (int i = 0; i < N; i++) {
+            const double2 a = ld2(kt, rw.off[i] + g0), b = ld2(kt, rw.off[i] + g0 + 2);
+            acc[0] = acc[0] + rw.w[i] * a.x; acc[1] = acc[1] + rw.w[i] * a.y;
+            acc[2] = acc[2] + rw.w[i] * b.x; acc[3] = acc[3] + rw.w[i] * b.y;
         }
-        if constexpr (R.key != K_BINARY) {
-            ldrow<NGC>(kt + ((LOWER || R.frac_from_a) ? L.fracrefa : L.fracrefb), frac);
+        const double2 fa = ld2(kt, rw.foff + g0), fb = ld2(kt, rw.foff + g0 + 2);
+        frac[0] = fa.x; frac[1] = fa.y; frac[2] = fb.x; frac[3] = fb.y;
+        if constexpr (R.key == K_BINARY) {
+            const double2 ga = ld2(kt, rw.foff + ng + g0), gb = ld2(kt, rw.foff + ng + g0 + 2);
+            frac[0] = frac[0] + rw.fpl * (ga.x - frac[0]); frac[1] = frac[1] + rw.fpl * (ga.y - frac[1]);
+            frac[2] = frac[2] + rw.fpl * (gb.x - frac[2]); frac[3] = frac[3] + rw.fpl * (gb.y - frac[3]);
         }
-
-        // ---- water-vapour continua: taumol :350-353 -------------------------------------------------------
-        if constexpr (R.self_) {
-            double t[NGC];
-            lerp_rows<NGC>(t, kt + L.selfref + (size_t)(indself - 1) * ng, ng, WS_F(F_SELFFRAC, lay));
-            const double selffac = WS_F(F_SELFFAC, lay);
 #pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = tau[j] + selffac * t[j];
-        }
-        if constexpr (R.for_) {
-            double t[NGC];
-            lerp_rows<NGC>(t, kt + L.forref + (size_t)(indfor - 1) * ng, ng, WS_F(F_FORFRAC, lay));
-            const double forfac = WS_F(F_FORFAC, lay);
-#pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = tau[j] + forfac * t[j];
-        }
-
-        // ---- minor gases ---------------------------------------------------------------------------------------
-#pragma unroll
-        for (int im = 0; im < R.nm; im++) {
-            constexpr int dummy = 0; (void)dummy;
-            const Minor M = R.m[im];
-            double amount;
-            if (M.amt == A_COL) amount = WS_F(F_COLH2O + M.sp, lay);
-            else if (M.amt == A_BRD_N2) amount = WS_F(F_COLBRD, lay) * WS_F(F_SCALEMINORN2, lay);
-            else if (M.amt == A_O2) amount = WS_F(F_COLO2, lay) * WS_F(F_SCALEMINOR, lay);
-            else if (M.amt == A_BRD) amount = WS_F(F_COLBRD, lay) * WS_F(F_SCALEMINOR, lay);
-            else {                                                       // A_ADJ: taumol :547-554
-                const double colx = WS_F(F_COLH2O + M.sp, lay), coldry = WS_F(F_COLDRY, lay);
-                const double chiref = M.chiconst > 0. ? M.chiconst : chi_tab[M.sp * 59 + jp];     // chi_mls(sp+1, jp+1)
-                const double chi = colx / coldry;
-                const double ratx = 1.e20 * chi / chiref;
-                amount = colx;
-                if (ratx > M.thr) amount = (M.base + pow(ratx - M.base, M.expo)) * chiref * coldry * 1.e-20;
-            }
-            const int slot = LOWER ? L.minor_lo[im] : L.minor_up[im];
-            double ab[NGC];
-            if (M.two_d) {                                               // taumol :635-639
-                constexpr int nj = LOWER ? 9 : 5;
-                const Spec sm = spec_calc(WS_F(F_COLH2O + R.a, lay), T.refrat[B - 1][M.refslot], WS_F(F_COLH2O + R.b, lay), LOWER ? 8. : 4., T.oneminus);
-                const double *r = kt + slot + (size_t)((indminor - 1) * nj + (sm.js - 1)) * ng;
-                double m1[NGC], m2[NGC];
-                lerp_rows<NGC>(m1, r, ng, sm.fs);
-                lerp_rows<NGC>(m2, r + (size_t)nj * ng, ng, sm.fs);
-#pragma unroll
-                for (int j = 0; j < NGC; j++) ab[j] = m1[j] + minorfrac * (m2[j] - m1[j]);
-            } else {
-                lerp_rows<NGC>(ab, kt + slot + (size_t)(indminor - 1) * ng, ng, minorfrac);
-            }
-#pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = tau[j] + amount * ab[j];
-        }
-
-        // ---- halocarbons: taumol :1254, :1381-1382, :1753-1754 ---------------------------------------------------------
-#pragma unroll
-        for (int ic = 0; ic < R.ncfc; ic++) {
-            const double wxv = WS_F(F_WX1 + R.cfc_wx[ic] - 1, lay);
-            double v[NGC];
-            ldrow<NGC>(kt + L.vec[ic], v);
-#pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = tau[j] + wxv * v[j];
-        }
-
-        if constexpr (R.corr != C_NONE) {
-            const double pp = WS_F(F_PAVEL, lay);
-            double corradj = 1.;
-            if constexpr (R.corr == C_B1LO) { if (pp < 250.) corradj = 1. - 0.15 * (250. - pp) / 154.4; }
-            else if constexpr (R.corr == C_B1UP) corradj = 1. - 0.15 * (pp / 95.6);
-            else corradj = 1. - .05 * (pp - 100.) / 900.;
-#pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = corradj * tau[j];
-        }
-        if constexpr (R.mult == 4) {
-#pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = tau[j] * kMult4[g0 + j];
-        } else if constexpr (R.mult == 7) {
-#pragma unroll
-            for (int j = 0; j < NGC; j++) tau[j] = tau[j] * kMult7[g0 + j];
+        for (int j = 0; j < 4; j++) {
+            tau[j] = acc[j];
+            if constexpr (R.mult == 4) tau[j] = tau[j] * kMult4[g0 + j];
+            else if constexpr (R.mult == 7) tau[j] = tau[j] * kMult7[g0 + j];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_band : taumol fused with the radiative-transfer sweeps.
-//   MODE 0 clear column set (icld = 0, or cloud-free call): rtrn/rtrnmr clear branch
-//   MODE 1 rtrn   (random overlap)            src/rrtmg_lw_rtrn.f90:339-574
-//   MODE 2 rtrnmr (maximum-random overlap)    src/rrtmg_lw_rtrnmr.f90:510-775
-// Per-(layer, g) quantities needed again by the up-sweep go through `scr` ([j][lay][col], coalesced).
-// Band fluxes are added to the caller's flux arrays (zeroed by k_prep); chunk kernels run in stream order
-// so the additions are deterministic and follow the reference's band order.
+// k_layer : for one (column, layer):  inatm's layer part (src/rrtmg_lw_rad.nomcica.f90:785-867), setcoef
+//           (src/rrtmg_lw_setcoef.f90:189-429), taumol for all bands (src/rrtmg_lw_taumol.f90:299-3164), taut = taug +
+//           taua (src/rrtmg_lw_rad.nomcica.f90:527-539) and, per g-point, the layer's transmittance and Planck source
+//           terms - the part of rtrn's sweep body that does not depend on the incoming radiance
+//           (src/rrtmg_lw_rtrn.f90:362-451).  Results go to the [g][layer][column] scratch arrays.
 // ------------------------------------------------------------------------------------------------
-struct BandArgs {
-    int ncol, col0, nct, g0, idrv;
-    const double *emis;        // semiss (nct,16)
-    const double *tauaer;      // (nct,nlay,16) or null
-    const double *cldfrac;     // (nct,nlay)
+struct LayerArgs {
+    int ncol, col0, nct, idrv, istart, iend;
+    int ktab_bytes;            // size of the packed k-table buffer (buffer descriptor range)
+    const double *tauaer;      // (nct,nlay,16)
 };
 
 __device__ __forceinline__ void gas_layer(double od, const double *__restrict__ lut, double bpade, double &atrans, double &tfn)
@@ -952,24 +840,354 @@ __device__ __forceinline__ void gas_layer(double od, const double *__restrict__ 
     }
 }
 
-template <int B, int NGC, int MODE>
-__global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs a, FluxOut out)
+// g-point "quads": every band is padded to a multiple of 4 g-points; quad q of the 38 holds g-points
+// QG0(band) + 4*(q - QSTART(band)) ... +3 of one band.  Scratch arrays are [array][quad][layer][column][4].
+__host__ __device__ constexpr int band_ng(int B) { return B == 1 ? 10 : B == 2 ? 12 : B == 3 ? 16 : B == 4 ? 14 : B == 5 ? 16 : B == 6 ? 8 : B == 7 ? 12 :
+                                                    B == 8 ? 8 : B == 9 ? 12 : B == 10 ? 6 : B == 11 ? 8 : B == 12 ? 8 : B == 13 ? 4 : 2; }
+__host__ __device__ constexpr int band_nquad(int B) { return (band_ng(B) + 3) / 4; }
+__host__ __device__ constexpr int band_qstart(int B)     // not recursive: a recursive constexpr function that is not folded becomes a
+{                                                       // real device call with a dynamic stack
+    int s = 0;
+    for (int b = 1; b < B; b++) s += band_nquad(b);
+    return s;
+}
+constexpr int NQUAD = band_qstart(17);      // 38
+static_assert(NQUAD == 38, "quad table");
+
+struct alignas(16) scr4 { scr_t v[4]; };
+
+// cells of quad `qi` (g-points 4*qi .. 4*qi+3 of band B) of one (layer, column)
+template <int B, bool CLOUD, bool LOWER, int N>
+__device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, int qi, int lay, int col,
+                                          double blay, double dplankup, double dplankdn, double secdiff, double taua,
+                                          int cloudy, double odcld, double pb, double dpb, bool idrv)
+{
+    constexpr int ng = BT<B>::ng;
+    const int nlay = W.nlay;
+    const size_t ncb = W.ncolb;
+    const int g0 = 4 * qi;
+    double tau[4], frac[4];
+    rows_eval<B, LOWER, N>(kt, rw, (unsigned)g0, tau, frac);
+    const double *S = T.stat;
+    const double *__restrict__ lut = S + T.sl.lut;
+    const double bpade = T.bpade;
+    constexpr int QS = band_qstart(B);
+    const int quad = QS + qi;
+    if (lay == 1) {               // surface emission seeds: rtrn :476-479
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool valid = g0 + j < ng;
+            W.rad0[(size_t)(quad * 4 + j) * ncb + col] = valid ? frac[j] * pb : 0.0;
+            if (idrv) W.rad0[(size_t)(4 * NQUAD + quad * 4 + j) * ncb + col] = valid ? frac[j] * dpb : 0.0;
+        }
+    }
+    scr4 oatr, obbd, obbu, oatot, obbdt, obbut;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool valid = g0 + j < ng;          // padding lanes of a band's last quad carry zeros
+        double od = secdiff * (tau[j] + taua);
+        if (!(od >= 0.0) || !valid) od = 0.0;
+        const double fr = valid ? frac[j] : 0.0;
+        if (!(CLOUD && cloudy)) {
+            double atr, tfn;
+            gas_layer(od, lut, bpade, atr, tfn);
+            oatr.v[j] = (scr_t)atr;
+            obbd.v[j] = (scr_t)(fr * (blay + tfn * dplankdn));
+            obbu.v[j] = (scr_t)(fr * (blay + tfn * dplankup));
+        } else {
+            // cloudy layer, three sub-branches: rtrn :372-435
+            double odtot = od + odcld;
+            double atr, tfgas, atot, tftot;
+            if (odtot < 0.06) {
+                atr = od - 0.5 * od * od; tfgas = 0.166667 * od;
+                atot = odtot - 0.5 * odtot * odtot; tftot = 0.166667 * odtot;
+            } else if (od <= 0.06) {
+                atr = od - 0.5 * od * od; tfgas = 0.166667 * od;
+                const int it = (int)(10000.0 * (odtot / (bpade + odtot)) + 0.5);
+                const double2 e = reinterpret_cast<const double2 *>(lut)[it];
+                atot = 1. - e.x; tftot = e.y;
+            } else {
+                const int ig = (int)(10000.0 * (od / (bpade + od)) + 0.5);
+                const double2 e = reinterpret_cast<const double2 *>(lut)[ig];
+                od = (S + T.sl.tau_tbl)[ig];
+                atr = 1. - e.x; tfgas = e.y;
+                odtot = od + odcld;
+                const int it = (int)(10000.0 * (odtot / (bpade + odtot)) + 0.5);
+                const double2 e2 = reinterpret_cast<const double2 *>(lut)[it];
+                atot = 1. - e2.x; tftot = e2.y;
+            }
+            oatr.v[j] = (scr_t)atr;
+            obbd.v[j] = (scr_t)(fr * (blay + tfgas * dplankdn));
+            obbu.v[j] = (scr_t)(fr * (blay + tfgas * dplankup));
+            oatot.v[j] = (scr_t)atot;
+            obbdt.v[j] = (scr_t)(fr * (blay + tftot * dplankdn));
+            obbut.v[j] = (scr_t)(fr * (blay + tftot * dplankup));
+        }
+    }
+    const size_t so = ((size_t)quad * nlay + (lay - 1)) * ncb + col;
+    reinterpret_cast<scr4 *>(W.scr[S_ATR])[so] = oatr;
+    reinterpret_cast<scr4 *>(W.scr[S_BBD])[so] = obbd;
+    reinterpret_cast<scr4 *>(W.scr[S_BBU])[so] = obbu;
+    if (CLOUD && cloudy) {
+        reinterpret_cast<scr4 *>(W.scr[S_ATOT])[so] = oatot;
+        reinterpret_cast<scr4 *>(W.scr[S_BBDTOT])[so] = obbdt;
+        reinterpret_cast<scr4 *>(W.scr[S_BBUTOT])[so] = obbut;
+    }
+}
+
+#ifndef RRLW_LAYER_WAVES
+#define RRLW_LAYER_WAVES 1        // waves per SIMD k_layer is compiled for; measured: 1 (no spills, deep ILP) beats 2 (25.9 vs 29.0 ms / 262144 columns)
+#endif
+
+// all quads of band B for one (layer, column)
+template <int B, bool CLOUD>
+__device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
+                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, size_t gc, int indlay, double tlayfrac,
+                                           int indhi, double thifrac, int indlo, double tlofrac, int cloudy, int ncbands)
+{
+    const size_t ncb = W.ncolb;
+    const int nlay = W.nlay, nct = a.nct;
+    const double *S = T.stat;
+    double odcld = 0.0;
+    if (CLOUD) {
+        if (cloudy) {
+            const int ibc = ncbands == 1 ? 0 : (ncbands == 5 ? (B <= 2 ? B - 1 : (B <= 5 ? 2 : (B <= 8 ? 3 : 4))) : B - 1);   // rtrn :343-349
+            odcld = W.odcld[((size_t)ibc * nlay + (lay - 1)) * ncb + col];
+        }
+    }
+    // Planck functions of the layer and of its two interfaces: setcoef :203-269
+    const bool alt16 = (B == 16 && a.istart == 16);
+    const double *tp = alt16 ? S + T.sl.totplk16 : S + T.sl.totplnk + 181 * (B - 1);
+    const double blay = tp[indlay - 1] + tlayfrac * (tp[indlay] - tp[indlay - 1]);
+    const double plev_hi = tp[indhi - 1] + thifrac * (tp[indhi] - tp[indhi - 1]);
+    double plev_lo;
+    if (alt16 && lay == 1) {       // :244-246: level 0 mixes the two tables when band 16 runs alone
+        const double *tq = S + T.sl.totplnk + 181 * 15;
+        plev_lo = tp[indlo - 1] + tlofrac * (tq[indlo] - tq[indlo - 1]);
+    } else {
+        plev_lo = tp[indlo - 1] + tlofrac * (tp[indlo] - tp[indlo - 1]);
+    }
+    const double dplankup = plev_hi - blay, dplankdn = plev_lo - blay;
+    const double secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
+    const double taua = a.tauaer[gc + (size_t)nct * ((lay - 1) + (size_t)nlay * (B - 1))];
+    double pb = 0.0, dpb = 0.0;
+    if (lay == 1) {
+        pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + col];
+        dpb = W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + col];
+    }
+    const bool idrv = a.idrv == 1;
+    if (lower) {
+        constexpr int N = region_nrows(BT<B>::lo, true);
+        Rows<N> rw;
+        rows_prep<B, true, N>(T, C, rw);
+#pragma unroll 1
+        for (int qi = 0; qi < band_nquad(B); qi++)
+            band_quad<B, CLOUD, true, N>(T, W, kt, rw, qi, lay, col, blay, dplankup, dplankdn, secdiff, taua, cloudy, odcld, pb, dpb, idrv);
+    } else {
+        constexpr int N = region_nrows(BT<B>::up, false);
+        Rows<N> rw;
+        rows_prep<B, false, N>(T, C, rw);
+#pragma unroll 1
+        for (int qi = 0; qi < band_nquad(B); qi++)
+            band_quad<B, CLOUD, false, N>(T, W, kt, rw, qi, lay, col, blay, dplankup, dplankdn, secdiff, taua, cloudy, odcld, pb, dpb, idrv);
+    }
+}
+
+
+// band groups: one k_layer launch covers the bands of one group; its threads do the inatm/setcoef prologue once
+//   0: 3,14   1: 5,15   2: 4,10,16   3: 7,8   4: 9,11,13   5: 1,2,6,12
+constexpr int NLGROUP = 6;
+
+template <bool GCM, bool CLOUD, int GROUP>
+__global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
+    const int lay = blockIdx.y + 1;
     const size_t gc = (size_t)a.col0 + col;
-    const int nlay = W.nlay, nct = a.nct, g0 = a.g0;
-    const size_t ncb = W.ncolb;
-    const double *__restrict__ lut = T.stat + T.sl.lut;
-    const double *__restrict__ tau_tbl = T.stat + T.sl.tau_tbl;
-    const double bpade = T.bpade;
-    const double secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
-    const double wtdelw = T.delwave[B - 1];
-    const int laytrop = W.laytrop[col];
-    const bool idrv = a.idrv == 1;
-    double *__restrict__ sA = W.scr[0], *__restrict__ sB = W.scr[1], *__restrict__ sC = W.scr[2], *__restrict__ sD = W.scr[3];
+    const int nct = a.nct;
+    const size_t gi = gc + (size_t)nct * (lay - 1);
+    const double *S = T.stat;
+    const double *preflog = S + T.sl.preflog, *tref = S + T.sl.tref;
+    const double amd = 28.9660, amw = 18.0160, avogad = 6.02214199e+23, grav = 9.8066;
+    const double stpfac = 296. / 1013.;
 
-    int ibc = 0;                    // 0-based cloud band for this spectral band: rtrn :343-349
+    double pavel, tavel, tz_lo, tz_hi, coldry, wbrodl, w1, w2, w3, w4, w5, w6, w7;
+    LayerCoef C;
+    if (GCM) {
+        pavel = g.play[gi];
+        tavel = g.tlay[gi];
+        const double pz_lo = g.plev[gi], pz_hi = g.plev[gc + (size_t)nct * lay];
+        tz_lo = g.tlev[gi];
+        tz_hi = g.tlev[gc + (size_t)nct * lay];
+        w1 = g.h2ovmr[gi]; w2 = g.co2vmr[gi]; w3 = g.o3vmr[gi]; w4 = g.n2ovmr[gi];
+        w5 = 0.0; w6 = g.ch4vmr[gi]; w7 = g.o2vmr[gi];
+        const double amm = (1. - w1) * amd + w1 * amw;
+        coldry = (pz_lo - pz_hi) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + w1));
+        double summol = 0.0;
+        summol = summol + w2; summol = summol + w3; summol = summol + w4;
+        summol = summol + w5; summol = summol + w6; summol = summol + w7;
+        wbrodl = coldry * (1. - summol);
+        w1 = coldry * w1; w2 = coldry * w2; w3 = coldry * w3; w4 = coldry * w4;
+        w5 = coldry * w5; w6 = coldry * w6; w7 = coldry * w7;
+        C.f[F_WX1] = coldry * g.ccl4vmr[gi] * 1.e-20;
+        C.f[F_WX2] = coldry * g.cfc11vmr[gi] * 1.e-20;
+        C.f[F_WX3] = coldry * g.cfc12vmr[gi] * 1.e-20;
+        C.f[F_WX4] = coldry * g.cfc22vmr[gi] * 1.e-20;
+    } else {
+        pavel = c.pavel[gi];
+        tavel = c.tavel[gi];
+        tz_lo = c.tz[gi];
+        tz_hi = c.tz[gc + (size_t)nct * lay];
+        coldry = c.coldry[gi];
+        wbrodl = c.wbrodl[gi];
+        const size_t wi = gc + (size_t)nct * 7 * (lay - 1);       // wkl (ncol,7,nlayers)
+        w1 = c.wkl[wi]; w2 = c.wkl[wi + (size_t)nct]; w3 = c.wkl[wi + (size_t)nct * 2];
+        w4 = c.wkl[wi + (size_t)nct * 3]; w5 = c.wkl[wi + (size_t)nct * 4]; w6 = c.wkl[wi + (size_t)nct * 5];
+        w7 = c.wkl[wi + (size_t)nct * 6];
+        const size_t xi = gc + (size_t)nct * 4 * (lay - 1);       // wx (ncol,4,nlayers)
+        C.f[F_WX1] = c.wx[xi]; C.f[F_WX2] = c.wx[xi + (size_t)nct];
+        C.f[F_WX3] = c.wx[xi + (size_t)nct * 2]; C.f[F_WX4] = c.wx[xi + (size_t)nct * 3];
+    }
+
+    // temperature indices for the Planck tables: setcoef :173-201
+    const int indlay = clampi((int)(tavel - 159.), 1, 180);
+    const double tlayfrac = tavel - 159. - (double)indlay;
+    const int indhi = clampi((int)(tz_hi - 159.), 1, 180);
+    const double thifrac = tz_hi - 159. - (double)indhi;
+    const int indlo = clampi((int)(tz_lo - 159.), 1, 180);
+    const double tlofrac = tz_lo - 159. - (double)indlo;
+
+    // pressure / temperature interpolation: setcoef :276-306
+    const double plog = log(pavel);
+    const int jp = clampi((int)(36. - 5 * (plog + 0.04)), 1, 58);
+    const double fp = 5. * (preflog[jp - 1] - plog);
+    const int jt = clampi((int)(3. + (tavel - tref[jp - 1]) / 15.), 1, 4);
+    const double ft = ((tavel - tref[jp - 1]) / 15.) - (double)(jt - 3);
+    const int jt1 = clampi((int)(3. + (tavel - tref[jp]) / 15.), 1, 4);
+    const double ft1 = ((tavel - tref[jp]) / 15.) - (double)(jt1 - 3);
+    const double water = w1 / coldry;
+    const double scalefac = pavel * stpfac / tavel;
+    int indself = 1, indfor, indminor;
+    double forfac, forfrac, selffac, selffrac = 0.0, factor;
+    if (!(plog <= 4.56)) {            // :312-334
+        forfac = scalefac / (1. + water);
+        factor = (332.0 - tavel) / 36.0;
+        indfor = min(2, max(1, (int)factor));
+        forfrac = factor - (double)indfor;
+        selffac = water * forfac;
+        factor = (tavel - 188.0) / 7.2;
+        indself = min(9, max(1, (int)factor - 7));
+        selffrac = factor - (double)(indself + 7);
+    } else {                          // :369-377
+        forfac = scalefac / (1. + water);
+        factor = (tavel - 188.0) / 36.0;
+        indfor = 3;
+        forfrac = factor - 1.0;
+        selffac = water * forfac;
+    }
+    factor = (tavel - 180.8) / 7.2;
+    indminor = min(18, max(1, (int)factor));
+    C.f[F_MINORFRAC] = factor - (double)indminor;
+    C.f[F_SCALEMINOR] = pavel / tavel;
+    C.f[F_SCALEMINORN2] = (pavel / tavel) * (wbrodl / (coldry + w1));
+    double colh2o = 1.e-20 * w1, colco2 = 1.e-20 * w2, colo3 = 1.e-20 * w3, coln2o = 1.e-20 * w4;
+    double colco = 1.e-20 * w5, colch4 = 1.e-20 * w6, colo2 = 1.e-20 * w7;
+    if (colco2 == 0.) colco2 = 1.e-32 * coldry;
+    if (colo3 == 0.) colo3 = 1.e-32 * coldry;
+    if (coln2o == 0.) coln2o = 1.e-32 * coldry;
+    if (colco == 0.) colco = 1.e-32 * coldry;
+    if (colch4 == 0.) colch4 = 1.e-32 * coldry;
+    const double compfp = 1. - fp;     // :421-429
+    C.f[F_FAC10] = compfp * ft;
+    C.f[F_FAC00] = compfp * (1. - ft);
+    C.f[F_FAC11] = fp * ft1;
+    C.f[F_FAC01] = fp * (1. - ft1);
+    C.f[F_SELFFAC] = colh2o * selffac;
+    C.f[F_FORFAC] = colh2o * forfac;
+    C.f[F_SELFFRAC] = selffrac;
+    C.f[F_FORFRAC] = forfrac;
+    C.f[F_COLH2O] = colh2o; C.f[F_COLCO2] = colco2; C.f[F_COLO3] = colo3; C.f[F_COLN2O] = coln2o;
+    C.f[F_COLCO] = colco; C.f[F_COLCH4] = colch4; C.f[F_COLO2] = colo2; C.f[F_COLBRD] = 1.e-20 * wbrodl;
+    C.f[F_COLDRY] = coldry;
+    C.f[F_PAVEL] = pavel;
+    C.jp = jp; C.jt = jt; C.jt1 = jt1; C.indself = indself; C.indfor = indfor; C.indminor = indminor;
+
+    // "lower atmosphere" for taumol is lay <= laytrop (the count of layers with ln p > 4.56), :312-313
+    const bool lower = lay <= W.laytrop[col];
+    int cloudy = 0, ncbands = 1;
+    if (CLOUD) {
+        cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
+        if (cloudy) ncbands = W.ncbands[col];
+    }
+    // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
+    const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
+#define BAND(B)                                                                                                     \
+    if (B >= a.istart && B <= a.iend)                                                                               \
+        layer_band<B, CLOUD>(T, W, a, C, kt, lower, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, cloudy, ncbands);
+    if constexpr (GROUP == 0) { BAND(3) BAND(14) }
+    else if constexpr (GROUP == 1) { BAND(5) BAND(15) }
+    else if constexpr (GROUP == 2) { BAND(4) BAND(10) BAND(16) }
+    else if constexpr (GROUP == 3) { BAND(7) BAND(8) }
+    else if constexpr (GROUP == 4) { BAND(9) BAND(11) BAND(13) }
+    else { BAND(1) BAND(2) BAND(6) BAND(12) }
+#undef BAND
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sweep : the vertical recurrences.  One thread owns NGC consecutive g-points of one band for one column.
+//   MODE 0 clear column set (icld = 0): rtrn/rtrnmr clear branch   src/rrtmg_lw_rtrn.f90:437-466,:497-540
+//   MODE 1 rtrn   (random overlap)                                 src/rrtmg_lw_rtrn.f90:361-540
+//   MODE 2 rtrnmr (maximum-random overlap)                         src/rrtmg_lw_rtrnmr.f90:531-738
+// Writes the chunk's flux contribution (sum over its g-points x 0.5 x delwave, rtrn :549-562) per level.
+// ------------------------------------------------------------------------------------------------
+#ifndef RRLW_SWEEP_UNROLL
+#define RRLW_SWEEP_UNROLL 4
+#endif
+
+struct SweepArgs {
+    int ncol, col0, nct, idrv;
+    int istart, iend;          // only bands in [istart, iend] are swept
+    const double *emis;        // semiss (nct,16)
+    const double *cldfrac;     // (nct,nlay)
+};
+
+__device__ __forceinline__ int quad_band(int q)     // 1-based band of quad q
+{
+    constexpr int qs[17] = {band_qstart(1), band_qstart(2), band_qstart(3), band_qstart(4), band_qstart(5), band_qstart(6),
+                            band_qstart(7), band_qstart(8), band_qstart(9), band_qstart(10), band_qstart(11), band_qstart(12),
+                            band_qstart(13), band_qstart(14), band_qstart(15), band_qstart(16), band_qstart(17)};
+    int b = 1;
+#pragma unroll
+    for (int B = 2; B <= 16; B++) b += (q >= qs[B - 1]) ? 1 : 0;
+    return b;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepArgs a)
+{
+    constexpr int NGC = 4;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= a.ncol) return;
+    const int quad = blockIdx.y;
+    const int B = quad_band(quad);
+    if (B < a.istart || B > a.iend) return;
+    const size_t gc = (size_t)a.col0 + col;
+    const int nlay = W.nlay, nct = a.nct;
+    const size_t ncb = W.ncolb;
+    const double wtdelw = T.delwave[B - 1];
+    const bool idrv = a.idrv == 1;
+    const scr4 *__restrict__ sA = reinterpret_cast<const scr4 *>(W.scr[S_ATR]) + (size_t)quad * nlay * ncb + col;
+    const scr4 *__restrict__ sBd = reinterpret_cast<const scr4 *>(W.scr[S_BBD]) + (size_t)quad * nlay * ncb + col;
+    const scr4 *__restrict__ sBu = reinterpret_cast<const scr4 *>(W.scr[S_BBU]) + (size_t)quad * nlay * ncb + col;
+    const scr4 *__restrict__ sT = reinterpret_cast<const scr4 *>(W.scr[S_ATOT]) + (size_t)quad * nlay * ncb + col;
+    const scr4 *__restrict__ sTd = reinterpret_cast<const scr4 *>(W.scr[S_BBDTOT]) + (size_t)quad * nlay * ncb + col;
+    const scr4 *__restrict__ sTu = reinterpret_cast<const scr4 *>(W.scr[S_BBUTOT]) + (size_t)quad * nlay * ncb + col;
+    Part2 *__restrict__ pdn = W.pdn + ((size_t)quad * (nlay + 1)) * ncb + col;
+    Part2 *__restrict__ pup = W.pup + ((size_t)quad * (nlay + 1)) * ncb + col;
+    Part2 *__restrict__ dbase = W.dpart + ((size_t)quad * (nlay + 1)) * ncb + col;
+
+    int ibc = 0;
     bool colcloud = false;
     if constexpr (MODE != 0) {
         const int ncbands = W.ncbands[col];
@@ -977,48 +1195,36 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
         colcloud = (W.cflag[col] & 8) != 0;
     }
 
-    double radld[NGC], radclrd[NGC], frac[NGC], tau[NGC];
-    double cldrad[NGC], clrrad[NGC], radmr[NGC];       // rtrnmr partial radiances
+    double radld[NGC], radclrd[NGC], cldrad[NGC], clrrad[NGC], radmr[NGC];
 #pragma unroll
     for (int j = 0; j < NGC; j++) { radld[j] = 0.0; radclrd[j] = 0.0; cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
     int iclddn = 0;
+    {   // downward flux at the top level is zero
+        Part2 z{0.0, 0.0};
+        pdn[(size_t)nlay * ncb] = z;
+    }
 
-    double plev_hi = W.planklev[((size_t)(B - 1) * (nlay + 1) + nlay) * ncb + col];
-    // ------------------------------------------------------------------ downward sweep: rtrn :361-466
+    // ------------------------------------------------------------------ downward sweep
+    // (unrolled so that the independent per-cell loads of several levels are in flight while the recurrence runs)
+#pragma unroll 4
     for (int lev = nlay; lev >= 1; lev--) {
-        const int packed = W.idx[(size_t)(lev - 1) * ncb + col];
-        if (lev <= laytrop) taumol_layer<B, NGC, true>(T, W, lev, col, g0, packed, tau, frac);
-        else taumol_layer<B, NGC, false>(T, W, lev, col, g0, packed, tau, frac);
-        const double taua = a.tauaer ? a.tauaer[gc + (size_t)nct * ((lev - 1) + (size_t)nlay * (B - 1))] : 0.0;
-        const double blay = W.planklay[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
-        const double plev_lo = W.planklev[((size_t)(B - 1) * (nlay + 1) + (lev - 1)) * ncb + col];
-        const double dplankup = plev_hi - blay, dplankdn = plev_lo - blay;
-        plev_hi = plev_lo;
-        int cloudy = 0;
-        double cf = 0.0, odcld = 0.0, efcl = 0.0;
-        int flags = 0;
+        int cloudy = 0, flags = 0;
+        double cf = 0.0, efcl = 0.0;
         if constexpr (MODE != 0) {
             flags = W.cflag[(size_t)lev * ncb + col];
             cloudy = flags & 1;
             if (cloudy) {
                 cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
-                odcld = W.odcld[((size_t)ibc * nlay + (lev - 1)) * ncb + col];
                 if constexpr (MODE == 1) efcl = W.efcl[((size_t)ibc * nlay + (lev - 1)) * ncb + col];
             }
         }
+        const size_t so = (size_t)(lev - 1) * ncb;
+        const scr4 vatr = sA[so], vbbd = sBd[so];
         double dsum = 0.0, dsumc = 0.0;
         if (!cloudy) {
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
-                double od = secdiff * (tau[j] + taua);
-                if (od < 0.0) od = 0.0;
-                double atr, tfn;
-                gas_layer(od, lut, bpade, atr, tfn);
-                const double bbd = frac[j] * (blay + tfn * dplankdn);
-                const double bbu = frac[j] * (blay + tfn * dplankup);
-                const size_t so = ((size_t)j * nlay + (lev - 1)) * ncb + col;
-                sA[so] = atr;
-                sB[so] = bbu;
+                const double atr = vatr.v[j], bbd = vbbd.v[j];
                 radld[j] = radld[j] + (bbd - radld[j]) * atr;
                 dsum = dsum + radld[j];
                 if constexpr (MODE != 0) {
@@ -1030,6 +1236,7 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
         } else {
             if constexpr (MODE != 0) {
                 iclddn = 1;
+                const scr4 vatot = sT[so], vbbdt = sTd[so];
                 double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
                 if constexpr (MODE == 2) {
                     const size_t mo = (size_t)(lev - 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
@@ -1039,37 +1246,8 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
                 }
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    double od = secdiff * (tau[j] + taua);
-                    if (od < 0.0) od = 0.0;
-                    double odtot = od + odcld;
-                    double atr, tfgas, atot, tftot;
-                    // three sub-branches: rtrn :372-435
-                    if (odtot < 0.06) {
-                        atr = od - 0.5 * od * od; tfgas = 0.166667 * od;
-                        atot = odtot - 0.5 * odtot * odtot; tftot = 0.166667 * odtot;
-                    } else if (od <= 0.06) {
-                        atr = od - 0.5 * od * od; tfgas = 0.166667 * od;
-                        const int it = (int)(10000.0 * (odtot / (bpade + odtot)) + 0.5);
-                        const double2 e = reinterpret_cast<const double2 *>(lut)[it];
-                        atot = 1. - e.x; tftot = e.y;
-                    } else {
-                        const int ig = (int)(10000.0 * (od / (bpade + od)) + 0.5);
-                        const double2 e = reinterpret_cast<const double2 *>(lut)[ig];
-                        od = tau_tbl[ig];
-                        atr = 1. - e.x; tfgas = e.y;
-                        odtot = od + odcld;
-                        const int it = (int)(10000.0 * (odtot / (bpade + odtot)) + 0.5);
-                        const double2 e2 = reinterpret_cast<const double2 *>(lut)[it];
-                        atot = 1. - e2.x; tftot = e2.y;
-                    }
-                    const double bbd = frac[j] * (blay + tfgas * dplankdn);
+                    const double atr = vatr.v[j], bbd = vbbd.v[j], atot = vatot.v[j], bbdtot = vbbdt.v[j];
                     const double gassrc = bbd * atr;
-                    const double bbdtot = frac[j] * (blay + tftot * dplankdn);
-                    const size_t so = ((size_t)j * nlay + (lev - 1)) * ncb + col;
-                    sA[so] = atr;
-                    sB[so] = frac[j] * (blay + tfgas * dplankup);
-                    sC[so] = atot;
-                    sD[so] = frac[j] * (blay + tftot * dplankup);
                     if constexpr (MODE == 1) {
                         radld[j] = radld[j] - radld[j] * (atr + efcl * (1. - atr)) + gassrc + cf * (bbdtot * atot - gassrc);
                     } else {            // rtrnmr :591-615
@@ -1096,38 +1274,37 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
                 }
             }
         }
-        const size_t oo = gc + (size_t)nct * (lev - 1);
-        out.dflx[oo] += (dsum * 0.5) * wtdelw;
-        if constexpr (MODE != 0) out.dflxc[oo] += (dsumc * 0.5) * wtdelw;
+        {
+            Part2 o{(dsum * 0.5) * wtdelw, (dsumc * 0.5) * wtdelw};
+            pdn[(size_t)(lev - 1) * ncb] = o;
+        }
     }
 
     // ------------------------------------------------------------------ surface: rtrn :476-495
-    const double plankbnd = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + col];
-    const double dplankbnd = idrv ? W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + col] : 0.0;
     const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
     double radlu[NGC], radclru[NGC], drad[NGC], dradc[NGC];
     double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
 #pragma unroll
     for (int j = 0; j < NGC; j++) {
-        const double rad0 = frac[j] * plankbnd;
+        const double rad0 = W.rad0[(size_t)(quad * 4 + j) * ncb + col];
         radlu[j] = rad0 + reflect * radld[j];
         radclru[j] = rad0 + reflect * radclrd[j];
         usum = usum + radlu[j];
         usumc = usumc + radclru[j];
-        drad[j] = frac[j] * dplankbnd;
+        drad[j] = idrv ? W.rad0[(size_t)(4 * NQUAD + quad * 4 + j) * ncb + col] : 0.0;
         dradc[j] = drad[j];
         dusum = dusum + drad[j];
     }
-    out.uflx[gc] += (usum * 0.5) * wtdelw;
-    if constexpr (MODE != 0) out.uflxc[gc] += (usumc * 0.5) * wtdelw;
-    if (idrv) {
-        out.duflx_dt[gc] += ((dusum * 0.5) * wtdelw) * T.fluxfac;
-        if constexpr (MODE != 0) out.duflxc_dt[gc] += ((dusum * 0.5) * wtdelw) * T.fluxfac;
+    {
+        Part2 o{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
+        pup[0] = o;
+        if (idrv) { Part2 od{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusum * 0.5) * wtdelw) * T.fluxfac}; dbase[0] = od; }
     }
 #pragma unroll
     for (int j = 0; j < NGC; j++) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
 
-    // ------------------------------------------------------------------ upward sweep: rtrn :497-540
+    // ------------------------------------------------------------------ upward sweep
+#pragma unroll 4
     for (int lev = 1; lev <= nlay; lev++) {
         int cloudy = 0, flags = 0;
         double cf = 0.0, efcl = 0.0;
@@ -1139,12 +1316,13 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
                 if constexpr (MODE == 1) efcl = W.efcl[((size_t)ibc * nlay + (lev - 1)) * ncb + col];
             }
         }
+        const size_t so = (size_t)(lev - 1) * ncb;
+        const scr4 vatr = sA[so], vbbu = sBu[so];
         usum = 0.0; usumc = 0.0; dusum = 0.0; dusumc = 0.0;
         if (!cloudy) {
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
-                const size_t so = ((size_t)j * nlay + (lev - 1)) * ncb + col;
-                const double atr = sA[so], bbu = sB[so];
+                const double atr = vatr.v[j], bbu = vbbu.v[j];
                 radlu[j] = radlu[j] + (bbu - radlu[j]) * atr;
                 usum = usum + radlu[j];
                 if (idrv) { drad[j] = drad[j] * (1.0 - atr); dusum = dusum + drad[j]; }
@@ -1161,6 +1339,7 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
             }
         } else {
             if constexpr (MODE != 0) {
+                const scr4 vatot = sT[so], vbbut = sTu[so];
                 double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
                 if constexpr (MODE == 2) {
                     const size_t mo = (size_t)(lev + 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
@@ -1170,8 +1349,7 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
                 }
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    const size_t so = ((size_t)j * nlay + (lev - 1)) * ncb + col;
-                    const double atr = sA[so], bbu = sB[so], atot = sC[so], bbutot = sD[so];
+                    const double atr = vatr.v[j], bbu = vbbu.v[j], atot = vatot.v[j], bbutot = vbbut.v[j];
                     const double gassrc = bbu * atr;
                     if constexpr (MODE == 1) {
                         radlu[j] = radlu[j] - radlu[j] * (atr + efcl * (1. - atr)) + gassrc + cf * (bbutot * atot - gassrc);
@@ -1205,46 +1383,70 @@ __global__ __launch_bounds__(256) void k_band(DevTables T, Workspace W, BandArgs
                 }
             }
         }
-        const size_t oo = gc + (size_t)nct * lev;
-        out.uflx[oo] += (usum * 0.5) * wtdelw;
-        if constexpr (MODE != 0) out.uflxc[oo] += (usumc * 0.5) * wtdelw;
-        if (idrv) {
-            out.duflx_dt[oo] += ((dusum * 0.5) * wtdelw) * T.fluxfac;
-            if constexpr (MODE != 0) out.duflxc_dt[oo] += ((dusumc * 0.5) * wtdelw) * T.fluxfac;
+        {
+            Part2 o{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
+            pup[(size_t)lev * ncb] = o;
+            if (idrv) { Part2 od{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusumc * 0.5) * wtdelw) * T.fluxfac}; dbase[(size_t)lev * ncb] = od; }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_final : rtrn :580-604 (flux scaling, net flux, heating rate) and the output copies of
-//           src/rrtmg_lw_rad.nomcica.f90:563-583.  clear_from_total: MODE 0 ran, so the clear-sky
-//           stream equals the total-sky stream.
+// k_flux  : sum of the quad partials in band order (rtrn :549-574) and flux scaling (rtrn :580-594), one
+//           thread per (column, level).  clear_from_total: MODE 0 ran, so the clear-sky stream equals the
+//           total-sky stream.  Only chunks whose band lies in [istart, iend] were swept.
+// k_rates : net flux and heating rate (rtrn :583-604; output copies src/rrtmg_lw_rad.nomcica.f90:563-583),
+//           one thread per (column, layer).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_final(DevTables T, FluxOut out, const double *pz, int ncol, int col0, int nct, int nlay,
-                                               int idrv, int clear_from_total)
+__global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut out, int ncol, int col0, int nct,
+                                              int idrv, int clear_from_total, int istart, int iend)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
+    const int lev = blockIdx.y;
     const size_t gc = (size_t)col0 + col;
-    double fnet_lo = 0.0, fnetc_lo = 0.0, pz_lo = 0.0;
-    for (int lev = 0; lev <= nlay; lev++) {
-        const size_t o = gc + (size_t)nct * lev;
-        const double u = out.uflx[o] * T.fluxfac, d = out.dflx[o] * T.fluxfac;
-        double uc, dc;
-        if (clear_from_total) { uc = u; dc = d; }
-        else { uc = out.uflxc[o] * T.fluxfac; dc = out.dflxc[o] * T.fluxfac; }
-        out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = uc; out.dflxc[o] = dc;
-        if (idrv == 1 && clear_from_total) out.duflxc_dt[o] = out.duflx_dt[o];
-        const double fnet = u - d, fnetc = uc - dc;
-        if (out.fnet) { out.fnet[o] = fnet; out.fnetc[o] = fnetc; }
-        const double pzl = pz[o];
-        if (lev > 0) {
-            const size_t ol = gc + (size_t)nct * (lev - 1);
-            out.hr[ol] = T.heatfac * (fnet_lo - fnet) / (pz_lo - pzl);
-            out.hrc[ol] = T.heatfac * (fnetc_lo - fnetc) / (pz_lo - pzl);
-        }
-        fnet_lo = fnet; fnetc_lo = fnetc; pz_lo = pzl;
+    const int nlay = W.nlay;
+    const size_t ncb = W.ncolb;
+    double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
+    unsigned long long active = 0ull;          // quads of the bands in [istart, iend] (wave-uniform)
+    for (int k = 0; k < NQUAD; k++) {
+        const int qb = quad_band(k);
+        if (qb >= istart && qb <= iend) active |= 1ull << k;
     }
+#pragma unroll 2
+    for (int k = 0; k < NQUAD; k++) {
+        if (!((active >> k) & 1ull)) continue;
+        const size_t po = ((size_t)k * (nlay + 1) + lev) * ncb + col;
+        const Part2 pu = W.pup[po], pd = W.pdn[po];
+        u = u + pu.a;
+        d = d + pd.a;
+        if (!clear_from_total) { uc = uc + pu.b; dc = dc + pd.b; }
+        if (idrv == 1) {
+            const Part2 q = W.dpart[po];
+            du = du + q.a;
+            if (!clear_from_total) duc = duc + q.b;
+        }
+    }
+    const size_t o = gc + (size_t)nct * lev;
+    u = u * T.fluxfac; d = d * T.fluxfac;
+    if (clear_from_total) { uc = u; dc = d; duc = du; }
+    else { uc = uc * T.fluxfac; dc = dc * T.fluxfac; }
+    out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = uc; out.dflxc[o] = dc;
+    if (idrv == 1) { out.duflx_dt[o] = du; out.duflxc_dt[o] = duc; }
+    if (out.fnet) { out.fnet[o] = u - d; out.fnetc[o] = uc - dc; }
+}
+
+__global__ __launch_bounds__(256) void k_rates(DevTables T, FluxOut out, const double *pz, int ncol, int col0, int nct)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncol) return;
+    const int l = blockIdx.y;                  // layer index 0 .. nlay-1 (htr(l) between levels l and l+1)
+    const size_t lo = (size_t)col0 + col + (size_t)nct * l, hi = lo + (size_t)nct;
+    const double fnet_lo = out.uflx[lo] - out.dflx[lo], fnet_hi = out.uflx[hi] - out.dflx[hi];
+    const double fnetc_lo = out.uflxc[lo] - out.dflxc[lo], fnetc_hi = out.uflxc[hi] - out.dflxc[hi];
+    const double dp = pz[lo] - pz[hi];
+    out.hr[lo] = T.heatfac * (fnet_lo - fnet_hi) / dp;
+    out.hrc[lo] = T.heatfac * (fnetc_lo - fnetc_hi) / dp;
 }
 
 }  // namespace rrlw
