@@ -32,11 +32,24 @@ def _worker(args):
     return time.perf_counter() - t0
 
 
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    hardware threads but a cpu.max of 16 CPUs; oversubscribing the quota only adds throttling)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None):
     from oracle.bindings import Reference
     kind = "reference" if Reference.available("nomcica") else "port"
     if cores is None:
-        cores = len(os.sched_getaffinity(0))
+        cores = usable_cores()
     jobs = [(cols_per_core, nlay, config, i * cols_per_core, kind) for i in range(cores)]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:

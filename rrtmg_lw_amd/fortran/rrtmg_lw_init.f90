@@ -1,0 +1,75 @@
+!  Drop-in replacement for the reference's module rrtmg_lw_init (src/rrtmg_lw_init.f90:47):
+!      use rrtmg_lw_init, only: rrtmg_lw_ini
+!      call rrtmg_lw_ini(cpdair)
+!  forwards to rrtmg_lw_hip_init of librrtmg_lw_hip.so (include/rrtmg_lw_hip.h).  The table files are
+!  looked up through the environment (RRTMG_LW_STATIC_TABLES, RRTMG_LW_KDATA, RRTMG_LW_DEVICE), falling
+!  back to ./lw_static.bin and ./rrtmg_lw.kdata.bin - the reference's netCDF reader likewise opens the
+!  literal 'rrtmg_lw.nc' in the working directory (src/rrtmg_lw_read_nc.f90:58).
+      module rrtmg_lw_init
+
+      use iso_c_binding
+      use parkind, only : im => kind_im, rb => kind_rb
+
+      implicit none
+
+      interface
+         function rrtmg_lw_hip_init(static_path, kdata_path, cpdair, device) bind(C, name='rrtmg_lw_hip_init') result(rc)
+            import :: c_char, c_double, c_int
+            character(kind=c_char), intent(in) :: static_path(*), kdata_path(*)
+            real(c_double), value :: cpdair
+            integer(c_int), value :: device
+            integer(c_int) :: rc
+         end function rrtmg_lw_hip_init
+         function rrtmg_lw_hip_last_error() bind(C, name='rrtmg_lw_hip_last_error') result(p)
+            import :: c_ptr
+            type(c_ptr) :: p
+         end function rrtmg_lw_hip_last_error
+      end interface
+
+      contains
+
+      subroutine rrtmg_lw_ini(cpdair)
+      real(kind=rb), intent(in) :: cpdair     ! Specific heat capacity of dry air at constant pressure at 273 K (J kg-1 K-1)
+      character(len=1024) :: spath, kpath, dev
+      integer :: ls, lk, ld, idev, ios
+      integer(c_int) :: rc
+
+      call get_environment_variable('RRTMG_LW_STATIC_TABLES', spath, ls)
+      if (ls == 0) then
+         spath = 'lw_static.bin'; ls = 13
+      endif
+      call get_environment_variable('RRTMG_LW_KDATA', kpath, lk)
+      if (lk == 0) then
+         kpath = 'rrtmg_lw.kdata.bin'; lk = 18
+      endif
+      idev = 0
+      call get_environment_variable('RRTMG_LW_DEVICE', dev, ld)
+      if (ld > 0) then
+         read(dev(1:ld), *, iostat=ios) idev
+         if (ios /= 0) idev = 0
+      endif
+      rc = rrtmg_lw_hip_init(spath(1:ls)//c_null_char, kpath(1:lk)//c_null_char, real(cpdair, c_double), int(idev, c_int))
+      if (rc /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_ini')
+      end subroutine rrtmg_lw_ini
+
+!  Turns a non-zero status of the C ABI into the reference's behaviour: print the message and stop.
+      subroutine rrtmg_lw_hip_abort(where)
+      character(len=*), intent(in) :: where
+      type(c_ptr) :: p
+      character(kind=c_char), pointer :: s(:)
+      character(len=256) :: msg
+      integer :: i
+      msg = ' '
+      p = rrtmg_lw_hip_last_error()
+      if (c_associated(p)) then
+         call c_f_pointer(p, s, [256])
+         do i = 1, 256
+            if (s(i) == c_null_char) exit
+            msg(i:i) = s(i)
+         enddo
+      endif
+      write(*,'(a,a,a)') where, ': ', trim(msg)
+      error stop 1
+      end subroutine rrtmg_lw_hip_abort
+
+      end module rrtmg_lw_init
