@@ -100,6 +100,86 @@ int rrtmg_lw_hip_run_columns(
     double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
     double *dtotuflux_dt, double *dtotuclfl_dt);
 
+/* McICA flavour ---------------------------------------------------------------------------------- */
+/* rrtmg_lw, McICA  -  reference: src/rrtmg_lw_rad.f90:99-594 (cldprmc src/rrtmg_lw_cldprmc.f90:49, rtrnmc
+ * src/rrtmg_lw_rtrnmc.f90:51).  HOST pointers; same contract as rrtmg_lw_hip_run_nomcica with the cloud
+ * arguments replaced by the sub-column arrays cldfmcl,taucmcl,ciwpmcl,clwpmcl (140,ncol,nlay) and
+ * reicmcl,relqmcl (ncol,nlay).  icld is reset to 2 when outside [0,3] (:469); icld==0 ignores the cloud arrays. */
+int rrtmg_lw_hip_run_mcica(
+    int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfmcl, const double *taucmcl, const double *ciwpmcl, const double *clwpmcl,
+    const double *reicmcl, const double *relqmcl, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt);
+
+/* DEVICE-pointer variant (enqueue on `stream`, no synchronisation; see rrtmg_lw_hip_check). */
+int rrtmg_lw_hip_run_mcica_device(
+    int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfmcl, const double *taucmcl, const double *ciwpmcl, const double *clwpmcl,
+    const double *reicmcl, const double *relqmcl, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt, void *stream);
+
+/* get_alpha  -  reference: src/mcica_subcol_gen_lw.f90:68-180.  HOST pointers; dz,cldfrac,alpha (ncol,nlay),
+ * lat (ncol).  alpha is written only for icld = 4 or 5 (exponential / exponential-random overlap). */
+int rrtmg_lw_hip_get_alpha(int ncol, int nlay, int icld, int idcor, double decorr_con, const double *dz, const double *lat,
+                           int juldat, const double *cldfrac, double *alpha);
+
+/* mcica_subcol_lw  -  reference: src/mcica_subcol_gen_lw.f90:183-291 (generate_stochastic_clouds :295-703,
+ * kissvec :711-745, Mersenne Twister src/mcica_random_numbers.f90).  HOST pointers.
+ * play,cldfrac,ciwp,clwp,rei,rel,alpha (ncol,nlay); tauc (16,ncol,nlay); outputs cldfmcl,ciwpmcl,clwpmcl,taucmcl
+ * (140,ncol,nlay), reicmcl,relqmcl (ncol,nlay).  icld 1..5 = random, maximum-random, maximum, exponential,
+ * exponential-random overlap (alpha may be NULL unless icld is 4 or 5); icld 0 returns without touching the
+ * outputs.  irng is in/out (any non-zero value becomes 1): 0 = kissvec, one stream per column seeded from
+ * its four lowest layer pressures; 1 = one Mersenne-Twister stream seeded with permuteseed, consumed in
+ * (sub-column, column, layer) order. */
+int rrtmg_lw_hip_mcica_subcol(
+    int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
+    const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
+    double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl);
+
+/* DEVICE-pointer variant (enqueue on `stream`; the irng = 1 stream is drawn on the host and synchronises). */
+int rrtmg_lw_hip_mcica_subcol_device(
+    int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
+    const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
+    double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl, void *stream);
+
+/* mcica_subcol_lw + McICA rrtmg_lw in one call (the sequence a host model runs every radiation step,
+ * README.md / src/rrtmg_lw_rad.f90:140-150), without materialising the (140,ncol,nlay) arrays: the generator
+ * leaves a 140-bit cloud mask per (column, layer) on the device and cldprmc/rtrnmc consume it directly.
+ * Results equal rrtmg_lw_hip_mcica_subcol followed by rrtmg_lw_hip_run_mcica.  Cloud arguments are the
+ * generator's inputs (cldfr,cicewp,cliqwp,reice,reliq,alpha (ncol,nlay); taucld (16,ncol,nlay)); icld in
+ * [0,5] selects the overlap for the generator and comes back as rrtmg_lw would leave it. */
+int rrtmg_lw_hip_run_mcica_subcol(
+    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *alpha, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt);
+
+int rrtmg_lw_hip_run_mcica_subcol_device(
+    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *alpha, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt, void *stream);
+
 /* Tuning / introspection ------------------------------------------------------------------------- */
 /* Columns processed per internal batch (bounds the device workspace); default 32768. */
 int rrtmg_lw_hip_set_batch(int ncol_batch);

@@ -119,6 +119,26 @@ class Oracle:
             raise RuntimeError(f"oracle: {self.errmsg()}")
         return res
 
+    def get_alpha(self, ncol, nlay, icld, idcor, decorr_con, dz, lat, juldat, cldfrac):
+        a = np.zeros((ncol, nlay), order="F")
+        self.lib.orc_get_alpha(C.c_int(ncol), C.c_int(nlay), C.c_int(icld), C.c_int(idcor), C.c_double(decorr_con),
+                               _p(_f(dz, (ncol, nlay))), _p(_f(lat, (ncol,))), C.c_int(juldat), _p(_f(cldfrac, (ncol, nlay))), _p(a))
+        return a
+
+    def mcica_subcol(self, ncol, nlay, icld, permuteseed, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha):
+        """mcica_subcol_lw with the GCM argument list (src/mcica_subcol_gen_lw.f90:183-185)."""
+        o = _subcol_outputs(ncol, nlay)
+        irng_c = C.c_int(irng)
+        ins = [_f(play, (ncol, nlay)), _f(cldfrac, (ncol, nlay)), _f(ciwp, (ncol, nlay)), _f(clwp, (ncol, nlay)),
+               _f(rei, (ncol, nlay)), _f(rel, (ncol, nlay)), _f(tauc, (NBND, ncol, nlay)), _f(alpha, (ncol, nlay))]
+        rc = self.lib.orc_mcica_subcol(C.c_int(ncol), C.c_int(nlay), C.c_int(icld), C.c_int(permuteseed), C.byref(irng_c),
+                                       *[_p(a) for a in ins],
+                                       *[_p(o[k]) for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")])
+        if rc != 0:
+            raise RuntimeError(f"oracle: {self.errmsg()}")
+        o["irng"] = irng_c.value
+        return o
+
     def table(self, band, name):
         n = self.lib.orc_get_table(C.c_int(band), name.encode(), None, C.c_long(0))
         if n < 0:
@@ -131,6 +151,12 @@ class Oracle:
         t, e, f = np.zeros(10001), np.zeros(10001), np.zeros(10001)
         self.lib.orc_get_luts(_p(t), _p(e), _p(f))
         return t, e, f
+
+
+def _subcol_outputs(ncol, nlay):
+    z3 = lambda: np.zeros((NGPT, ncol, nlay), order="F")
+    z2 = lambda: np.zeros((ncol, nlay), order="F")
+    return dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), reicmcl=z2(), relqmcl=z2(), taucmcl=z3())
 
 
 class Reference:
@@ -160,3 +186,21 @@ class Reference:
         idrv = int(col["idrv"]) if idrv is None else idrv
         _, res = _column_call(self.lib.ref_column, col, istart, iend, iout, icld, idrv, True)
         return res
+
+    def get_alpha_1col(self, nlay, icld, idcor, decorr_con, dz, lat, juldat, cldfrac):
+        a = np.zeros(nlay)
+        self.lib.ref_get_alpha_1col(C.c_int(nlay), C.c_int(icld), C.c_int(idcor), C.c_double(decorr_con), _p(_f(dz, (nlay,))),
+                                    C.c_double(lat), C.c_int(juldat), _p(_f(cldfrac, (nlay,))), _p(a))
+        return a
+
+    def mcica_subcol_1col(self, nlay, icld, ims, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha):
+        """The reference's one-column generator (src/mcica_subcol_gen_lw.1col.f90:171); permuteseed = ims * 140."""
+        z2 = lambda: np.zeros((NGPT, nlay), order="F")
+        o = dict(cldfmc=z2(), ciwpmc=z2(), clwpmc=z2(), reicmc=np.zeros(nlay), relqmc=np.zeros(nlay), taucmc=z2())
+        irng_c = C.c_int(irng)
+        ins = [_f(play, (nlay,)), _f(cldfrac, (nlay,)), _f(ciwp, (nlay,)), _f(clwp, (nlay,)), _f(rei, (nlay,)), _f(rel, (nlay,)),
+               _f(tauc, (NBND, nlay)), _f(alpha, (nlay,))]
+        self.lib.ref_mcica_subcol_1col(C.c_int(nlay), C.c_int(icld), C.c_int(ims), C.byref(irng_c), *[_p(a) for a in ins],
+                                       *[_p(o[k]) for k in ("cldfmc", "ciwpmc", "clwpmc", "reicmc", "relqmc", "taucmc")])
+        o["irng"] = irng_c.value
+        return o

@@ -204,4 +204,35 @@ contains
   end subroutine ref_column
 #endif
 
+
+  ! One-column McICA sub-column generator of the reference (src/mcica_subcol_gen_lw.1col.f90:67-168,:171-280).
+  subroutine ref_get_alpha_1col(nlayers, icld, idcor, decorr_con, dz, lat, juldat, cldfrac, alpha) bind(C, name='ref_get_alpha_1col')
+    use mcica_subcol_gen_lw, only: get_alpha
+    integer(c_int), value :: nlayers, icld, idcor, juldat
+    real(c_double), value :: decorr_con, lat
+    real(c_double), intent(in) :: dz(nlayers), cldfrac(nlayers)
+    real(c_double), intent(out) :: alpha(nlayers)
+    real(rb) :: dc, la
+    dc = decorr_con
+    la = lat
+    alpha = 0._rb
+    call get_alpha(1_im, int(nlayers,im), int(icld,im), int(idcor,im), dc, dz, la, int(juldat,im), cldfrac, alpha)
+  end subroutine ref_get_alpha_1col
+
+  subroutine ref_mcica_subcol_1col(nlayers, icld, ims, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha, &
+       cldfmc, ciwpmc, clwpmc, reicmc, relqmc, taucmc) bind(C, name='ref_mcica_subcol_1col')
+    use mcica_subcol_gen_lw, only: mcica_subcol_lw
+    integer(c_int), value :: nlayers, icld, ims
+    integer(c_int), intent(inout) :: irng
+    real(c_double), intent(in) :: play(nlayers), cldfrac(nlayers), ciwp(nlayers), clwp(nlayers), rei(nlayers), rel(nlayers)
+    real(c_double), intent(in) :: tauc(nbndlw,nlayers), alpha(nlayers)
+    real(c_double), intent(out) :: cldfmc(ngptlw,nlayers), ciwpmc(ngptlw,nlayers), clwpmc(ngptlw,nlayers)
+    real(c_double), intent(out) :: reicmc(nlayers), relqmc(nlayers), taucmc(ngptlw,nlayers)
+    integer(im) :: irng_f
+    irng_f = irng
+    call mcica_subcol_lw(1_im, int(nlayers,im), int(icld,im), int(ims,im), irng_f, play, cldfrac, ciwp, clwp, rei, rel, &
+                         tauc, alpha, cldfmc, ciwpmc, clwpmc, reicmc, relqmc, taucmc)
+    irng = irng_f
+  end subroutine ref_mcica_subcol_1col
+
 end module ref_harness

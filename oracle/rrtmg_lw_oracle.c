@@ -2150,3 +2150,189 @@ int orc_column(int nlayers, int istart, int iend, int iout, int icld, int idrv,
     *ncbands_out = c->ncbands;
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * McICA sub-column generator.  The GCM routine (src/mcica_subcol_gen_lw.f90:183-703) does not compile as
+ * shipped; its compilable statement is the one-column generator
+ * src/mcica_subcol_gen_lw.1col.f90:171-710, whose per-column semantics are restated here behind the GCM
+ * argument list:  irng = 0 (kissvec) seeds every column from its own pressures, so columns are independent;
+ * irng = 1 (Mersenne Twister) draws from ONE stream in (sub-column, column, layer) order as the GCM routine
+ * does (src/mcica_subcol_gen_lw.f90:476-490, :523-530), which for ncol = 1 is the column driver's order.
+ * ------------------------------------------------------------------------------------------- */
+/* MT19937 on 32-bit words: src/mcica_random_numbers.f90:77-306 (signed arithmetic there, same bits) */
+typedef struct { int cur; uint32_t st[624]; } mt_t;
+
+static void mt_init(mt_t *t, int32_t seed)       /* initialize_scalar :157-169 */
+{
+    t->st[0] = (uint32_t)seed;
+    for (int i = 1; i < 624; i++) t->st[i] = 1812433253u * (t->st[i - 1] ^ (t->st[i - 1] >> 30)) + (uint32_t)i;
+    t->cur = 624;
+}
+
+static uint32_t mt_twist(uint32_t u, uint32_t v)  /* mixbits/twist :112-131 */
+{
+    uint32_t mix = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (mix >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+
+static void mt_next(mt_t *t)                      /* nextState :133-147 */
+{
+    int k;
+    for (k = 0; k <= 624 - 397 - 1; k++) t->st[k] = t->st[k + 397] ^ mt_twist(t->st[k], t->st[k + 1]);
+    for (k = 624 - 397; k <= 624 - 2; k++) t->st[k] = t->st[k + 397 - 624] ^ mt_twist(t->st[k], t->st[k + 1]);
+    t->st[623] = t->st[396] ^ mt_twist(t->st[623], t->st[0]);
+    t->cur = 0;
+}
+
+static double mt_real(mt_t *t)                    /* getRandomInt/temper/getRandomReal :149-155,:262-295 */
+{
+    if (t->cur >= 624) mt_next(t);
+    uint32_t y = t->st[t->cur++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    int32_t li = (int32_t)y;
+    if (li < 0) return ((double)li + 4294967296.0) / (4294967296.0 - 1.0);
+    return ((double)li) / (4294967296.0 - 1.0);
+}
+
+/* kissvec: src/mcica_subcol_gen_lw.1col.f90:677-710 (32-bit wrap-around, logical shifts) */
+static double kissvec(int32_t *s1, int32_t *s2, int32_t *s3, int32_t *s4)
+{
+    uint32_t a = (uint32_t)*s1, b = (uint32_t)*s2, c = (uint32_t)*s3, d = (uint32_t)*s4;
+    a = 69069u * a + 1327217885u;
+    b ^= b << 13; b ^= b >> 17; b ^= b << 5;
+    c = 18000u * (c & 65535u) + (c >> 16);
+    d = 30903u * (d & 65535u) + (d >> 16);
+    uint32_t kiss = a + b + (c << 16) + d;
+    *s1 = (int32_t)a; *s2 = (int32_t)b; *s3 = (int32_t)c; *s4 = (int32_t)d;
+    return (double)(int32_t)kiss * 2.328306e-10 + 0.5;
+}
+
+/* get_alpha: src/mcica_subcol_gen_lw.f90:68-180 (.1col :67-168).  dz, cldfrac, alpha are (ncol,nlay); lat (ncol). */
+void orc_get_alpha(int ncol, int nlay, int icld, int idcor, double decorr_con, const double *dz, const double *lat,
+                   int juldat, const double *cldfrac, double *alpha)
+{
+    const double am1 = 1.4315, am2 = 2.1219, am4 = -25.584, amr = 7.0;
+    for (int i = 0; i < ncol; i++) {
+        double decorr_inv = 1.0, decorr_len = 0.0;
+        if (icld == 4 || icld == 5) {
+            if (idcor == 1) {
+                double am3;
+                if (juldat > 181) am3 = -4. * amr / 365. * (juldat - 272);
+                else am3 = 4. * amr / 365. * (juldat - 91);
+                double decorr_lat = am1 + am2 * exp(-((lat[i] - am3) * (lat[i] - am3)) / (am4 * am4));
+                decorr_len = decorr_lat * 1.e3;
+            } else {
+                decorr_len = decorr_con;
+            }
+            if (decorr_len >= 0.0) decorr_inv = 1.0 / decorr_len;
+        }
+        if (icld == 4 || icld == 5) {
+            alpha[i] = 0.0;
+            for (int k = 2; k <= nlay; k++) {
+                size_t o = (size_t)i + (size_t)ncol * (k - 1), om = (size_t)i + (size_t)ncol * (k - 2);
+                alpha[o] = exp(-(0.5 * (dz[o] + dz[om])) * decorr_inv);
+                if (icld == 5 && cldfrac[o] == 0.0 && cldfrac[om] > 0.0) alpha[o] = 0.0;
+            }
+        }
+    }
+}
+
+/* mcica_subcol_lw with the GCM argument list (src/mcica_subcol_gen_lw.f90:183-291).  play, cldfrac, ciwp, clwp, rei, rel,
+ * alpha: (ncol,nlay); tauc: (16,ncol,nlay); outputs cldfmcl, ciwpmcl, clwpmcl, taucmcl: (140,ncol,nlay); reicmcl, relqmcl (ncol,nlay). */
+int orc_mcica_subcol(int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac,
+                     const double *ciwp, const double *clwp, const double *rei, const double *rel, const double *tauc,
+                     const double *alpha, double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl,
+                     double *taucmcl)
+{
+    if (!initialised) { strcpy(errmsg, "orc_init not called"); return -1; }
+    if (icld == 0) return 0;
+    if (icld < 0 || icld > 5) { strcpy(errmsg, "MCICA_SUBCOL_LW: INVALID ICLD"); return 1; }
+    if (*irng != 0) *irng = 1;
+    const double cldmin = 1.0e-20;
+    const int nsub = NGPT;
+    for (size_t k = 0; k < (size_t)ncol * nlay; k++) { reicmcl[k] = rei[k]; relqmcl[k] = rel[k]; }
+    double *cdf = (double *)malloc(sizeof(double) * nsub * (size_t)ncol * nlay);
+    double *cdf2 = (double *)malloc(sizeof(double) * nsub * (size_t)ncol * nlay);
+#define CDF(a, s, i, l) (a)[(s) + (size_t)nsub * ((i) + (size_t)ncol * (l))]
+#define P2(a, i, l) (a)[(i) + (size_t)ncol * (l)]
+    mt_t mt;
+    if (*irng == 1) mt_init(&mt, (int32_t)permuteseed);
+    const int two = (icld == 4 || icld == 5);
+    if (*irng == 0) {
+        for (int i = 0; i < ncol; i++) {
+            if (nlay < 4) { free(cdf); free(cdf2); strcpy(errmsg, "MCICA_SUBCOL: fewer than four layers"); return 1; }
+            if (P2(play, i, 0) * 1.e2 < P2(play, i, 1) * 1.e2) {
+                free(cdf); free(cdf2);
+                strcpy(errmsg, "MCICA_SUBCOL: KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS.");
+                return 1;
+            }
+            int32_t s[4];
+            for (int q = 0; q < 4; q++) {
+                double pm = P2(play, i, q) * 1.e2;
+                s[q] = (int32_t)((pm - (double)(int)pm) * 1000000000);
+            }
+            for (int q = 0; q < permuteseed; q++) (void)kissvec(&s[0], &s[1], &s[2], &s[3]);
+            for (int isub = 0; isub < nsub; isub++) {
+                if (icld == 3) {
+                    double r = kissvec(&s[0], &s[1], &s[2], &s[3]);
+                    for (int l = 0; l < nlay; l++) CDF(cdf, isub, i, l) = r;
+                } else {
+                    for (int l = 0; l < nlay; l++) {
+                        CDF(cdf, isub, i, l) = kissvec(&s[0], &s[1], &s[2], &s[3]);
+                        if (two) CDF(cdf2, isub, i, l) = kissvec(&s[0], &s[1], &s[2], &s[3]);
+                    }
+                }
+            }
+        }
+    } else {
+        for (int isub = 0; isub < nsub; isub++)
+            for (int i = 0; i < ncol; i++) {
+                if (icld == 3) {
+                    double r = mt_real(&mt);
+                    for (int l = 0; l < nlay; l++) CDF(cdf, isub, i, l) = r;
+                } else {
+                    for (int l = 0; l < nlay; l++) {
+                        CDF(cdf, isub, i, l) = mt_real(&mt);
+                        if (two) CDF(cdf2, isub, i, l) = mt_real(&mt);
+                    }
+                }
+            }
+    }
+    for (int i = 0; i < ncol; i++) {
+        for (int l = 1; l < nlay; l++) {
+            double cfl = P2(cldfrac, i, l - 1);
+            if (cfl < cldmin) cfl = 0.0;
+            for (int isub = 0; isub < nsub; isub++) {
+                if (icld == 2) {                       /* maximum-random, .1col :440-448 */
+                    if (CDF(cdf, isub, i, l - 1) > 1. - cfl) CDF(cdf, isub, i, l) = CDF(cdf, isub, i, l - 1);
+                    else CDF(cdf, isub, i, l) = CDF(cdf, isub, i, l) * (1. - cfl);
+                } else if (two) {                      /* exponential(-random), .1col :492-496,:521-525 */
+                    if (CDF(cdf2, isub, i, l) < P2(alpha, i, l)) CDF(cdf, isub, i, l) = CDF(cdf, isub, i, l - 1);
+                }
+            }
+        }
+        for (int l = 0; l < nlay; l++) {
+            double cf = P2(cldfrac, i, l);
+            if (cf < cldmin) cf = 0.0;
+            for (int isub = 0; isub < nsub; isub++) {
+                size_t o = isub + (size_t)nsub * (i + (size_t)ncol * l);
+                if (CDF(cdf, isub, i, l) >= 1. - cf) {
+                    cldfmcl[o] = 1.0;
+                    clwpmcl[o] = P2(clwp, i, l);
+                    ciwpmcl[o] = P2(ciwp, i, l);
+                    taucmcl[o] = tauc[(ngb_[isub] - 1) + (size_t)NBND * (i + (size_t)ncol * l)];
+                } else {
+                    cldfmcl[o] = 0.0; clwpmcl[o] = 0.0; ciwpmcl[o] = 0.0; taucmcl[o] = 0.0;
+                }
+            }
+        }
+    }
+#undef CDF
+#undef P2
+    free(cdf);
+    free(cdf2);
+    return 0;
+}

@@ -174,6 +174,127 @@ def run_columns(cols, istart=1, iend=16, icld=None, idrv=None):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------
+# McICA flavour: reference src/rrtmg_lw_rad.f90:99-108, src/mcica_subcol_gen_lw.f90:68,183
+# ---------------------------------------------------------------------------------------------------
+def _out_arrays(ncol, nlay, idrv):
+    out = {k: np.empty((ncol, nlay + 1), order="F") for k in ("uflx", "dflx", "uflxc", "dflxc")}
+    out["hr"] = np.empty((ncol, nlay), order="F")
+    out["hrc"] = np.empty((ncol, nlay), order="F")
+    if idrv == 1:
+        out["duflx_dt"] = np.empty((ncol, nlay + 1), order="F")
+        out["duflxc_dt"] = np.empty((ncol, nlay + 1), order="F")
+    return out
+
+
+def _out_ptrs(out, idrv):
+    null = C.cast(None, _dp)
+    return [_p(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")] + \
+           [_p(out["duflx_dt"]) if idrv == 1 else null, _p(out["duflxc_dt"]) if idrv == 1 else null]
+
+
+def _gcm_arrays(ncol, nlay, play, plev, tlay, tlev, tsfc, gases, emis):
+    return [_f(play, (ncol, nlay)), _f(plev, (ncol, nlay + 1)), _f(tlay, (ncol, nlay)), _f(tlev, (ncol, nlay + 1)),
+            _f(tsfc, (ncol,))] + [_f(x, (ncol, nlay)) for x in gases] + [_f(emis, (ncol, NBND))]
+
+
+def rrtmg_lw_mcica(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr,
+                   cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, inflglw, iceflglw, liqflglw, cldfmcl, taucmcl, ciwpmcl,
+                   clwpmcl, reicmcl, relqmcl, tauaer):
+    """McICA rrtmg_lw (src/rrtmg_lw_rad.f90:99-108) with host arrays; sub-column arrays are (140, ncol, nlay)."""
+    a = _gcm_arrays(ncol, nlay, play, plev, tlay, tlev, tsfc,
+                    (h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr), emis)
+    cld = [_f(cldfmcl, (NGPT, ncol, nlay)), _f(taucmcl, (NGPT, ncol, nlay)), _f(ciwpmcl, (NGPT, ncol, nlay)),
+           _f(clwpmcl, (NGPT, ncol, nlay)), _f(reicmcl, (ncol, nlay)), _f(relqmcl, (ncol, nlay)), _f(tauaer, (ncol, nlay, NBND))]
+    out = _out_arrays(ncol, nlay, idrv)
+    icld_c = C.c_int(int(icld))
+    args = [C.c_int(ncol), C.c_int(nlay), C.byref(icld_c), C.c_int(int(idrv))] + [_p(x) for x in a]
+    args += [C.c_int(int(inflglw)), C.c_int(int(iceflglw)), C.c_int(int(liqflglw))] + [_p(x) for x in cld] + _out_ptrs(out, idrv)
+    _check(lib().rrtmg_lw_hip_run_mcica(*args))
+    out["icld"] = icld_c.value
+    return out
+
+
+_MC_ORDER = ("cldfmcl", "taucmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "tauaer")
+
+
+def rrtmg_lw_mcica_from_dict(d, icld=None, idrv=None):
+    icld = d["icld"] if icld is None else icld
+    idrv = d["idrv"] if idrv is None else idrv
+    return rrtmg_lw_mcica(d["ncol"], d["nlay"], icld, idrv, *[d[k] for k in _GCM_ORDER], d["inflglw"], d["iceflglw"],
+                          d["liqflglw"], *[d[k] for k in _MC_ORDER])
+
+
+def get_alpha(ncol, nlay, icld, idcor, decorr_con, dz, lat, juldat, cldfrac):
+    """get_alpha (src/mcica_subcol_gen_lw.f90:68): decorrelation-length overlap parameter, (ncol, nlay)."""
+    alpha = np.zeros((ncol, nlay), order="F")
+    _check(lib().rrtmg_lw_hip_get_alpha(C.c_int(ncol), C.c_int(nlay), C.c_int(int(icld)), C.c_int(int(idcor)),
+                                        C.c_double(float(decorr_con)), _p(_f(dz, (ncol, nlay))), _p(_f(lat, (ncol,))),
+                                        C.c_int(int(juldat)), _p(_f(cldfrac, (ncol, nlay))), _p(alpha)))
+    return alpha
+
+
+def mcica_subcol_lw(ncol, nlay, icld, permuteseed, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha=None):
+    """mcica_subcol_lw (src/mcica_subcol_gen_lw.f90:183-185; `iplon` dropped: every column is generated).
+    Returns dict(cldfmcl, ciwpmcl, clwpmcl, taucmcl (140,ncol,nlay), reicmcl, relqmcl (ncol,nlay), irng)."""
+    z3 = lambda: np.zeros((NGPT, ncol, nlay), order="F")
+    z2 = lambda: np.zeros((ncol, nlay), order="F")
+    o = dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), reicmcl=z2(), relqmcl=z2(), taucmcl=z3())
+    irng_c = C.c_int(int(irng))
+    ins = [_f(play, (ncol, nlay)), _f(cldfrac, (ncol, nlay)), _f(ciwp, (ncol, nlay)), _f(clwp, (ncol, nlay)),
+           _f(rei, (ncol, nlay)), _f(rel, (ncol, nlay)), _f(tauc, (NBND, ncol, nlay))]
+    al = _p(_f(alpha, (ncol, nlay))) if alpha is not None else C.cast(None, _dp)
+    _check(lib().rrtmg_lw_hip_mcica_subcol(C.c_int(ncol), C.c_int(nlay), C.c_int(int(icld)), C.c_int(int(permuteseed)),
+                                           C.byref(irng_c), *[_p(x) for x in ins], al,
+                                           *[_p(o[k]) for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")]))
+    o["irng"] = irng_c.value
+    return o
+
+
+def rrtmg_lw_mcica_subcol(ncol, nlay, icld, idrv, permuteseed, irng, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr,
+                          ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, inflglw, iceflglw, liqflglw,
+                          cldfr, taucld, cicewp, cliqwp, reice, reliq, alpha, tauaer):
+    """mcica_subcol_lw followed by the McICA rrtmg_lw in one call; the sub-columns stay on the device as bit masks."""
+    a = _gcm_arrays(ncol, nlay, play, plev, tlay, tlev, tsfc,
+                    (h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr), emis)
+    cld = [_p(_f(cldfr, (ncol, nlay))), _p(_f(taucld, (NBND, ncol, nlay))), _p(_f(cicewp, (ncol, nlay))), _p(_f(cliqwp, (ncol, nlay))),
+           _p(_f(reice, (ncol, nlay))), _p(_f(reliq, (ncol, nlay))),
+           _p(_f(alpha, (ncol, nlay))) if alpha is not None else C.cast(None, _dp), _p(_f(tauaer, (ncol, nlay, NBND)))]
+    out = _out_arrays(ncol, nlay, idrv)
+    icld_c, irng_c = C.c_int(int(icld)), C.c_int(int(irng))
+    args = [C.c_int(ncol), C.c_int(nlay), C.byref(icld_c), C.c_int(int(idrv)), C.c_int(int(permuteseed)), C.byref(irng_c)]
+    args += [_p(x) for x in a] + [C.c_int(int(inflglw)), C.c_int(int(iceflglw)), C.c_int(int(liqflglw))] + cld + _out_ptrs(out, idrv)
+    _check(lib().rrtmg_lw_hip_run_mcica_subcol(*args))
+    out["icld"] = icld_c.value
+    out["irng"] = irng_c.value
+    return out
+
+
+def rrtmg_lw_mcica_subcol_from_dict(d, permuteseed, irng, alpha=None, icld=None, idrv=None):
+    icld = d["icld"] if icld is None else icld
+    idrv = d["idrv"] if idrv is None else idrv
+    return rrtmg_lw_mcica_subcol(d["ncol"], d["nlay"], icld, idrv, permuteseed, irng, *[d[k] for k in _GCM_ORDER], d["inflglw"],
+                                 d["iceflglw"], d["liqflglw"], d["cldfr"], d["taucld"], d["cicewp"], d["cliqwp"], d["reice"],
+                                 d["reliq"], alpha, d["tauaer"])
+
+
+def rrtmg_lw_mcica_subcol_device(d, out, permuteseed, irng, alpha=None, icld=None, idrv=None, stream=None):
+    """Device-resident fused generator + solver (torch CUDA tensors, column-fastest); see rrtmg_lw_device."""
+    icld = d["icld"] if icld is None else icld
+    idrv = d["idrv"] if idrv is None else idrv
+    icld_c, irng_c = C.c_int(int(icld)), C.c_int(int(irng))
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    args = [C.c_int(d["ncol"]), C.c_int(d["nlay"]), C.byref(icld_c), C.c_int(int(idrv)), C.c_int(int(permuteseed)), C.byref(irng_c)]
+    args += [ptr(d[k]) for k in _GCM_ORDER]
+    args += [C.c_int(int(d["inflglw"])), C.c_int(int(d["iceflglw"])), C.c_int(int(d["liqflglw"]))]
+    args += [ptr(d[k]) for k in ("cldfr", "taucld", "cicewp", "cliqwp", "reice", "reliq")]
+    args += [ptr(alpha) if alpha is not None else C.c_void_p(0), ptr(d["tauaer"])]
+    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")]
+    args.append(C.c_void_p(stream or 0))
+    _check(lib().rrtmg_lw_hip_run_mcica_subcol_device(*args))
+    return icld_c.value
+
+
 def finalize():
     global _initialised
     if _lib is not None:

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdarg>
 #include <mutex>
 #include <string>
@@ -29,8 +30,11 @@ struct State {
     void *ws_base = nullptr;
     size_t ws_bytes = 0;
     int ws_nlay = 0, ws_ncolb = 0;
-    bool ws_cloud = false;
+    bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
+    // McICA sub-column masks of all columns of the current call
+    unsigned *mask = nullptr;
+    size_t mask_bytes = 0;
     int batch = 32768;
     // host-entry staging
     void *stage_base = nullptr;
@@ -71,6 +75,8 @@ const char *physics_message(int code)
     case E_ICE_GEN_BOUNDS: return "ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS";
     case E_LIQ_BOUNDS: return "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS";
     case E_BAD_FLAG: return "INVALID CLOUD PROPERTY FLAG";
+    case E_MC_INFLAG1: return "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA";            // src/rrtmg_lw_cldprmc.f90:191
+    case E_KISS_PMID: return "MCICA_SUBCOL: KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS.";   // src/mcica_subcol_gen_lw.f90:465
     default: return "unknown physics error";
     }
 }
@@ -100,12 +106,13 @@ hipEvent_t get_event()
     } while (0)
 
 // (re)allocate the per-batch workspace
-int ensure_workspace(int nlay, int ncolb, bool cloud)
+int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
 {
-    if (G.ws_base && G.ws_nlay == nlay && G.ws_ncolb >= ncolb && (G.ws_cloud || !cloud)) return 0;
+    if (G.ws_base && G.ws_nlay == nlay && G.ws_ncolb >= ncolb && (G.ws_cloud || !cloud) && (G.ws_mc || !mc)) return 0;
     if (G.ws_base) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.ws_base)); G.ws_base = nullptr; }
     ncolb = std::max(ncolb, G.ws_nlay == nlay ? G.ws_ncolb : 0);
-    cloud = cloud || G.ws_cloud;
+    cloud = cloud || G.ws_cloud || mc;
+    mc = mc || G.ws_mc;
     const size_t n = (size_t)ncolb, L = (size_t)nlay;
     struct Item { void **p; size_t bytes; };
     Workspace &W = G.W;
@@ -132,6 +139,10 @@ int ensure_workspace(int nlay, int ncolb, bool cloud)
         items.push_back({(void **)&W.efcl, 16 * L * n * 8});
         items.push_back({(void **)&W.mrfac, (size_t)NMRFAC * (L + 2) * n * 8});
     }
+    if (mc) {
+        items.push_back({(void **)&W.odg, (size_t)NQUAD * 4 * L * n * 8});
+        items.push_back({(void **)&W.cfef, (size_t)NQUAD * 8 * L * n * 4});
+    }
     size_t total = 0;
     for (auto &it : items) total += align_up(it.bytes, 256);
     HIP_TRY(hipMalloc(&G.ws_base, total));
@@ -144,18 +155,36 @@ int ensure_workspace(int nlay, int ncolb, bool cloud)
     G.ws_nlay = nlay;
     G.ws_ncolb = ncolb;
     G.ws_cloud = cloud;
+    G.ws_mc = mc;
     return 0;
 }
 
-// one column batch, everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr
+int ensure_mask(int nlay, size_t ncol)
+{
+    const size_t bytes = (size_t)5 * nlay * ncol * sizeof(unsigned);
+    if (G.mask_bytes < bytes) {
+        if (G.mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.mask)); G.mask = nullptr; G.mask_bytes = 0; }
+        HIP_TRY(hipMalloc((void **)&G.mask, bytes));
+        G.mask_bytes = bytes;
+    }
+    return 0;
+}
+
+// one column batch, everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr, 3 rtrnmc (McICA; `mc` = the
+// sub-column arrays, or null when the sub-columns come from the generator's mask in G.W.mask)
 template <bool GCM>
 int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
-              const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out)
+              const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
 {
     const dim3 grid((nb + BLOCK - 1) / BLOCK), block(BLOCK);
     LAUNCH("k_colprep", (k_colprep<GCM>), grid, block, s, G.D, G.W, g, c, nb, col0, nct, idrv, istart);
-    if (mode != 0)
+    if (mode == 1 || mode == 2)
         LAUNCH("k_cloud", (k_cloud<GCM>), grid, block, s, G.D, G.W, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+    if (mode == 3) {
+        const dim3 cgrid((nb + BLOCK - 1) / BLOCK, nlay);
+        if (mc) LAUNCH("k_cloudmc<arrays>", (k_cloudmc<false>), cgrid, block, s, G.D, G.W, *mc, g, nb, col0, nct, inflag, iceflag, liqflag);
+        else LAUNCH("k_cloudmc<mask>", (k_cloudmc<true>), cgrid, block, s, G.D, G.W, McIn{}, g, nb, col0, nct, inflag, iceflag, liqflag);
+    }
     LayerArgs la;
     la.ncol = nb; la.col0 = col0; la.nct = nct; la.idrv = idrv; la.istart = istart; la.iend = iend;
     la.ktab_bytes = (int)(G.H.ktab.size() * 8);
@@ -163,8 +192,9 @@ int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int 
     const unsigned gx = (nb + BLOCK - 1) / BLOCK;
     const dim3 lgrid(gx, nlay);
 #define LAYER_GROUP(GR)                                                                                              \
-    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, false, GR>), lgrid, block, s, G.D, G.W, g, c, la);     \
-    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, true, GR>), lgrid, block, s, G.D, G.W, g, c, la);
+    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, block, s, G.D, G.W, g, c, la);         \
+    else if (mode == 3) { if constexpr (GCM) LAUNCH("k_layer<mcica," #GR ">", (k_layer<true, 2, GR>), lgrid, block, s, G.D, G.W, g, c, la); } \
+    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, block, s, G.D, G.W, g, c, la);
     LAYER_GROUP(0) LAYER_GROUP(1) LAYER_GROUP(2) LAYER_GROUP(3) LAYER_GROUP(4) LAYER_GROUP(5)
 #undef LAYER_GROUP
     SweepArgs sa;
@@ -174,6 +204,7 @@ int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int 
     const dim3 sgrid(gx, NQUAD);
     if (mode == 0) LAUNCH("k_sweep<0>", (k_sweep<0>), sgrid, block, s, G.D, G.W, sa);
     else if (mode == 1) LAUNCH("k_sweep<1>", (k_sweep<1>), sgrid, block, s, G.D, G.W, sa);
+    else if (mode == 3) LAUNCH("k_sweep<3>", (k_sweep<3>), sgrid, block, s, G.D, G.W, sa);
     else LAUNCH("k_sweep<2>", (k_sweep<2>), sgrid, block, s, G.D, G.W, sa);
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
     LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, G.W, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);
@@ -209,6 +240,140 @@ int check_common(int ncol, int nlay)
 {
     if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
     if (ncol < 1 || nlay < 1 || nlay > 603) return fail(RRTMG_LW_HIP_EARG, "bad dimensions ncol=%d nlay=%d", ncol, nlay);
+    return 0;
+}
+
+
+// ---- host-pointer staging ---------------------------------------------------------------------------
+// Every array of the interface is [rows][ncol][inner] with `inner` fastest (inner = 1 for (ncol,nlay) arrays,
+// 16 for taucld, 140 for the McICA sub-column arrays); a column block is therefore one 2-D copy.
+struct HostIn { const double *h; size_t inner, rows; double *d; };
+struct HostOut { double *h; size_t rows; double *d; bool active; };
+
+int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
+{
+    size_t tot = 0;
+    for (auto &a : ins) tot += a.h ? a.inner * a.rows * nb : 0;
+    for (auto &a : outs) tot += a.rows * nb;
+    if (int rc = ensure_stage(tot * 8 + 4096)) return rc;
+    double *p = (double *)G.stage_base;
+    for (auto &a : ins) { a.d = a.h ? p : nullptr; p += a.h ? a.inner * a.rows * nb : 0; }
+    for (auto &a : outs) { a.d = p; p += a.rows * nb; }
+    return 0;
+}
+
+int stage_in(std::vector<HostIn> &ins, size_t ncol, size_t col0, size_t nb, hipStream_t s)
+{
+    for (auto &a : ins) {
+        if (!a.h) continue;
+        const size_t w = a.inner * nb * 8, sp = a.inner * ncol * 8;
+        HIP_TRY(hipMemcpy2DAsync(a.d, w, a.h + a.inner * col0, sp, w, a.rows, hipMemcpyHostToDevice, s));
+    }
+    return 0;
+}
+
+int stage_out(std::vector<HostOut> &outs, size_t ncol, size_t col0, size_t nb, hipStream_t s)
+{
+    for (auto &a : outs) {
+        if (!a.active || !a.h) continue;
+        const size_t w = nb * 8, sp = ncol * 8;
+        HIP_TRY(hipMemcpy2DAsync(a.h + col0, sp, a.d, w, w, a.rows, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---- Mersenne Twister MT19937 (Matsumoto & Nishimura 1998; init_genrand / genrand_real1 of mt19937ar) -------
+// The reference's irng = 1 stream: src/mcica_random_numbers.f90:157-169 (scalar seeding), :262-295 (deviate on [0,1]).
+struct MT19937 {
+    uint32_t st[624];
+    int cur = 624;
+    explicit MT19937(uint32_t seed)
+    {
+        st[0] = seed;
+        for (int i = 1; i < 624; i++) st[i] = 1812433253u * (st[i - 1] ^ (st[i - 1] >> 30)) + (uint32_t)i;
+    }
+    void refill()
+    {
+        for (int k = 0; k < 624; k++) {
+            const uint32_t y = (st[k] & 0x80000000u) | (st[(k + 1) % 624] & 0x7fffffffu);
+            st[k] = st[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        cur = 0;
+    }
+    double real1()
+    {
+        if (cur >= 624) refill();
+        uint32_t y = st[cur++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return (double)y / 4294967295.0;
+    }
+};
+
+// Sub-column masks of all `ncol` columns into G.mask (device arrays play, cldfrac, alpha are (ncol,nlay)).
+int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, int irng, const double *play,
+                  const double *cldfrac, const double *alpha)
+{
+    if (nlay < 4 && irng == 0) return fail(RRTMG_LW_HIP_EARG, "the kissvec generator needs at least four layers");
+    if ((icld == 4 || icld == 5) && !alpha) return fail(RRTMG_LW_HIP_EARG, "icld = 4/5 needs alpha");
+    if (int rc = ensure_mask(nlay, (size_t)ncol)) return rc;
+    G.W.mask = G.mask;
+    G.W.mask_stride = (size_t)ncol;
+    G.W.mask_col0 = 0;
+    G.W.err = G.d_err;
+    SubcolIn in{play, cldfrac, alpha};
+    if (irng == 0) {
+        const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned);
+        if (lds > 160 * 1024) return fail(RRTMG_LW_HIP_EARG, "nlay=%d exceeds the generator's LDS budget", nlay);
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const dim3 grid((ncol + SUBCOL_BLOCK - 1) / SUBCOL_BLOCK), block(SUBCOL_BLOCK);
+        if (G.profile) {
+            State::ProfRec r{"k_subcol_kiss", get_event(), get_event()};
+            (void)hipEventRecord(r.a, s);
+            hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, G.W, in, ncol, nlay, icld, permuteseed);
+            (void)hipEventRecord(r.b, s);
+            G.prof.push_back(r);
+        } else {
+            hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, G.W, in, ncol, nlay, icld, permuteseed);
+        }
+    } else {
+        // one stream over (sub-column, column, layer): drawn here, applied per sub-column slab on the device
+        HIP_TRY(hipMemsetAsync(G.mask, 0, (size_t)5 * nlay * ncol * sizeof(unsigned), s));
+        const int nd = (icld == 4 || icld == 5) ? 2 : 1;
+        const size_t per = icld == 3 ? (size_t)ncol : (size_t)ncol * nlay * nd;
+        std::vector<double> buf(per);
+        double *d_rnd = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_rnd, per * 8));
+        MT19937 mt((uint32_t)permuteseed);
+        const dim3 grid((ncol + BLOCK - 1) / BLOCK), block(BLOCK);
+        int rc = 0;
+        for (int isub = 0; isub < NGPT && rc == 0; isub++) {
+            for (size_t k = 0; k < per; k++) buf[k] = mt.real1();
+            hipError_t e = hipMemcpyAsync(d_rnd, buf.data(), per * 8, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_subcol_slab, grid, block, 0, s, G.W, in, (const double *)d_rnd, ncol, nlay, icld, isub);
+                e = hipStreamSynchronize(s);
+            }
+            if (e != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "sub-column slab %d: %s", isub, hipGetErrorString(e));
+        }
+        (void)hipFree(d_rnd);
+        if (rc) return rc;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "generator launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int check_subcol_args(int ncol, int nlay, int icld, int *irng)
+{
+    if (int rc = check_common(ncol, nlay)) return rc;
+    if (!irng) return fail(RRTMG_LW_HIP_EARG, "irng is null");
+    if (icld < 0 || icld > 5) return fail(RRTMG_LW_HIP_EPHYSICS, "MCICA_SUBCOL: INVALID ICLD");   // src/mcica_subcol_gen_lw.f90:266
+    if (*irng != 0) *irng = 1;                                                                    // :442
     return 0;
 }
 
@@ -252,7 +417,7 @@ int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, do
     D.absice0[0] = G.H.absice0[0]; D.absice0[1] = G.H.absice0[1];
     D.abscld1 = G.H.abscld1; D.absliq0 = G.H.absliq0;
     D.heatfac = G.H.heatfac; D.fluxfac = G.H.fluxfac; D.oneminus = G.H.oneminus; D.bpade = G.H.bpade;
-    if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; }
+    if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; G.ws_mc = false; }
     G.device = device;
     G.init = true;
     G.err.clear();
@@ -268,6 +433,7 @@ void rrtmg_lw_hip_finalize(void)
     (void)hipDeviceSynchronize();
     if (G.ws_base) (void)hipFree(G.ws_base);
     if (G.stage_base) (void)hipFree(G.stage_base);
+    if (G.mask) (void)hipFree(G.mask);
     if (G.d_ktab) (void)hipFree(G.d_ktab);
     if (G.d_stat) (void)hipFree(G.d_stat);
     if (G.d_err) (void)hipFree(G.d_err);
@@ -483,6 +649,257 @@ int rrtmg_lw_hip_run_columns(
     if (int rc = run_batch<false>(s, ncol, 0, ncol, nlayers, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out)) return rc;
     double *ho[10] = {totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, dtotuflux_dt, dtotuclfl_dt};
     for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(ho[k], o[k], n * (L + 1) * 8, hipMemcpyDeviceToHost, s));
+    return read_physics_error(s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// McICA flavour
+// ---------------------------------------------------------------------------------------------------
+#define GCM_PARAMS                                                                                              \
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,         \
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr, \
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,               \
+    const double *ccl4vmr, const double *emis
+#define OUT_PARAMS                                                                                              \
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc, double *duflx_dt, double *duflxc_dt
+
+int rrtmg_lw_hip_run_mcica_device(
+    int ncol, int nlay, int *icld, int idrv, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfmcl, const double *taucmcl, const double *ciwpmcl, const double *clwpmcl,
+    const double *reicmcl, const double *relqmcl, const double *tauaer, OUT_PARAMS, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(ncol, nlay)) return rc;
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.f90:469
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int mode = *icld == 0 ? 0 : 3;                         // inatm leaves the cloud arrays zero when icld = 0 (:899-911)
+    const int nbmax = std::min(ncol, G.batch);
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, mode == 3)) return rc;
+    GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
+            ccl4vmr, emis, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tauaer};
+    McIn m{cldfmcl, taucmcl, ciwpmcl, clwpmcl, reicmcl, relqmcl};
+    ColIn c{};
+    FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
+    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
+        const int nb = std::min(nbmax, ncol - col0);
+        if (int rc = run_batch<true>((hipStream_t)stream, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, &m))
+            return rc;
+    }
+    return 0;
+}
+
+int rrtmg_lw_hip_run_mcica(
+    int ncol, int nlay, int *icld, int idrv, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfmcl, const double *taucmcl, const double *ciwpmcl, const double *clwpmcl,
+    const double *reicmcl, const double *relqmcl, const double *tauaer, OUT_PARAMS)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(ncol, nlay)) return rc;
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (*icld < 0 || *icld > 3) *icld = 2;
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int mode = *icld == 0 ? 0 : 3;
+    const bool cloud = mode == 3;
+    // the sub-column arrays are 4 x 140 x nlay doubles per column: bound the batch so that staging stays below ~4 GB
+    const int mcmax = (int)std::max<size_t>(64, ((size_t)4 << 30) / ((size_t)4 * NGPT * nlay * 8));
+    const int nbmax = std::min(ncol, cloud ? std::min(G.batch, mcmax) : G.batch);
+    if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud)) return rc;
+    const size_t L = (size_t)nlay;
+    std::vector<HostIn> ins = {
+        {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
+        {h2ovmr, 1, L, 0}, {o3vmr, 1, L, 0}, {co2vmr, 1, L, 0}, {ch4vmr, 1, L, 0}, {n2ovmr, 1, L, 0}, {o2vmr, 1, L, 0},
+        {cfc11vmr, 1, L, 0}, {cfc12vmr, 1, L, 0}, {cfc22vmr, 1, L, 0}, {ccl4vmr, 1, L, 0}, {emis, 1, 16, 0}, {tauaer, 1, 16 * L, 0},
+        {cloud ? cldfmcl : nullptr, NGPT, L, 0}, {cloud ? taucmcl : nullptr, NGPT, L, 0}, {cloud ? ciwpmcl : nullptr, NGPT, L, 0},
+        {cloud ? clwpmcl : nullptr, NGPT, L, 0}, {cloud ? reicmcl : nullptr, 1, L, 0}, {cloud ? relqmcl : nullptr, 1, L, 0}};
+    for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
+    if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null McICA cloud array");
+    std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
+                                 {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
+    if (int rc = stage_alloc(ins, outs, (size_t)nbmax)) return rc;
+    hipStream_t s = G.stream;
+    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
+        const int nb = std::min(nbmax, ncol - col0);
+        if (int rc = stage_in(ins, (size_t)ncol, (size_t)col0, (size_t)nb, s)) return rc;
+        GcmIn g{ins[0].d, ins[1].d, ins[2].d, ins[3].d, ins[4].d, ins[5].d, ins[6].d, ins[7].d, ins[8].d, ins[9].d, ins[10].d,
+                ins[11].d, ins[12].d, ins[13].d, ins[14].d, ins[15].d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ins[16].d};
+        McIn m{ins[17].d, ins[18].d, ins[19].d, ins[20].d, ins[21].d, ins[22].d};
+        ColIn c{};
+        FluxOut out{outs[0].d, outs[1].d, outs[2].d, outs[3].d, outs[4].d, outs[5].d, outs[6].d, outs[7].d, nullptr, nullptr};
+        if (int rc = run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, &m)) return rc;
+        if (int rc = stage_out(outs, (size_t)ncol, (size_t)col0, (size_t)nb, s)) return rc;
+    }
+    return read_physics_error(s);
+}
+
+int rrtmg_lw_hip_get_alpha(int ncol, int nlay, int icld, int idcor, double decorr_con, const double *dz, const double *lat,
+                           int juldat, const double *cldfrac, double *alpha)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(ncol, nlay)) return rc;
+    if (!(icld == 4 || icld == 5)) return 0;                      // alpha is only defined for the exponential overlaps
+    const size_t n = (size_t)ncol, L = (size_t)nlay;
+    std::vector<HostIn> ins = {{dz, 1, L, 0}, {lat, 1, 1, 0}, {cldfrac, 1, L, 0}};
+    for (auto &a : ins) if (!a.h) return fail(RRTMG_LW_HIP_EARG, "null input array");
+    std::vector<HostOut> outs = {{alpha, L, 0, true}};
+    if (int rc = stage_alloc(ins, outs, n)) return rc;
+    hipStream_t s = G.stream;
+    if (int rc = stage_in(ins, n, 0, n, s)) return rc;
+    const dim3 grid((ncol + BLOCK - 1) / BLOCK, nlay), block(BLOCK);
+    hipLaunchKernelGGL(k_alpha, grid, block, 0, s, ncol, nlay, icld, idcor, decorr_con, (const double *)ins[0].d, (const double *)ins[1].d,
+                       juldat, (const double *)ins[2].d, outs[0].d);
+    return stage_out(outs, n, 0, n, s);
+}
+
+int rrtmg_lw_hip_mcica_subcol_device(
+    int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
+    const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
+    double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
+    if (icld == 0) return 0;                                      // src/mcica_subcol_gen_lw.f90:265
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = generate_mask(s, ncol, nlay, icld, permuteseed, *irng, play, cldfrac, alpha)) return rc;
+    const size_t tot = (size_t)NGPT * ncol;
+    const dim3 grid((unsigned)((tot + BLOCK - 1) / BLOCK), nlay), block(BLOCK);
+    LAUNCH("k_subcol_expand", k_subcol_expand, grid, block, s, G.W, ciwp, clwp, tauc, ncol, nlay, 0, cldfmcl, ciwpmcl, clwpmcl, taucmcl);
+    HIP_TRY(hipMemcpyAsync(reicmcl, rei, (size_t)ncol * nlay * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(relqmcl, rel, (size_t)ncol * nlay * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int rrtmg_lw_hip_mcica_subcol(
+    int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
+    const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
+    double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
+    if (icld == 0) return 0;
+    const size_t n = (size_t)ncol, L = (size_t)nlay;
+    const bool two = icld == 4 || icld == 5;
+    std::vector<HostIn> ins = {{play, 1, L, 0}, {cldfrac, 1, L, 0}, {ciwp, 1, L, 0}, {clwp, 1, L, 0}, {tauc, NBND, L, 0},
+                               {two ? alpha : nullptr, 1, L, 0}};
+    for (size_t k = 0; k < 5; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array");
+    if (two && !alpha) return fail(RRTMG_LW_HIP_EARG, "icld = 4/5 needs alpha");
+    std::vector<HostOut> outs;                                   // outputs are copied with plain 1-D copies below
+    if (int rc = stage_alloc(ins, outs, n)) return rc;
+    hipStream_t s = G.stream;
+    if (int rc = stage_in(ins, n, 0, n, s)) return rc;
+    if (int rc = generate_mask(s, ncol, nlay, icld, permuteseed, *irng, ins[0].d, ins[1].d, ins[5].d)) return rc;
+    // expand layer slabs through a bounded device buffer: 4 arrays x 140 x ncol doubles per layer
+    const size_t slab = (size_t)NGPT * n;
+    double *d_out = nullptr;
+    const int lchunk = (int)std::max<size_t>(1, std::min<size_t>(L, ((size_t)1 << 30) / (slab * 4 * 8 + 1)));
+    HIP_TRY(hipMalloc((void **)&d_out, slab * 4 * 8 * lchunk));
+    int rc = 0;
+    for (int l0 = 0; l0 < nlay && rc == 0; l0 += lchunk) {
+        const int nl = std::min(lchunk, nlay - l0);
+        double *o[4];
+        for (int k = 0; k < 4; k++) o[k] = d_out + (size_t)k * slab * lchunk;
+        const dim3 grid((unsigned)((slab + BLOCK - 1) / BLOCK), nl), block(BLOCK);
+        hipLaunchKernelGGL(k_subcol_expand, grid, block, 0, s, G.W, (const double *)ins[2].d, (const double *)ins[3].d,
+                           (const double *)ins[4].d, ncol, nlay, l0, o[0], o[1], o[2], o[3]);
+        double *ho[4] = {cldfmcl, ciwpmcl, clwpmcl, taucmcl};
+        for (int k = 0; k < 4 && rc == 0; k++) {
+            hipError_t e = hipMemcpyAsync(ho[k] + slab * l0, d_out + (size_t)k * slab * lchunk, slab * nl * 8, hipMemcpyDeviceToHost, s);
+            if (e != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "sub-column copy: %s", hipGetErrorString(e));
+        }
+        if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "sub-column expand failed");
+    }
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    memcpy(reicmcl, rei, n * L * 8);                            // :283-284
+    memcpy(relqmcl, rel, n * L * 8);
+    return read_physics_error(s);
+}
+
+// Fused generator + solver: mcica_subcol_lw followed by the McICA rrtmg_lw without materialising the (140,ncol,nlay)
+// sub-column arrays (they are implied by the mask and the grid-mean cloud properties).  DEVICE pointers.
+int rrtmg_lw_hip_run_mcica_subcol_device(
+    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
+    const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS, void *stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int icld_gen = *icld;
+    if (*icld > 3) *icld = 2;                                     // what rrtmg_lw does to the generator's icld (src/rrtmg_lw_rad.f90:469)
+    const int mode = icld_gen == 0 ? 0 : 3;
+    hipStream_t s = (hipStream_t)stream;
+    const int nbmax = std::min(ncol, G.batch);
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, mode == 3)) return rc;
+    if (mode == 3)
+        if (int rc = generate_mask(s, ncol, nlay, icld_gen, permuteseed, *irng, play, cldfr, alpha)) return rc;
+    GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
+            ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
+    ColIn c{};
+    FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
+    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
+        const int nb = std::min(nbmax, ncol - col0);
+        if (int rc = run_batch<true>(s, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, nullptr)) return rc;
+    }
+    return 0;
+}
+
+int rrtmg_lw_hip_run_mcica_subcol(
+    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
+    const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int icld_gen = *icld;
+    if (*icld > 3) *icld = 2;
+    const int mode = icld_gen == 0 ? 0 : 3;
+    const bool cloud = mode == 3, two = icld_gen == 4 || icld_gen == 5;
+    const int nbmax = std::min(ncol, G.batch);
+    if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud)) return rc;
+    const size_t L = (size_t)nlay, n = (size_t)ncol;
+    hipStream_t s = G.stream;
+    // 1. masks of all columns (the Mersenne-Twister stream couples the columns): needs play, cldfr, alpha of every column
+    double *d_gen = nullptr;
+    if (cloud) {
+        if (!play || !cldfr || (two && !alpha)) return fail(RRTMG_LW_HIP_EARG, "null generator input");
+        HIP_TRY(hipMalloc((void **)&d_gen, n * L * 8 * 3));
+        hipError_t e = hipMemcpyAsync(d_gen, play, n * L * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_gen + n * L, cldfr, n * L * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && two) e = hipMemcpyAsync(d_gen + 2 * n * L, alpha, n * L * 8, hipMemcpyHostToDevice, s);
+        int rc = e == hipSuccess ? 0 : fail(RRTMG_LW_HIP_EHIP, "generator input copy: %s", hipGetErrorString(e));
+        if (rc == 0) rc = generate_mask(s, ncol, nlay, icld_gen, permuteseed, *irng, d_gen, d_gen + n * L, two ? d_gen + 2 * n * L : nullptr);
+        if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "generator failed");
+        (void)hipFree(d_gen);
+        if (rc) return rc;
+    }
+    // 2. column batches
+    std::vector<HostIn> ins = {
+        {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
+        {h2ovmr, 1, L, 0}, {o3vmr, 1, L, 0}, {co2vmr, 1, L, 0}, {ch4vmr, 1, L, 0}, {n2ovmr, 1, L, 0}, {o2vmr, 1, L, 0},
+        {cfc11vmr, 1, L, 0}, {cfc12vmr, 1, L, 0}, {cfc22vmr, 1, L, 0}, {ccl4vmr, 1, L, 0}, {emis, 1, 16, 0}, {tauaer, 1, 16 * L, 0},
+        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, NBND, L, 0}, {cloud ? cicewp : nullptr, 1, L, 0},
+        {cloud ? cliqwp : nullptr, 1, L, 0}, {cloud ? reice : nullptr, 1, L, 0}, {cloud ? reliq : nullptr, 1, L, 0}};
+    for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
+    if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
+    std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
+                                 {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
+    if (int rc = stage_alloc(ins, outs, (size_t)nbmax)) return rc;
+    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
+        const int nb = std::min(nbmax, ncol - col0);
+        if (int rc = stage_in(ins, n, (size_t)col0, (size_t)nb, s)) return rc;
+        GcmIn g{ins[0].d, ins[1].d, ins[2].d, ins[3].d, ins[4].d, ins[5].d, ins[6].d, ins[7].d, ins[8].d, ins[9].d, ins[10].d,
+                ins[11].d, ins[12].d, ins[13].d, ins[14].d, ins[15].d, ins[17].d, ins[18].d, ins[19].d, ins[20].d, ins[21].d, ins[22].d, ins[16].d};
+        ColIn c{};
+        FluxOut out{outs[0].d, outs[1].d, outs[2].d, outs[3].d, outs[4].d, outs[5].d, outs[6].d, outs[7].d, nullptr, nullptr};
+        G.W.mask_col0 = (size_t)col0;                             // staged arrays start at column 0, the mask holds all columns
+        if (int rc = run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, nullptr)) return rc;
+        if (int rc = stage_out(outs, n, (size_t)col0, (size_t)nb, s)) return rc;
+    }
+    G.W.mask_col0 = 0;
     return read_physics_error(s);
 }
 

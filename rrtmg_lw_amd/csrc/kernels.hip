@@ -78,6 +78,12 @@ struct Workspace {
     Part2 *pdn, *pup;   // [NQUAD][nlay+1][ncolb]
     Part2 *dpart;       // [NQUAD][nlay+1][ncolb]  (idrv = 1)
     int *err;           // [1] first physics error code
+    // McICA (rtrnmc): per-g-point cloud terms, written by k_cloudmc
+    double *odg;        // [NQUAD][nlay][ncolb][4]     secdiff(band) * taucmc(g)
+    float *cfef;        // [NQUAD][nlay][ncolb][8]     {cldfmc(g) x4, efclfrac(g) x4}
+    unsigned *mask;     // [5][nlay][mask_stride]      sub-column cloud mask of ALL columns of the call (indexed by the global
+    size_t mask_stride; //                             column mask_col0 + col0 + col), bit k of word w = sub-column 32 w + k
+    size_t mask_col0;
 };
 
 // GCM-interface inputs (device pointers, column stride = ncol_total), reference src/rrtmg_lw_rad.nomcica.f90:219-276
@@ -91,12 +97,18 @@ struct ColIn {
     const double *pavel, *tavel, *pz, *tz, *tbound, *semiss, *coldry, *wkl, *wbrodl, *wx, *pwvcm;
     const double *cldfrac, *tauc, *ciwp, *clwp, *rei, *rel, *taua;
 };
+// McICA cloud inputs (device pointers), reference src/rrtmg_lw_rad.f90:267-298
+struct McIn {
+    const double *cldfmcl, *taucmcl, *ciwpmcl, *clwpmcl;   // (140, ncol_total, nlay)
+    const double *reicmcl, *relqmcl;                       // (ncol_total, nlay)
+};
 struct FluxOut {
     double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *duflx_dt, *duflxc_dt;   // stride ncol_total
     double *fnet, *fnetc;                                                     // optional (column entry)
 };
 
-enum ErrCode { E_NONE = 0, E_ICE_SMALL = 1, E_ICE_BOUNDS = 2, E_ICE_GEN_BOUNDS = 3, E_LIQ_BOUNDS = 4, E_BAD_FLAG = 5 };
+enum ErrCode { E_NONE = 0, E_ICE_SMALL = 1, E_ICE_BOUNDS = 2, E_ICE_GEN_BOUNDS = 3, E_LIQ_BOUNDS = 4, E_BAD_FLAG = 5,
+               E_MC_INFLAG1 = 6, E_KISS_PMID = 7 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -857,7 +869,8 @@ static_assert(NQUAD == 38, "quad table");
 struct alignas(16) scr4 { scr_t v[4]; };
 
 // cells of quad `qi` (g-points 4*qi .. 4*qi+3 of band B) of one (layer, column)
-template <int B, bool CLOUD, bool LOWER, int N>
+// CLOUD: 0 clear-sky set, 1 one cloud optical depth per band (rtrn / rtrnmr), 2 one per g-point (rtrnmc)
+template <int B, int CLOUD, bool LOWER, int N>
 __device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, int qi, int lay, int col,
                                           double blay, double dplankup, double dplankdn, double secdiff, double taua,
                                           int cloudy, double odcld, double pb, double dpb, bool idrv)
@@ -881,6 +894,14 @@ __device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W
             if (idrv) W.rad0[(size_t)(4 * NQUAD + quad * 4 + j) * ncb + col] = valid ? frac[j] * dpb : 0.0;
         }
     }
+    double odc[4] = {odcld, odcld, odcld, odcld};
+    if constexpr (CLOUD == 2) {
+        if (cloudy) {
+            const double2 *po = reinterpret_cast<const double2 *>(W.odg + (((size_t)quad * nlay + (lay - 1)) * ncb + col) * 4);
+            const double2 a = po[0], b = po[1];
+            odc[0] = a.x; odc[1] = a.y; odc[2] = b.x; odc[3] = b.y;
+        }
+    }
     scr4 oatr, obbd, obbu, oatot, obbdt, obbut;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -896,7 +917,7 @@ __device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W
             obbu.v[j] = (scr_t)(fr * (blay + tfn * dplankup));
         } else {
             // cloudy layer, three sub-branches: rtrn :372-435
-            double odtot = od + odcld;
+            double odtot = od + odc[j];
             double atr, tfgas, atot, tftot;
             if (odtot < 0.06) {
                 atr = od - 0.5 * od * od; tfgas = 0.166667 * od;
@@ -911,7 +932,7 @@ __device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W
                 const double2 e = reinterpret_cast<const double2 *>(lut)[ig];
                 od = (S + T.sl.tau_tbl)[ig];
                 atr = 1. - e.x; tfgas = e.y;
-                odtot = od + odcld;
+                odtot = od + odc[j];
                 const int it = (int)(10000.0 * (odtot / (bpade + odtot)) + 0.5);
                 const double2 e2 = reinterpret_cast<const double2 *>(lut)[it];
                 atot = 1. - e2.x; tftot = e2.y;
@@ -940,7 +961,7 @@ __device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W
 #endif
 
 // all quads of band B for one (layer, column)
-template <int B, bool CLOUD>
+template <int B, int CLOUD>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
                                            __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, size_t gc, int indlay, double tlayfrac,
                                            int indhi, double thifrac, int indlo, double tlofrac, int cloudy, int ncbands)
@@ -949,7 +970,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
     const int nlay = W.nlay, nct = a.nct;
     const double *S = T.stat;
     double odcld = 0.0;
-    if (CLOUD) {
+    if (CLOUD == 1) {
         if (cloudy) {
             const int ibc = ncbands == 1 ? 0 : (ncbands == 5 ? (B <= 2 ? B - 1 : (B <= 5 ? 2 : (B <= 8 ? 3 : 4))) : B - 1);   // rtrn :343-349
             odcld = W.odcld[((size_t)ibc * nlay + (lay - 1)) * ncb + col];
@@ -998,7 +1019,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
 //   0: 3,14   1: 5,15   2: 4,10,16   3: 7,8   4: 9,11,13   5: 1,2,6,12
 constexpr int NLGROUP = 6;
 
-template <bool GCM, bool CLOUD, int GROUP>
+template <bool GCM, int CLOUD, int GROUP>
 __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1118,7 +1139,7 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
     int cloudy = 0, ncbands = 1;
     if (CLOUD) {
         cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
-        if (cloudy) ncbands = W.ncbands[col];
+        if (CLOUD == 1 && cloudy) ncbands = W.ncbands[col];
     }
     // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
     const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
@@ -1135,10 +1156,344 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_cloudmc : McICA cloud terms per g-point: cldprmc (src/rrtmg_lw_cldprmc.f90:49-279) followed by the cloud
+//             part of rtrnmc's set-up (src/rrtmg_lw_rtrnmc.f90:307-329).  One thread per (column, layer).
+//   FROMMASK = false: the sub-column arrays of the reference's McICA argument list, (140,ncol,nlay)
+//                     (src/rrtmg_lw_rad.f90:267-298)
+//   FROMMASK = true : sub-columns given by the generator's bit mask (k_subcol_*) plus the grid-mean cloud
+//                     properties - the same values the generator would have expanded into those arrays
+//                     (src/mcica_subcol_gen_lw.f90:664-680).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int band_g0(int B)      // 0-based first g-point of band B among the 140
+{
+    int s = 0;
+    for (int b = 1; b < B; b++) s += band_ng(b);
+    return s;
+}
+static_assert(band_g0(17) == NGPT, "g-point table");
+
+template <bool FROMMASK>
+__global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn m, GcmIn g, int ncol, int col0, int nct,
+                                                 int inflag, int iceflag, int liqflag)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncol) return;
+    const int lay = blockIdx.y + 1;
+    const int nlay = W.nlay;
+    const size_t ncb = W.ncolb;
+    const size_t gc = (size_t)col0 + col;
+    const size_t cl = gc + (size_t)nct * (lay - 1);
+    const double *S = T.stat;
+    const double *absice1 = S + T.sl.absice1, *absice2 = S + T.sl.absice2, *absice3 = S + T.sl.absice3, *absliq1 = S + T.sl.absliq1;
+    const double cldmin = 1.e-20;
+    const double radice = FROMMASK ? g.reice[cl] : m.reicmcl[cl];
+    const double radliq = FROMMASK ? g.reliq[cl] : m.relqmcl[cl];
+    double mciwp = 0.0, mclwp = 0.0;
+    unsigned mw[5] = {0u, 0u, 0u, 0u, 0u};
+    if (FROMMASK) {
+        mciwp = g.cicewp[cl];
+        mclwp = g.cliqwp[cl];
+#pragma unroll
+        for (int w = 0; w < 5; w++) mw[w] = W.mask[((size_t)w * nlay + (lay - 1)) * W.mask_stride + W.mask_col0 + gc];
+    }
+    // particle-size interpolation positions (band independent): cldprmc :208-262
+    int ice_err = 0, liq_err = 0, index_i = 1, index_l = 1;
+    double fint_i = 0.0, fint_l = 0.0;
+    if (iceflag == 0) { if (radice < 10.0) ice_err = E_ICE_SMALL; }
+    else if (iceflag == 1) { if (radice < 13.0 || radice > 130.) ice_err = E_ICE_BOUNDS; }
+    else if (iceflag == 2) {
+        if (radice < 5.0 || radice > 131.0) ice_err = E_ICE_BOUNDS;
+        const double factor = (radice - 2.) / 3.;
+        index_i = (int)factor; if (index_i == 43) index_i = 42;
+        fint_i = factor - (double)index_i;
+        index_i = clampi(index_i, 1, 42);
+    } else if (iceflag == 3) {
+        if (radice < 5.0 || radice > 140.0) ice_err = E_ICE_GEN_BOUNDS;
+        const double factor = (radice - 2.) / 3.;
+        index_i = (int)factor; if (index_i == 46) index_i = 45;
+        fint_i = factor - (double)index_i;
+        index_i = clampi(index_i, 1, 45);
+    }
+    if (liqflag == 1) {
+        if (radliq < 2.5 || radliq > 60.) liq_err = E_LIQ_BOUNDS;
+        index_l = (int)(radliq - 1.5);
+        if (index_l == 0) index_l = 1;
+        if (index_l == 58) index_l = 57;
+        fint_l = radliq - 1.5 - (double)index_l;
+        index_l = clampi(index_l, 1, 57);
+    }
+    int err = 0, any = 0, quad = 0;
+#pragma unroll 1
+    for (int B = 1; B <= NBND; B++) {
+        const int ng = band_ng(B), g0 = band_g0(B);
+        const double secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
+        double ai = 0.0, al = 0.0;         // coefficients of a cell of this band that holds ice / liquid
+        if (inflag == 2) {
+            if (iceflag == 0) ai = T.absice0[0] + T.absice0[1] / radice;
+            else if (iceflag == 1) {
+                const int icx = B <= 2 ? B : (B <= 5 ? 3 : (B <= 8 ? 4 : 5));                 // ipat(1:16,1), cldprmc :214-216
+                ai = absice1[2 * (icx - 1)] + absice1[2 * (icx - 1) + 1] / radice;
+            } else if (iceflag == 2) { const double *t = absice2 + 43 * (B - 1); ai = t[index_i - 1] + fint_i * (t[index_i] - t[index_i - 1]); }
+            else if (iceflag == 3) { const double *t = absice3 + 46 * (B - 1); ai = t[index_i - 1] + fint_i * (t[index_i] - t[index_i - 1]); }
+            if (liqflag == 0) al = T.absliq0;
+            else if (liqflag == 1) { const double *t = absliq1 + 58 * (B - 1); al = t[index_l - 1] + fint_l * (t[index_l] - t[index_l - 1]); }
+        }
+        const double tband = FROMMASK ? g.taucld[(B - 1) + (size_t)NBND * cl] : 0.0;
+#pragma unroll 1
+        for (int qi = 0; qi < (ng + 3) / 4; qi++, quad++) {
+            double cf[4], tau[4], ci[4], cw[4];
+            if (FROMMASK) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ig = g0 + 4 * qi + j;
+                    const bool on = (4 * qi + j < ng) && ((mw[ig >> 5] >> (ig & 31)) & 1u);
+                    cf[j] = on ? 1.0 : 0.0; tau[j] = on ? tband : 0.0; ci[j] = on ? mciwp : 0.0; cw[j] = on ? mclwp : 0.0;
+                }
+            } else {
+                const size_t base = (size_t)(g0 + 4 * qi) + (size_t)NGPT * cl;     // 16-byte aligned: every band starts on an even g
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (4 * qi + 2 * h < ng) {              // band sizes are even: a pair is inside the band or outside it
+                        const double2 a = *reinterpret_cast<const double2 *>(m.cldfmcl + base + 2 * h);
+                        const double2 b = *reinterpret_cast<const double2 *>(m.taucmcl + base + 2 * h);
+                        const double2 c = *reinterpret_cast<const double2 *>(m.ciwpmcl + base + 2 * h);
+                        const double2 d = *reinterpret_cast<const double2 *>(m.clwpmcl + base + 2 * h);
+                        cf[2 * h] = a.x; cf[2 * h + 1] = a.y; tau[2 * h] = b.x; tau[2 * h + 1] = b.y;
+                        ci[2 * h] = c.x; ci[2 * h + 1] = c.y; cw[2 * h] = d.x; cw[2 * h + 1] = d.y;
+                    } else {
+                        cf[2 * h] = cf[2 * h + 1] = 0.0; tau[2 * h] = tau[2 * h + 1] = 0.0;
+                        ci[2 * h] = ci[2 * h + 1] = 0.0; cw[2 * h] = cw[2 * h + 1] = 0.0;
+                    }
+                }
+            }
+            double od[4];
+            float ocf[4], oef[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                double t = tau[j];
+                if (cf[j] >= cldmin && (ci[j] + cw[j] >= cldmin || t >= cldmin)) {        // cldprmc :181-183
+                    if (inflag == 1) err = E_MC_INFLAG1;                                     // :190-191
+                    else if (inflag == 2) {
+                        double a_i = 0.0, a_l = 0.0;
+                        if (ci[j] != 0.0 && iceflag >= 0 && iceflag <= 3) { a_i = ai; if (ice_err) err = ice_err; }
+                        if (cw[j] != 0.0) {
+                            if (liqflag == 0) a_l = al;
+                            else if (liqflag == 1) { a_l = al; if (liq_err) err = liq_err; }
+                        }
+                        t = ci[j] * a_i + cw[j] * a_l;                                          // :267-268
+                    }
+                }
+                od[j] = 0.0; oef[j] = 0.f;
+                if (cf[j] == 1.0) {                                                             // rtrnmc :311-317
+                    od[j] = secdiff * t;
+                    oef[j] = (float)((1. - exp(-od[j])) * cf[j]);
+                    any = 1;
+                }
+                ocf[j] = (float)cf[j];
+            }
+            const size_t so = ((size_t)quad * nlay + (lay - 1)) * ncb + col;
+            double2 *po = reinterpret_cast<double2 *>(W.odg + so * 4);
+            po[0] = make_double2(od[0], od[1]);
+            po[1] = make_double2(od[2], od[3]);
+            float4 *pf = reinterpret_cast<float4 *>(W.cfef + so * 8);
+            pf[0] = make_float4(ocf[0], ocf[1], ocf[2], ocf[3]);
+            pf[1] = make_float4(oef[0], oef[1], oef[2], oef[3]);
+        }
+    }
+    W.cflag[(size_t)lay * ncb + col] = any;
+    if (any) atomicOr(&W.cflag[col], 8);
+    if (lay == 1) W.cflag[(size_t)(nlay + 1) * ncb + col] = 0;
+    if (err) atomicCAS(W.err, 0, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// McICA sub-column generator: mcica_subcol_lw / generate_stochastic_clouds (src/mcica_subcol_gen_lw.f90:183-703).
+// The GCM routine does not compile as shipped; the per-column semantics are those of its
+// compilable one-column statement, src/mcica_subcol_gen_lw.1col.f90:171-710.
+//   k_subcol_kiss  irng = 0: every column owns a KISS stream seeded from its four lowest layer pressures
+//                  (:460-474) and consumed in (sub-column, layer) order -> one thread per column, the 140 x nlay
+//                  decisions are accumulated as bit masks in LDS and written out coalesced.
+//   k_subcol_slab  irng = 1: the Mersenne-Twister stream is ONE sequence over (sub-column, column, layer)
+//                  (:497-503); the host draws it (driver.hip) and this kernel applies the overlap rules to
+//                  the slab of one sub-column.
+//   k_subcol_expand  mask -> the (140,ncol,nlay) arrays of the reference interface (:664-680).
+//   k_alpha        get_alpha (src/mcica_subcol_gen_lw.f90:68-180).
+// Integer arithmetic is 32-bit wrap-around with logical shifts and the uniform deviates are formed without
+// FMA contraction, so the cloud masks are bit-identical to the reference's.
+// ------------------------------------------------------------------------------------------------
+struct SubcolIn { const double *play, *cldfrac, *alpha; };      // each (ncol_total, nlay), device pointers
+
+struct Kiss { unsigned a, b, c, d; };
+
+__device__ __forceinline__ double kiss_next(Kiss &s)           // kissvec, src/mcica_subcol_gen_lw.f90:711-745
+{
+#pragma clang fp contract(off)
+    s.a = 69069u * s.a + 1327217885u;
+    s.b ^= s.b << 13; s.b ^= s.b >> 17; s.b ^= s.b << 5;
+    s.c = 18000u * (s.c & 65535u) + (s.c >> 16);
+    s.d = 30903u * (s.d & 65535u) + (s.d >> 16);
+    const unsigned k = s.a + s.b + (s.c << 16) + s.d;
+    const double r = (double)(int)k * 2.328306e-10;
+    return r + 0.5;
+}
+
+// overlap rule applied to the deviate of (sub-column, layer l) given the final deviate of layer l-1
+__device__ __forceinline__ double overlap_rule(int icld, int l, double x, double x2, double prev, double cf_below, double alpha_l)
+{
+#pragma clang fp contract(off)
+    if (l > 0) {
+        if (icld == 2) {                                        // maximum-random, .1col :440-448
+            const double one_m = 1. - cf_below;
+            if (prev > one_m) x = prev;
+            else x = x * one_m;
+        } else if (icld == 4 || icld == 5) {                    // exponential(-random), .1col :492-496, :521-525
+            if (x2 < alpha_l) x = prev;
+        }
+    }
+    return x;
+}
+
+constexpr int SUBCOL_BLOCK = 64;
+
+__global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn in, int ncol, int nlay, int icld, int permuteseed)
+{
+#pragma clang fp contract(off)
+    extern __shared__ unsigned acc[];                           // [nlay][SUBCOL_BLOCK]
+    const int tid = threadIdx.x;
+    const size_t gc = (size_t)blockIdx.x * SUBCOL_BLOCK + tid;
+    if (gc >= (size_t)ncol) return;
+    const double cldmin = 1.0e-20;
+    Kiss s;
+    {
+        const double p1 = in.play[gc] * 1.e2, p2 = in.play[gc + (size_t)ncol] * 1.e2;
+        const double p3 = in.play[gc + (size_t)ncol * 2] * 1.e2, p4 = in.play[gc + (size_t)ncol * 3] * 1.e2;
+        if (p1 < p2) { atomicCAS(W.err, 0, (int)E_KISS_PMID); return; }            // :463-466
+        s.a = (unsigned)(int)((p1 - (double)(long long)p1) * 1000000000.);
+        s.b = (unsigned)(int)((p2 - (double)(long long)p2) * 1000000000.);
+        s.c = (unsigned)(int)((p3 - (double)(long long)p3) * 1000000000.);
+        s.d = (unsigned)(int)((p4 - (double)(long long)p4) * 1000000000.);
+    }
+    for (int q = 0; q < permuteseed; q++) (void)kiss_next(s);                       // :471-474
+    const bool two = icld == 4 || icld == 5;
+#pragma unroll 1
+    for (int w = 0; w < 5; w++) {
+        for (int l = 0; l < nlay; l++) acc[l * SUBCOL_BLOCK + tid] = 0u;
+        const int nb = min(32, NGPT - 32 * w);
+#pragma unroll 1
+        for (int k = 0; k < nb; k++) {
+            double r3 = 0.0;
+            if (icld == 3) r3 = kiss_next(s);
+            double prev = 0.0, cf_below = 0.0;
+#pragma unroll 1
+            for (int l = 0; l < nlay; l++) {
+                double x, x2 = 0.0;
+                if (icld == 3) x = r3;
+                else { x = kiss_next(s); if (two) x2 = kiss_next(s); }
+                double cf = in.cldfrac[gc + (size_t)ncol * l];
+                if (cf < cldmin) cf = 0.0;
+                const double al = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
+                x = overlap_rule(icld, l, x, x2, prev, cf_below, al);
+                prev = x; cf_below = cf;
+                if (x >= 1. - cf) acc[l * SUBCOL_BLOCK + tid] |= 1u << k;               // :655-661
+            }
+        }
+        for (int l = 0; l < nlay; l++) W.mask[((size_t)w * nlay + l) * W.mask_stride + gc] = acc[l * SUBCOL_BLOCK + tid];
+    }
+}
+
+// rnd: the deviates of sub-column `isub` for all columns in stream order: icld == 3: [ncol]; otherwise
+// [ncol][nlay][nd] with nd = 2 for icld 4/5 (CDF, CDF2), else 1.  The mask must have been zeroed.
+__global__ __launch_bounds__(256) void k_subcol_slab(Workspace W, SubcolIn in, const double *rnd, int ncol, int nlay, int icld, int isub)
+{
+#pragma clang fp contract(off)
+    const size_t gc = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gc >= (size_t)ncol) return;
+    const double cldmin = 1.0e-20;
+    const bool two = icld == 4 || icld == 5;
+    const int nd = two ? 2 : 1;
+    const int w = isub >> 5;
+    const unsigned bit = 1u << (isub & 31);
+    double prev = 0.0, cf_below = 0.0;
+    for (int l = 0; l < nlay; l++) {
+        double x, x2 = 0.0;
+        if (icld == 3) x = rnd[gc];
+        else {
+            const size_t o = (gc * nlay + l) * nd;
+            x = rnd[o];
+            if (two) x2 = rnd[o + 1];
+        }
+        double cf = in.cldfrac[gc + (size_t)ncol * l];
+        if (cf < cldmin) cf = 0.0;
+        const double al = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
+        x = overlap_rule(icld, l, x, x2, prev, cf_below, al);
+        prev = x; cf_below = cf;
+        if (x >= 1. - cf) W.mask[((size_t)w * nlay + l) * W.mask_stride + gc] |= bit;
+    }
+}
+
+__device__ __forceinline__ int g_band(int ig)            // 1-based band of 0-based g-point ig (ngb)
+{
+    int b = 1;
+#pragma unroll
+    for (int B = 2; B <= NBND; B++) b += (ig >= band_g0(B)) ? 1 : 0;
+    return b;
+}
+
+// one thread per (sub-column, column) of one layer: fully coalesced stores into the (140,ncol,nlay) arrays.
+// Layers l0 .. l0 + gridDim.y - 1 are written to the output arrays starting at their layer 0.
+__global__ __launch_bounds__(256) void k_subcol_expand(Workspace W, const double *ciwp, const double *clwp, const double *tauc,
+                                                       int ncol, int nlay, int l0, double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *taucmcl)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)NGPT * ncol) return;
+    const int l = l0 + blockIdx.y;
+    const int isub = (int)(e % NGPT);
+    const size_t gc = e / NGPT;
+    const unsigned word = W.mask[((size_t)(isub >> 5) * nlay + l) * W.mask_stride + gc];
+    const bool on = (word >> (isub & 31)) & 1u;
+    const size_t cl = gc + (size_t)ncol * l;
+    const size_t o = e + (size_t)NGPT * ncol * blockIdx.y;
+    cldfmcl[o] = on ? 1.0 : 0.0;
+    ciwpmcl[o] = on ? ciwp[cl] : 0.0;
+    clwpmcl[o] = on ? clwp[cl] : 0.0;
+    taucmcl[o] = on ? tauc[(g_band(isub) - 1) + (size_t)NBND * cl] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int idcor, double decorr_con, const double *dz,
+                                               const double *lat, int juldat, const double *cldfrac, double *alpha)
+{
+    const size_t gc = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gc >= (size_t)ncol) return;
+    const int k = blockIdx.y;                       // layer index 0 .. nlay-1
+    if (!(icld == 4 || icld == 5)) return;
+    const double am1 = 1.4315, am2 = 2.1219, am4 = -25.584, amr = 7.0;
+    double decorr_len, decorr_inv = 1.0;
+    if (idcor == 1) {                               // latitude / day-of-year dependent decorrelation length, :140-152
+        double am3;
+        if (juldat > 181) am3 = -4. * amr / 365. * (juldat - 272);
+        else am3 = 4. * amr / 365. * (juldat - 91);
+        const double y = lat[gc] - am3;
+        decorr_len = (am1 + am2 * exp(-(y * y) / (am4 * am4))) * 1.e3;
+    } else {
+        decorr_len = decorr_con;
+    }
+    if (decorr_len >= 0.0) decorr_inv = 1.0 / decorr_len;
+    const size_t o = gc + (size_t)ncol * k;
+    double a = 0.0;
+    if (k > 0) {
+        const size_t om = o - (size_t)ncol;
+        a = exp(-(0.5 * (dz[o] + dz[om])) * decorr_inv);
+        if (icld == 5 && cldfrac[o] == 0.0 && cldfrac[om] > 0.0) a = 0.0;
+    }
+    alpha[o] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_sweep : the vertical recurrences.  One thread owns NGC consecutive g-points of one band for one column.
 //   MODE 0 clear column set (icld = 0): rtrn/rtrnmr clear branch   src/rrtmg_lw_rtrn.f90:437-466,:497-540
 //   MODE 1 rtrn   (random overlap)                                 src/rrtmg_lw_rtrn.f90:361-540
 //   MODE 2 rtrnmr (maximum-random overlap)                         src/rrtmg_lw_rtrnmr.f90:531-738
+//   MODE 3 rtrnmc (McICA: cloud terms per g-point, k_cloudmc)      src/rrtmg_lw_rtrnmc.f90:331-520
 // Writes the chunk's flux contribution (sum over its g-points x 0.5 x delwave, rtrn :549-562) per level.
 // ------------------------------------------------------------------------------------------------
 #ifndef RRLW_SWEEP_UNROLL
@@ -1214,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
             flags = W.cflag[(size_t)lev * ncb + col];
             cloudy = flags & 1;
             if (cloudy) {
-                cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
+                if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
                 if constexpr (MODE == 1) efcl = W.efcl[((size_t)ibc * nlay + (lev - 1)) * ncb + col];
             }
         }
@@ -1244,12 +1599,19 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
                     fcmb1 = W.mrfac[MR_FACCMB1D * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2D * ms + mo];
                     fclr2 = W.mrfac[MR_FACCLR2D * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2D * ms + mo];
                 }
+                double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
+                if constexpr (MODE == 3) {          // rtrnmc: cloud fraction and effective emissivity per g-point
+                    const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
+                    const float4 c4 = pc[0], e4 = pc[1];
+                    cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
+                    efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
+                }
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
                     const double atr = vatr.v[j], bbd = vbbd.v[j], atot = vatot.v[j], bbdtot = vbbdt.v[j];
                     const double gassrc = bbd * atr;
-                    if constexpr (MODE == 1) {
-                        radld[j] = radld[j] - radld[j] * (atr + efcl * (1. - atr)) + gassrc + cf * (bbdtot * atot - gassrc);
+                    if constexpr (MODE == 1 || MODE == 3) {
+                        radld[j] = radld[j] - radld[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbdtot * atot - gassrc);
                     } else {            // rtrnmr :591-615
                         if (flags & 4) {        // istcldd(lev) == 1
                             cldrad[j] = cf * radld[j];
@@ -1312,7 +1674,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
             flags = W.cflag[(size_t)lev * ncb + col];
             cloudy = flags & 1;
             if (cloudy) {
-                cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
+                if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
                 if constexpr (MODE == 1) efcl = W.efcl[((size_t)ibc * nlay + (lev - 1)) * ncb + col];
             }
         }
@@ -1347,12 +1709,19 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
                     fcmb1 = W.mrfac[MR_FACCMB1 * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2 * ms + mo];
                     fclr2 = W.mrfac[MR_FACCLR2 * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2 * ms + mo];
                 }
+                double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
+                if constexpr (MODE == 3) {
+                    const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
+                    const float4 c4 = pc[0], e4 = pc[1];
+                    cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
+                    efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
+                }
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
                     const double atr = vatr.v[j], bbu = vbbu.v[j], atot = vatot.v[j], bbutot = vbbut.v[j];
                     const double gassrc = bbu * atr;
-                    if constexpr (MODE == 1) {
-                        radlu[j] = radlu[j] - radlu[j] * (atr + efcl * (1. - atr)) + gassrc + cf * (bbutot * atot - gassrc);
+                    if constexpr (MODE == 1 || MODE == 3) {
+                        radlu[j] = radlu[j] - radlu[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbutot * atot - gassrc);
                     } else {            // rtrnmr :680-703
                         if (flags & 2) {        // istcld(lev) == 1
                             cldrad[j] = cf * radlu[j];
@@ -1373,7 +1742,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
                     }
                     usum = usum + radlu[j];
                     if (idrv) {
-                        drad[j] = drad[j] * cf * (1.0 - atot) + drad[j] * (1.0 - cf) * (1.0 - atr);
+                        drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr);
                         dusum = dusum + drad[j];
                         dradc[j] = dradc[j] * (1.0 - atr);
                         dusumc = dusumc + dradc[j];

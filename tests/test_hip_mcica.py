@@ -1,0 +1,200 @@
+"""GPU parity tests of the McICA flavour: sub-column generator (bit-exact masks), cldprmc + rtrnmc through
+rrtmg_lw_hip_run_mcica, and the fused generator+solver entry, all against the CPU oracle (which is itself
+bit-identical to the reference's Fortran: tests/test_oracle_vs_ref.py).
+"""
+import numpy as np
+import pytest
+
+from rrtmg_lw_amd.synth import make_gcm_inputs
+
+pytestmark = pytest.mark.gpu
+
+FLUX_TOL = 0.01      # W m-2     (BASELINE.json north_star)
+HR_TOL = 0.001       # K day-1
+TIGHT_FLUX = 5e-5    # see tests/test_hip_parity.py for why this is not 1e-12
+TIGHT_HR = 5e-5
+SUB = ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")
+
+
+def _compare(got, ref, idrv, tag):
+    dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
+    dhr = max(np.abs(got[k] - ref[k]).max() for k in ("hr", "hrc"))
+    ddt = 0.0
+    if idrv == 1:
+        ddt = max(np.abs(got[k] - ref[k]).max() for k in ("duflx_dt", "duflxc_dt"))
+    print(f"{tag}: max|dflux|={dflux:.3e} W/m2  max|dhr|={dhr:.3e} K/d  max|d(dF/dT)|={ddt:.3e}")
+    assert np.isfinite(got["uflx"]).all() and np.isfinite(got["hr"]).all()
+    assert dflux <= FLUX_TOL and dhr <= HR_TOL and ddt <= FLUX_TOL
+    assert dflux <= TIGHT_FLUX and dhr <= TIGHT_HR and ddt <= TIGHT_FLUX
+    assert got["icld"] == ref["icld"]
+
+
+def _geometry(ncol, nlay, seed=3):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(100, 1500, (ncol, nlay)), rng.uniform(-90, 90, ncol)
+
+
+def _gen_args(d):
+    return d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"], d["reliq"], d["taucld"]
+
+
+@pytest.mark.parametrize("icld,idcor,juldat", [(4, 0, 10), (4, 1, 150), (5, 1, 300), (5, 0, 200), (2, 1, 100)])
+def test_get_alpha(hip, oracle, icld, idcor, juldat):
+    ncol, nlay = 130, 47
+    d = make_gcm_inputs(ncol, nlay, "cloudy")
+    dz, lat = _geometry(ncol, nlay)
+    got = hip.get_alpha(ncol, nlay, icld, idcor, 2500.0, dz, lat, juldat, d["cldfr"])
+    ref = oracle.get_alpha(ncol, nlay, icld, idcor, 2500.0, dz, lat, juldat, d["cldfr"])
+    np.testing.assert_allclose(got, ref, rtol=4e-16 * 8, atol=0)      # device exp vs libm exp: a few ulp
+
+
+@pytest.mark.parametrize("irng", [0, 1])
+@pytest.mark.parametrize("icld", [1, 2, 3, 4, 5])
+def test_subcolumn_generator_is_bit_exact(hip, oracle, icld, irng):
+    """kissvec (one stream per column) and Mersenne Twister (one stream over all columns): identical cloud masks,
+    water paths and optical depths (src/mcica_subcol_gen_lw.f90:183-703)."""
+    ncol, nlay = 70, 40          # 70 > one generator block
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=11)
+    dz, lat = _geometry(ncol, nlay)
+    alpha = oracle.get_alpha(ncol, nlay, icld, 1, 2500.0, dz, lat, 100, d["cldfr"])
+    for permuteseed in (140, 3 * 140):
+        got = hip.mcica_subcol_lw(ncol, nlay, icld, permuteseed, irng, *_gen_args(d), alpha)
+        ref = oracle.mcica_subcol(ncol, nlay, icld, permuteseed, irng, *_gen_args(d), alpha)
+        assert 0.01 < ref["cldfmcl"].mean() < 0.9
+        for k in SUB:
+            assert np.array_equal(got[k], ref[k]), (k, icld, irng, permuteseed)
+        assert got["irng"] == ref["irng"]
+
+
+def test_subcolumn_generator_flags(hip, oracle):
+    ncol, nlay = 64, 33
+    d = make_gcm_inputs(ncol, nlay, "cloudy")
+    # irng is normalised to 0/1 (:442); alpha may be omitted for icld < 4
+    got = hip.mcica_subcol_lw(ncol, nlay, 2, 140, 7, *_gen_args(d))
+    assert got["irng"] == 1
+    ref = oracle.mcica_subcol(ncol, nlay, 2, 140, 1, *_gen_args(d), np.zeros((ncol, nlay)))
+    assert np.array_equal(got["cldfmcl"], ref["cldfmcl"])
+    # icld = 0 returns without touching the outputs (:265)
+    got = hip.mcica_subcol_lw(ncol, nlay, 0, 140, 0, *_gen_args(d))
+    assert not got["cldfmcl"].any()
+    with pytest.raises(hip.RrtmgLwError, match="INVALID ICLD"):
+        hip.mcica_subcol_lw(ncol, nlay, 6, 140, 0, *_gen_args(d))
+    # the kissvec seeds need pressures ordered surface -> top (:463-466)
+    bad = dict(d)
+    bad["play"] = np.asfortranarray(d["play"][:, ::-1])
+    with pytest.raises(hip.RrtmgLwError, match="KISSVEC SEED GENERATOR REQUIRES PMID"):
+        hip.mcica_subcol_lw(ncol, nlay, 2, 140, 0, *_gen_args(bad))
+
+
+def _with_subcolumns(oracle, d, icld, irng=0, permuteseed=140, alpha=None):
+    ncol, nlay = d["ncol"], d["nlay"]
+    alpha = np.zeros((ncol, nlay)) if alpha is None else alpha
+    sc = oracle.mcica_subcol(ncol, nlay, icld, permuteseed, irng, *_gen_args(d), alpha)
+    dd = dict(d)
+    dd.update({k: sc[k] for k in SUB})
+    return dd
+
+
+@pytest.mark.parametrize("config,nlay,icld,ncol,flags", [
+    ("cloudy", 72, 2, 300, None),            # synth default flags (inflag 2, iceflag 3, liqflag 1)
+    ("cloudy", 72, 1, 130, (2, 0, 0)),
+    ("cloudy", 51, 3, 100, (2, 1, 1)),
+    ("cloudy", 72, 2, 100, (2, 2, 1)),
+    ("cloudy", 40, 2, 70, (0, 0, 0)),         # inflag 0: optical depths taken from taucmcl
+    ("aer_idrv", 137, 2, 130, None),          # aerosol + dF/dT, 137 layers
+    ("aer_idrv", 33, 1, 64, (2, 3, 1)),
+    ("cloudy", 72, 9, 65, None),              # out-of-range icld is reset to 2 (src/rrtmg_lw_rad.f90:469)
+])
+def test_mcica_entry_matches_oracle(hip, oracle, config, nlay, icld, ncol, flags):
+    d = make_gcm_inputs(ncol, nlay, config, col0=77)
+    if flags is not None:
+        d["inflglw"], d["iceflglw"], d["liqflglw"] = flags
+        if flags[1] == 0:
+            d["reice"] = np.asfortranarray(np.clip(d["reice"], 10.0, 30.0))
+        if flags[1] == 1:
+            d["reice"] = np.asfortranarray(np.clip(d["reice"], 13.0, 130.0))
+    dd = _with_subcolumns(oracle, d, min(max(icld, 1), 3))
+    got = hip.rrtmg_lw_mcica_from_dict(dd, icld=icld)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    _compare(got, ref, d["idrv"], f"mcica {config} L{nlay} icld{icld} flags{flags}")
+    assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0 or flags == (0, 0, 0)      # clouds actually matter
+
+
+def test_mcica_icld0_ignores_cloud_arrays(hip, oracle):
+    d = make_gcm_inputs(100, 72, "cloudy")
+    dd = _with_subcolumns(oracle, d, 2)
+    got = hip.rrtmg_lw_mcica_from_dict(dd, icld=0)
+    ref = oracle.rrtmg_lw(100, 72, 0, 0, dd, mcica=True)
+    _compare(got, ref, 0, "mcica icld=0")
+    assert np.array_equal(got["uflx"], got["uflxc"])
+
+
+def test_mcica_fractional_and_partial_cells(hip, oracle):
+    """cldfmcl values other than 0/1 and cells with water but no cloud flag follow cldprmc/rtrnmc literally
+    (only cldfmc == 1 contributes optical depth: src/rrtmg_lw_rtrnmc.f90:311)."""
+    ncol, nlay = 90, 45
+    d = make_gcm_inputs(ncol, nlay, "cloudy")
+    dd = _with_subcolumns(oracle, d, 1)
+    rng = np.random.default_rng(5)
+    cf = dd["cldfmcl"].copy()
+    pick = rng.random(cf.shape) < 0.05
+    cf[pick] = 0.5
+    dd["cldfmcl"] = np.asfortranarray(cf)
+    dd["ciwpmcl"] = np.asfortranarray(np.where(rng.random(cf.shape) < 0.3, 0.0, dd["ciwpmcl"]))
+    got = hip.rrtmg_lw_mcica_from_dict(dd, icld=1)
+    ref = oracle.rrtmg_lw(ncol, nlay, 1, d["idrv"], dd, mcica=True)
+    _compare(got, ref, d["idrv"], "mcica fractional cells")
+
+
+def test_mcica_batching_is_transparent(hip, oracle):
+    d = make_gcm_inputs(600, 40, "cloudy", col0=5)
+    dd = _with_subcolumns(oracle, d, 2)
+    hip.set_batch(131072)
+    one = hip.rrtmg_lw_mcica_from_dict(dd)
+    hip.set_batch(256)
+    many = hip.rrtmg_lw_mcica_from_dict(dd)
+    fused_many = hip.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0)
+    hip.set_batch(131072)
+    fused_one = hip.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(one[k], many[k]), k
+        assert np.array_equal(fused_one[k], fused_many[k]), k
+        assert np.array_equal(one[k], fused_one[k]), k          # mask path == array path, bit for bit
+
+
+def test_mcica_errors(hip, oracle):
+    d = make_gcm_inputs(64, 40, "cloudy")
+    dd = _with_subcolumns(oracle, d, 2)
+    dd["inflglw"] = 1
+    with pytest.raises(hip.RrtmgLwError, match="INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA"):
+        hip.rrtmg_lw_mcica_from_dict(dd)
+    dd["inflglw"] = 2
+    dd["reicmcl"] = np.asfortranarray(np.full((64, 40), 500.0))
+    with pytest.raises(hip.RrtmgLwError, match="ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS"):
+        hip.rrtmg_lw_mcica_from_dict(dd)
+
+
+@pytest.mark.parametrize("icld,irng,config,nlay,ncol", [
+    (2, 0, "cloudy", 72, 300),
+    (1, 0, "cloudy", 72, 100),
+    (3, 0, "cloudy", 51, 100),
+    (4, 0, "cloudy", 72, 130),
+    (5, 0, "aer_idrv", 72, 130),
+    (2, 1, "cloudy", 40, 70),        # Mersenne Twister stream
+    (5, 1, "aer_idrv", 33, 64),
+    (0, 0, "cloudy", 72, 64),
+])
+def test_fused_generator_and_solver_matches_oracle(hip, oracle, icld, irng, config, nlay, ncol):
+    """rrtmg_lw_hip_run_mcica_subcol == mcica_subcol_lw followed by the McICA rrtmg_lw."""
+    d = make_gcm_inputs(ncol, nlay, config, col0=31)
+    dz, lat = _geometry(ncol, nlay)
+    alpha = oracle.get_alpha(ncol, nlay, icld, 1, 2500.0, dz, lat, 100, d["cldfr"])
+    got = hip.rrtmg_lw_mcica_subcol_from_dict(d, 280, irng, alpha=alpha, icld=icld)
+    if icld == 0:
+        from oracle.bindings import _subcol_outputs
+        dd = dict(d)
+        dd.update(_subcol_outputs(ncol, nlay))
+    else:
+        dd = _with_subcolumns(oracle, d, icld, irng=irng, permuteseed=280, alpha=alpha)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    _compare(got, ref, d["idrv"], f"fused icld{icld} irng{irng} {config} L{nlay}")
