@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--ncol", type=int, default=1_000_000, help="total columns over all GPUs")
     ap.add_argument("--nlay", type=int, default=72)
     ap.add_argument("--config", default="cloudy", choices=["clear", "cloudy", "aer_idrv"])
+    ap.add_argument("--mcica", type=int, default=0, metavar="ICLD",
+                    help="McICA flavour (BASELINE configs[3]): sub-column generator with overlap ICLD (5 = exponential-random) "
+                         "+ cldprmc + rtrnmc through the fused device entry; 0 = non-McICA rtrn/rtrnmr")
     ap.add_argument("--batch", type=int, default=0, help="columns per internal batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols-per-core", type=int, default=6000)
@@ -116,9 +119,20 @@ def main():
             raise SystemExit("--ncol must be divisible by --gpus for the all-gather")
 
     stream = torch.cuda.current_stream().cuda_stream
+    alpha = None
+    if args.mcica:
+        # overlap parameter of get_alpha for a constant 2 km decorrelation length and hydrostatic layer depths
+        z = 7000.0 * torch.log(d["plev"][:, :1] / d["plev"])                       # (ncol, nlay+1), column-fastest
+        dz = z[:, 1:] - z[:, :-1]
+        a = torch.exp(-0.5 * (dz[:, 1:] + dz[:, :-1]) / 2000.0)
+        alpha = torch.cat([torch.zeros_like(a[:, :1]), a], dim=1).t().contiguous().t()
+        del z, dz, a
 
     def step():
-        api.rrtmg_lw_device(d, out, stream=stream)
+        if args.mcica:
+            api.rrtmg_lw_mcica_subcol_device(d, out, 140, 0, alpha=alpha, icld=args.mcica, stream=stream)
+        else:
+            api.rrtmg_lw_device(d, out, stream=stream)
         if do_gather:
             dist.all_gather_into_tensor(gathered, outbuf)
 
@@ -129,7 +143,13 @@ def main():
         api.check(stream)
         n = min(256, ncol)
         dn = make_gcm_inputs(n, nlay, args.config, col0=col0)
-        ref = Oracle(kdata=api.default_kdata()).rrtmg_lw(n, nlay, dn["icld"], dn["idrv"], dn)
+        orc = Oracle(kdata=api.default_kdata())
+        if args.mcica:
+            al = np.asfortranarray(alpha[:n].cpu().numpy())
+            sub = orc.mcica_subcol(n, nlay, args.mcica, 140, 0, dn["play"], dn["cldfr"], dn["cicewp"], dn["cliqwp"], dn["reice"],
+                                   dn["reliq"], dn["taucld"], al)
+            dn.update({k: sub[k] for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")})
+        ref = orc.rrtmg_lw(n, nlay, args.mcica or dn["icld"], dn["idrv"], dn, mcica=bool(args.mcica))
         dfl = max(float(np.abs(out[k][:, :n].T.cpu().numpy() - ref[k]).max()) for k in ("uflx", "dflx", "uflxc", "dflxc"))
         dhr = max(float(np.abs(out[k][:, :n].T.cpu().numpy() - ref[k]).max()) for k in ("hr", "hrc"))
         print(f"# check vs oracle on {n} columns: max|dflux| = {dfl:.3e} W/m2, max|dhr| = {dhr:.3e} K/d", file=sys.stderr)
@@ -165,7 +185,7 @@ def main():
         for line in buf.value.decode().splitlines():
             nm, cnt, tot = line.rsplit(" ", 2)
             kern[nm] = (int(cnt), float(tot))
-        bpc = algo_bytes_per_col(nlay, idrv)
+        bpc = algo_bytes_per_col(nlay, idrv) + (8.0 * nlay if args.mcica else 0.0)     # + alpha
         roof = None
         path = None
         if kern:
@@ -188,7 +208,7 @@ def main():
                         top=[dict(kernel=k, ms_per_step=round(v[1] / args.steps, 3)) for k, v in
                              sorted(kern.items(), key=lambda kv: -kv[1][1])[:6]],
                         families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
-                                  for fam in ("k_colprep", "k_cloud", "k_layer", "k_sweep", "k_flux", "k_rates")})
+                                  for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweep", "k_flux", "k_rates")})
             # PMC-derived HBM traffic of the dominant kernel, if a summary has been committed under profiles/
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
@@ -201,7 +221,8 @@ def main():
                    ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
                    dtype="f64", data="synthetic",
                    config=dict(workload=f"{args.ncol} synthetic {nlay}-layer columns, config '{args.config}' "
-                                        f"(icld={d['icld']}: {'rtrnmr max-random overlap' if d['icld'] == 2 else 'clear'}, idrv={idrv}), "
+                                        + (f"(McICA: kissvec sub-column generator icld={args.mcica} + cldprmc + rtrnmc, idrv={idrv}), " if args.mcica else
+                                           f"(icld={d['icld']}: {'rtrnmr max-random overlap' if d['icld'] == 2 else 'clear'}, idrv={idrv}), ") +
                                         f"sharded {world}x{per}",
                                ncol_total=args.ncol, nlay=nlay, columns_per_gpu=per, parallelism=f"columns/{world}",
                                gather="rccl all_gather" if do_gather else "none",

@@ -1,0 +1,98 @@
+!  Drop-in replacement for the reference's module rrtmg_lw_rad, McICA flavour
+!  (src/rrtmg_lw_rad.f90:99-108): same module name, subroutine name, argument order, kinds,
+!  intents and assumed-shape dummies, so a host model's
+!      use rrtmg_lw_rad, only: rrtmg_lw
+!      call rrtmg_lw(ncol, nlay, icld, idrv, play, plev, ..., uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt)
+!  (with the sub-column arrays produced by mcica_subcol_lw) compiles unchanged.  The body forwards to rrtmg_lw_hip_run_mcica (include/rrtmg_lw_hip.h); assumed-shape
+!  actuals that are not contiguous are packed by the compiler at the call of the assumed-size C interface.
+      module rrtmg_lw_rad
+
+      use iso_c_binding
+      use parkind, only : im => kind_im, rb => kind_rb
+      use rrtmg_lw_init, only : rrtmg_lw_hip_abort
+
+      implicit none
+
+      public :: rrtmg_lw
+
+      interface
+         function rrtmg_lw_hip_run_mcica(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, &
+               h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, &
+               inflglw, iceflglw, liqflglw, cldfmcl, taucmcl, ciwpmcl, clwpmcl, reicmcl, relqmcl, tauaer, &
+               uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt) bind(C, name='rrtmg_lw_hip_run_mcica') result(rc)
+            import :: c_int, c_double, c_ptr
+            integer(c_int), value :: ncol, nlay, idrv, inflglw, iceflglw, liqflglw
+            integer(c_int), intent(inout) :: icld
+            real(c_double), intent(in) :: play(*), plev(*), tlay(*), tlev(*), tsfc(*), h2ovmr(*), o3vmr(*), co2vmr(*)
+            real(c_double), intent(in) :: ch4vmr(*), n2ovmr(*), o2vmr(*), cfc11vmr(*), cfc12vmr(*), cfc22vmr(*), ccl4vmr(*)
+            real(c_double), intent(in) :: emis(*), cldfmcl(*), taucmcl(*), ciwpmcl(*), clwpmcl(*), reicmcl(*), relqmcl(*), tauaer(*)
+            real(c_double), intent(out) :: uflx(*), dflx(*), hr(*), uflxc(*), dflxc(*), hrc(*)
+            type(c_ptr), value :: duflx_dt, duflxc_dt
+            integer(c_int) :: rc
+         end function rrtmg_lw_hip_run_mcica
+      end interface
+
+      contains
+
+      subroutine rrtmg_lw &
+            (ncol    ,nlay    ,icld    ,idrv    , &
+             play    ,plev    ,tlay    ,tlev    ,tsfc    , &
+             h2ovmr  ,o3vmr   ,co2vmr  ,ch4vmr  ,n2ovmr  ,o2vmr , &
+             cfc11vmr,cfc12vmr,cfc22vmr,ccl4vmr ,emis    , &
+             inflglw ,iceflglw,liqflglw,cldfmcl , &
+             taucmcl ,ciwpmcl ,clwpmcl ,reicmcl ,relqmcl , &
+             tauaer  , &
+             uflx    ,dflx    ,hr      ,uflxc   ,dflxc,  hrc, &
+             duflx_dt,duflxc_dt )
+
+      integer(kind=im), intent(in) :: ncol            ! Number of horizontal columns
+      integer(kind=im), intent(in) :: nlay            ! Number of model layers
+      integer(kind=im), intent(inout) :: icld         ! Cloud overlap method
+      integer(kind=im), intent(in) :: idrv            ! Flag for calculation of dFdT
+      real(kind=rb), intent(in) :: play(:,:)          ! Layer pressures (hPa, mb)           (ncol,nlay)
+      real(kind=rb), intent(in) :: plev(:,:)          ! Interface pressures (hPa, mb)       (ncol,nlay+1)
+      real(kind=rb), intent(in) :: tlay(:,:)          ! Layer temperatures (K)
+      real(kind=rb), intent(in) :: tlev(:,:)          ! Interface temperatures (K)
+      real(kind=rb), intent(in) :: tsfc(:)            ! Surface temperature (K)
+      real(kind=rb), intent(in) :: h2ovmr(:,:), o3vmr(:,:), co2vmr(:,:), ch4vmr(:,:), n2ovmr(:,:), o2vmr(:,:)
+      real(kind=rb), intent(in) :: cfc11vmr(:,:), cfc12vmr(:,:), cfc22vmr(:,:), ccl4vmr(:,:)
+      real(kind=rb), intent(in) :: emis(:,:)          ! Surface emissivity                  (ncol,nbndlw)
+      integer(kind=im), intent(in) :: inflglw, iceflglw, liqflglw
+      real(kind=rb), intent(in) :: cldfmcl(:,:,:)     ! Cloud fraction [mcica]              (ngptlw,ncol,nlay)
+      real(kind=rb), intent(in) :: ciwpmcl(:,:,:), clwpmcl(:,:,:)
+      real(kind=rb), intent(in) :: reicmcl(:,:), relqmcl(:,:)      !                        (ncol,nlay)
+      real(kind=rb), intent(in) :: taucmcl(:,:,:)     ! In-cloud optical depth [mcica]      (ngptlw,ncol,nlay)
+      real(kind=rb), intent(in) :: tauaer(:,:,:)      ! Aerosol optical depth               (ncol,nlay,nbndlw)
+      real(kind=rb), intent(out) :: uflx(:,:), dflx(:,:), hr(:,:), uflxc(:,:), dflxc(:,:), hrc(:,:)
+      real(kind=rb), intent(out), optional, target :: duflx_dt(:,:), duflxc_dt(:,:)
+
+      integer(c_int) :: rc, icld_c
+      real(c_double), allocatable, target :: d1(:,:), d2(:,:)
+      type(c_ptr) :: p1, p2
+
+      icld_c = int(icld, c_int)
+      p1 = c_null_ptr
+      p2 = c_null_ptr
+      if (idrv == 1) then
+         if (.not. (present(duflx_dt) .and. present(duflxc_dt))) then
+            write(*,*) 'rrtmg_lw: idrv = 1 requires duflx_dt and duflxc_dt'
+            error stop 1
+         endif
+         allocate(d1(ncol, nlay+1), d2(ncol, nlay+1))
+         p1 = c_loc(d1)
+         p2 = c_loc(d2)
+      endif
+      rc = rrtmg_lw_hip_run_mcica(int(ncol, c_int), int(nlay, c_int), icld_c, int(idrv, c_int), &
+            play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, &
+            cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, int(inflglw, c_int), int(iceflglw, c_int), int(liqflglw, c_int), &
+            cldfmcl, taucmcl, ciwpmcl, clwpmcl, reicmcl, relqmcl, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, p1, p2)
+      if (rc /= 0) call rrtmg_lw_hip_abort('rrtmg_lw')
+      icld = int(icld_c, im)
+      if (idrv == 1) then
+         duflx_dt(1:ncol, 1:nlay+1) = d1
+         duflxc_dt(1:ncol, 1:nlay+1) = d2
+      endif
+
+      end subroutine rrtmg_lw
+
+      end module rrtmg_lw_rad

@@ -16,16 +16,19 @@ SHIM = os.path.join(ROOT, "rrtmg_lw_amd", "fortran")
 needs_flang = pytest.mark.skipif(not os.path.exists(FLANG), reason="flang not installed")
 
 
-def _compile(tmp, link):
+def _compile(tmp, link, mcica=False):
     objs = []
-    for f in ("parkind.f90", "rrtmg_lw_init.f90", "rrtmg_lw_rad.nomcica.f90"):
+    shim = ("parkind.f90", "rrtmg_lw_init.f90", "mcica_subcol_gen_lw.f90", "rrtmg_lw_rad.f90") if mcica else \
+           ("parkind.f90", "rrtmg_lw_init.f90", "rrtmg_lw_rad.nomcica.f90")
+    prog = "drive_shim_mcica" if mcica else "drive_shim"
+    for f in shim:
         o = os.path.join(tmp, f + ".o")
         subprocess.run([FLANG, "-c", "-O2", "-fPIC", os.path.join(SHIM, f), "-o", o], check=True, cwd=tmp)
         objs.append(o)
-    drv = os.path.join(tmp, "drive_shim.o")
-    subprocess.run([FLANG, "-c", "-O2", os.path.join(ROOT, "tests", "fortran", "drive_shim.f90"), "-o", drv], check=True, cwd=tmp)
+    drv = os.path.join(tmp, prog + ".o")
+    subprocess.run([FLANG, "-c", "-O2", os.path.join(ROOT, "tests", "fortran", prog + ".f90"), "-o", drv], check=True, cwd=tmp)
     if link:
-        exe = os.path.join(tmp, "drive_shim")
+        exe = os.path.join(tmp, prog)
         libdir = os.path.join(ROOT, "rrtmg_lw_amd")
         subprocess.run([FLANG, "-o", exe, drv, *objs, f"-L{libdir}", "-lrrtmg_lw_hip", f"-Wl,-rpath,{libdir}"], check=True, cwd=tmp)
         return exe
@@ -37,6 +40,13 @@ def test_shim_modules_compile(tmp_path):
     """Same module / subroutine names and dummy lists as the reference: a host model compiles against them unchanged."""
     _compile(str(tmp_path), link=False)
     assert os.path.exists(tmp_path / "rrtmg_lw_rad.mod") and os.path.exists(tmp_path / "rrtmg_lw_init.mod")
+
+
+@needs_flang
+def test_mcica_shim_modules_compile(tmp_path):
+    """McICA flavour: modules mcica_subcol_gen_lw (get_alpha, mcica_subcol_lw) and rrtmg_lw_rad with the sub-column dummy list."""
+    _compile(str(tmp_path), link=False, mcica=True)
+    assert os.path.exists(tmp_path / "rrtmg_lw_rad.mod") and os.path.exists(tmp_path / "mcica_subcol_gen_lw.mod")
 
 
 @needs_flang
@@ -74,3 +84,53 @@ def test_fortran_host_model_matches_oracle(tmp_path, oracle, config, icld):
         if k.startswith("du") and d["idrv"] != 1:
             continue
         assert np.abs(got - ref[k]).max() <= 5e-5, k
+
+
+@needs_flang
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,icld,irng", [("cloudy", 2, 0), ("aer_idrv", 5, 0), ("cloudy", 4, 1)])
+def test_fortran_mcica_host_model_matches_oracle(tmp_path, oracle, config, icld, irng):
+    """get_alpha -> mcica_subcol_lw -> McICA rrtmg_lw from Fortran, against the same sequence on the oracle."""
+    tmp = str(tmp_path)
+    exe = _compile(tmp, link=True, mcica=True)
+    ncol, nlay, permuteseed, idcor, juldat = 70, 45, 280, 1, 160
+    d = make_gcm_inputs(ncol, nlay, config, col0=31)
+    rng = np.random.default_rng(9)
+    dz, lat = rng.uniform(100, 1500, (ncol, nlay)), rng.uniform(-90, 90, ncol)
+    with open(os.path.join(tmp, "in.bin"), "wb") as f:
+        np.array([ncol, nlay, icld, d["idrv"], d["inflglw"], d["iceflglw"], d["liqflglw"], permuteseed, irng, idcor, juldat],
+                 dtype=np.int32).tofile(f)
+        for k in ["play", "plev", "tlay", "tlev", "tsfc"]:
+            f.write(np.asfortranarray(d[k]).tobytes(order="F"))
+        gases = ["h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr"]
+        f.write(np.stack([d[k] for k in gases], axis=2).tobytes(order="F"))
+        f.write(np.asfortranarray(d["emis"]).tobytes(order="F"))
+        f.write(np.stack([d[k] for k in ("cldfr", "cicewp", "cliqwp", "reice", "reliq")], axis=2).tobytes(order="F"))
+        f.write(np.asfortranarray(d["taucld"]).tobytes(order="F"))
+        f.write(np.asfortranarray(d["tauaer"]).tobytes(order="F"))
+        f.write(np.asfortranarray(dz).tobytes(order="F"))
+        f.write(np.asfortranarray(lat).tobytes(order="F"))
+    env = dict(os.environ, RRTMG_LW_STATIC_TABLES=os.path.join(ROOT, "rrtmg_lw_amd", "data", "lw_static.bin"),
+               RRTMG_LW_KDATA=os.path.join(ROOT, "rrtmg_lw_amd", "data", "standin.kdata.bin"))
+    subprocess.run([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")], check=True, env=env, cwd=tmp, timeout=300)
+    raw = open(os.path.join(tmp, "out.bin"), "rb").read()
+    icld_out = int(np.frombuffer(raw, dtype=np.int32, count=1)[0])
+    a = np.frombuffer(raw, dtype=np.float64, offset=4)
+    alpha = oracle.get_alpha(ncol, nlay, icld, idcor, 2500.0, dz, lat, juldat, d["cldfr"])
+    sub = oracle.mcica_subcol(ncol, nlay, icld, permuteseed, irng, d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"],
+                              d["reliq"], d["taucld"], alpha)
+    dd = dict(d)
+    dd.update({k: sub[k] for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")})
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    assert icld_out == ref["icld"]
+    pos = 0
+    for k, nl in (("uflx", nlay + 1), ("dflx", nlay + 1), ("hr", nlay), ("uflxc", nlay + 1), ("dflxc", nlay + 1), ("hrc", nlay),
+                  ("duflx_dt", nlay + 1), ("duflxc_dt", nlay + 1)):
+        got = a[pos:pos + ncol * nl].reshape((ncol, nl), order="F")
+        pos += ncol * nl
+        if k.startswith("du") and d["idrv"] != 1:
+            continue
+        assert np.abs(got - ref[k]).max() <= 5e-5, k
+    cloudy_count = a[pos:pos + ncol * nlay].reshape((ncol, nlay), order="F")
+    # alpha from the device differs from libm's by a few ulp at most; a flipped `CDF2 < alpha` decision would show up here
+    assert np.array_equal(cloudy_count, sub["cldfmcl"].sum(axis=0))

@@ -198,3 +198,43 @@ def test_fused_generator_and_solver_matches_oracle(hip, oracle, icld, irng, conf
         dd = _with_subcolumns(oracle, d, icld, irng=irng, permuteseed=280, alpha=alpha)
     ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
     _compare(got, ref, d["idrv"], f"fused icld{icld} irng{irng} {config} L{nlay}")
+
+
+import glob  # noqa: E402
+import os  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_mcica_*.npz"))), ids=os.path.basename)
+def test_against_reference_fixture(hip, path):
+    """HIP generator and McICA solver against outputs of the REFERENCE's own Fortran (tools/gen_ref_fixtures.py):
+    masks bit-exact, fluxes within the north-star bars.  The Mersenne-Twister fixtures were generated column by
+    column (one freshly seeded stream each, as the reference's column driver does)."""
+    f = np.load(path)
+    ncol, nlay, icld, irng, seed = int(f["ncol"]), int(f["nlay"]), int(f["icld"]), int(f["irng"]), int(f["ims"]) * 140
+    d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
+    alpha = hip.get_alpha(ncol, nlay, icld, int(f["idcor"]), 2000.0, f["dz"], f["lat"], int(f["juldat"]), d["cldfr"])
+    np.testing.assert_allclose(alpha, f["alpha"], rtol=4e-15, atol=0)
+    alpha = np.asfortranarray(f["alpha"])        # continue from the reference's alpha so that the masks must agree exactly
+    args = lambda sl: (d["play"][sl], d["cldfr"][sl], d["cicewp"][sl], d["cliqwp"][sl], d["reice"][sl], d["reliq"][sl],
+                       d["taucld"][:, sl, :], alpha[sl])
+    if irng == 0:
+        sub = hip.mcica_subcol_lw(ncol, nlay, icld, seed, 0, *args(slice(None)))
+    else:
+        parts = [hip.mcica_subcol_lw(1, nlay, icld, seed, 1, *args(slice(c, c + 1))) for c in range(ncol)]
+        sub = {k: np.asfortranarray(np.concatenate([p[k] for p in parts], axis=1 if parts[0][k].ndim == 3 else 0)) for k in SUB}
+    mask = np.unpackbits(f["mask"])[:140 * ncol * nlay].reshape((140, ncol, nlay), order="F")
+    assert np.array_equal(sub["cldfmcl"], mask.astype(float))
+    for k3, ks in (("ciwpmcl", "ciwpsum"), ("clwpmcl", "clwpsum"), ("taucmcl", "taucsum")):
+        assert np.array_equal(sub[k3].sum(axis=0), f[ks]), k3
+    dd = dict(d)
+    dd.update({k: sub[k] for k in SUB})
+    got = hip.rrtmg_lw_mcica_from_dict(dd, icld=icld)
+    ref = {k: f[k] for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")}
+    ref["icld"] = int(f["icld_out"])
+    _compare(got, ref, d["idrv"], os.path.basename(path))
+    if irng == 0:       # the fused entry generates the same sub-columns internally
+        fused = hip.rrtmg_lw_mcica_subcol_from_dict(d, seed, 0, alpha=alpha, icld=icld)
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+            assert np.array_equal(fused[k], got[k]), k

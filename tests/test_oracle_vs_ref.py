@@ -52,6 +52,71 @@ def test_column_fixture(oracle, path):
             assert np.abs(ob["htr"] - f[f"b{b}_htr"]).max() <= TOL
 
 
+def _oracle_subcolumns(oracle, f, d):
+    """Sub-columns of every column with the oracle's generator; the Mersenne-Twister cases are generated column by
+    column (one freshly seeded stream each), which is how the fixture was produced with the reference's 1-column generator."""
+    ncol, nlay, icld, irng, seed = int(f["ncol"]), int(f["nlay"]), int(f["icld"]), int(f["irng"]), int(f["ims"]) * 140
+    alpha = oracle.get_alpha(ncol, nlay, icld, int(f["idcor"]), 2000.0, f["dz"], f["lat"], int(f["juldat"]), d["cldfr"])
+    args = lambda sl: (d["play"][sl], d["cldfr"][sl], d["cicewp"][sl], d["cliqwp"][sl], d["reice"][sl], d["reliq"][sl],
+                       d["taucld"][:, sl, :], alpha[sl])
+    if irng == 0:
+        return alpha, oracle.mcica_subcol(ncol, nlay, icld, seed, 0, *args(slice(None)))
+    parts = [oracle.mcica_subcol(1, nlay, icld, seed, 1, *args(slice(c, c + 1))) for c in range(ncol)]
+    sub = {k: np.asfortranarray(np.concatenate([p[k] for p in parts], axis=1 if parts[0][k].ndim == 3 else 0))
+           for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl", "reicmcl", "relqmcl")}
+    return alpha, sub
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_mcica_*.npz"))), ids=os.path.basename)
+def test_mcica_fixture(oracle, path):
+    """Generator (get_alpha, kissvec / Mersenne Twister, five overlaps): bit-exact masks; cldprmc + rtrnmc: fluxes."""
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
+    alpha, sub = _oracle_subcolumns(oracle, f, d)
+    assert np.array_equal(alpha, f["alpha"])
+    mask = np.unpackbits(f["mask"])[:140 * ncol * nlay].reshape((140, ncol, nlay), order="F")
+    assert np.array_equal(sub["cldfmcl"], mask.astype(float))
+    assert 0 < mask.mean() < 1
+    for k3, ks in (("ciwpmcl", "ciwpsum"), ("clwpmcl", "clwpsum"), ("taucmcl", "taucsum")):
+        assert np.array_equal(sub[k3].sum(axis=0), f[ks]), k3
+    dd = dict(d)
+    dd.update(sub)
+    o = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    assert o["icld"] == int(f["icld_out"])
+    keys = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if d["idrv"] else ())
+    for k in keys:
+        assert np.abs(o[k] - f[k]).max() <= TOL, k
+
+
+def test_live_mcica_reference_if_built(oracle):
+    from oracle.bindings import Reference
+    if not Reference.available("mcica"):
+        pytest.skip("oracle/_ref not built (needs /root/reference and flang)")
+    ref = Reference("mcica")
+    ncol, nlay = 5, 45
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=321)
+    rng = np.random.default_rng(1)
+    dz, lat = rng.uniform(100, 1500, (ncol, nlay)), rng.uniform(-90, 90, ncol)
+    for icld in (1, 2, 3, 4, 5):
+        alpha = oracle.get_alpha(ncol, nlay, icld, 1, 2500.0, dz, lat, 200, d["cldfr"])
+        for c in range(ncol):
+            assert np.array_equal(alpha[c], ref.get_alpha_1col(nlay, icld, 1, 2500.0, dz[c], lat[c], 200, d["cldfr"][c]))
+        sub = oracle.mcica_subcol(ncol, nlay, icld, 280, 0, d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"], d["reliq"],
+                                  d["taucld"], alpha)
+        for c in range(ncol):
+            r = ref.mcica_subcol_1col(nlay, icld, 2, 0, d["play"][c], d["cldfr"][c], d["cicewp"][c], d["cliqwp"][c], d["reice"][c],
+                                      d["reliq"][c], d["taucld"][:, c, :], alpha[c])
+            for k3, k2 in (("cldfmcl", "cldfmc"), ("ciwpmcl", "ciwpmc"), ("clwpmcl", "clwpmc"), ("taucmcl", "taucmc")):
+                assert np.array_equal(sub[k3][:, c, :], r[k2]), (icld, c, k3)
+        dd = dict(d)
+        dd.update(sub)
+        a = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+        b = ref.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd)
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+            assert np.abs(a[k] - b[k]).max() <= TOL, (icld, k)
+
+
 def test_live_reference_if_built(oracle):
     from oracle.bindings import Reference
     if not Reference.available("nomcica"):

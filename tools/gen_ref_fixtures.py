@@ -25,6 +25,11 @@ GCM_CASES = [  # name, config, ncol, nlay, icld
     ("cloudy72_rnd", "cloudy", 24, 72, 1), ("aer137", "aer_idrv", 8, 137, 2), ("aer40_rnd", "aer_idrv", 8, 40, 1),
     ("cloudy72_icld9", "cloudy", 6, 72, 9),
 ]
+MCICA_CASES = [  # name, config, ncol, nlay, icld, irng, ims (permuteseed = ims * 140), idcor, juldat
+    ("mr_kiss", "cloudy", 6, 40, 2, 0, 1, 0, 0), ("rnd_kiss", "cloudy", 5, 72, 1, 0, 2, 0, 0), ("max_kiss", "cloudy", 5, 51, 3, 0, 1, 0, 0),
+    ("exp_kiss", "cloudy", 6, 40, 4, 0, 1, 1, 150), ("exprnd_kiss", "aer_idrv", 6, 40, 5, 0, 3, 1, 300),
+    ("mr_mt", "cloudy", 4, 40, 2, 1, 1, 0, 0), ("exprnd_mt", "aer_idrv", 4, 33, 5, 1, 2, 0, 20), ("max_mt", "cloudy", 3, 36, 3, 1, 1, 0, 0),
+]
 COL_CASES = [  # name, input, cloud file, aerosol file
     ("MLS-clr", "input_rrtm_MLS-clr", None, None), ("MLS-clr-aer12", "input_rrtm_MLS-clr-aer12", None, "in_aer_rrtm-aer12"),
     ("MLS-clr-idrv1", "input_rrtm_MLS-clr-idrv1", None, None), ("MLS-clr-xsec", "input_rrtm_MLS-clr-xsec", None, None),
@@ -57,6 +62,35 @@ def main():
                             taug=o["taug"], fracs=o["fracs"], ncbands=o["ncbands"],
                             **{k: o[k] for k in ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc",
                                                  "dtotuflux_dt", "dtotuclfl_dt")}, **bands)
+    # McICA: the reference's one-column generator (src/mcica_subcol_gen_lw.1col.f90) per column - for the Mersenne
+    # Twister every column is its own call (its own freshly seeded stream), as in the reference's column driver -
+    # followed by the McICA rrtmg_lw (src/rrtmg_lw_rad.f90) on the generated sub-columns.
+    refm = Reference("mcica")
+    for name, cfg, ncol, nlay, icld, irng, ims, idcor, juldat in MCICA_CASES:
+        d = make_gcm_inputs(ncol, nlay, cfg, col0=777)
+        rng = np.random.default_rng(12)
+        dz, lat = rng.uniform(100, 1500, (ncol, nlay)), rng.uniform(-90, 90, ncol)
+        alpha = np.zeros((ncol, nlay), order="F")
+        z3 = lambda: np.zeros((140, ncol, nlay), order="F")
+        sub = dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), taucmcl=z3(), reicmcl=np.zeros((ncol, nlay), order="F"),
+                   relqmcl=np.zeros((ncol, nlay), order="F"))
+        for c in range(ncol):
+            alpha[c] = refm.get_alpha_1col(nlay, icld, idcor, 2000.0, dz[c], lat[c], juldat, d["cldfr"][c])
+            r = refm.mcica_subcol_1col(nlay, icld, ims, irng, d["play"][c], d["cldfr"][c], d["cicewp"][c], d["cliqwp"][c],
+                                       d["reice"][c], d["reliq"][c], d["taucld"][:, c, :], alpha[c])
+            for k3, k2 in (("cldfmcl", "cldfmc"), ("ciwpmcl", "ciwpmc"), ("clwpmcl", "clwpmc"), ("taucmcl", "taucmc")):
+                sub[k3][:, c, :] = r[k2]
+            sub["reicmcl"][c] = r["reicmc"]
+            sub["relqmcl"][c] = r["relqmc"]
+        dd = dict(d)
+        dd.update(sub)
+        o = refm.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd)
+        assert set(np.unique(sub["cldfmcl"])) <= {0.0, 1.0}
+        np.savez_compressed(os.path.join(G, f"ref_mcica_{name}.npz"), config=cfg, ncol=ncol, nlay=nlay, icld=icld, irng=irng, ims=ims,
+                            idcor=idcor, juldat=juldat, col0=777, dz=dz, lat=lat, alpha=alpha, icld_out=o["icld"],
+                            mask=np.packbits(sub["cldfmcl"].astype(np.uint8).ravel(order="F")),
+                            ciwpsum=sub["ciwpmcl"].sum(axis=0), clwpsum=sub["clwpmcl"].sum(axis=0), taucsum=sub["taucmcl"].sum(axis=0),
+                            **{k: o[k] for k in OUT_KEYS})
     print("wrote fixtures to", G)
 
 
