@@ -193,6 +193,10 @@ int rrtmg_lw_hip_num_chunks(void);
 void rrtmg_lw_hip_profile_begin(void);
 int rrtmg_lw_hip_profile_end(char *buf, int len);
 
+/* PMC calibration: one kernel that reads `bytes` and writes `bytes` with 16 B per lane (known HBM traffic), so that a
+ * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can fix the counters' unit and scale in the same session. */
+int rrtmg_lw_hip_calibrate_stream(long long bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -652,6 +652,26 @@ int rrtmg_lw_hip_run_columns(
     return read_physics_error(s);
 }
 
+// Streams `bytes` from one device buffer into another with 16 B per lane (k_calibrate): known traffic for PMC calibration.
+int rrtmg_lw_hip_calibrate_stream(long long bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
+    if (bytes < 16) return fail(RRTMG_LW_HIP_EARG, "bytes must be >= 16");
+    const size_t n = (size_t)bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc(&a, n * 16));
+    if (hipMalloc(&b, n * 16) != hipSuccess) { (void)hipFree(a); return fail(RRTMG_LW_HIP_EHIP, "hipMalloc failed"); }
+    (void)hipMemset(a, 0, n * 16);
+    (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL(k_calibrate, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, G.stream, (const double2 *)a, (double2 *)b, n);
+    hipError_t e = hipStreamSynchronize(G.stream);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "calibration kernel failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // McICA flavour
 // ---------------------------------------------------------------------------------------------------

@@ -1818,4 +1818,16 @@ __global__ __launch_bounds__(256) void k_rates(DevTables T, FluxOut out, const d
     out.hrc[lo] = T.heatfac * (fnetc_lo - fnetc_hi) / dp;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_calibrate : reads n 16-byte words per array with 16 B per lane and writes them back (known byte counts),
+//               launched by rrtmg_lw_hip_calibrate_stream so that a PMC run can check the unit and scale of
+//               FETCH_SIZE / WRITE_SIZE on this chip (MI355X_MICROARCH.md, HBM section) in the same session.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_calibrate(const double2 *__restrict__ in, double2 *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { double2 v = in[i]; v.x += 1.0; out[i] = v; }
+}
+
 }  // namespace rrlw
