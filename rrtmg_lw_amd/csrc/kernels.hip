@@ -307,13 +307,16 @@ __global__ __launch_bounds__(256) void k_cloud(DevTables T, Workspace W, GcmIn g
         const int cloudy = cf >= 1.e-6;
         anycloud |= cloudy;
         W.cflag[(size_t)lay * W.ncolb + col] = cloudy;
-        for (int ib = 0; ib < NBND; ib++) {
-            const size_t o = ((size_t)ib * nlay + (lay - 1)) * W.ncolb + col;
+        // stored per SPECTRAL band B (1..16) with the band -> cloud-band map of rtrn :343-349 already applied, so that the
+        // consumers need neither ncbands nor a dependent index load
+        for (int B = 1; B <= NBND; B++) {
+            const int ib = ncbands == 1 ? 0 : (ncbands == 5 ? (B <= 2 ? B - 1 : (B <= 5 ? 2 : (B <= 8 ? 3 : 4))) : B - 1);
             double od = 0.0, ef = 0.0;
-            if (cloudy && ib < ncbands) {
-                od = W.percol[(size_t)(PC_SECDIFF + ib) * W.ncolb + col] * W.taucloud[o];
+            if (cloudy) {
+                od = W.percol[(size_t)(PC_SECDIFF + ib) * W.ncolb + col] * W.taucloud[((size_t)ib * nlay + (lay - 1)) * W.ncolb + col];
                 if (mode == 1) ef = (1. - exp(-od)) * cf;
             }
+            const size_t o = ((size_t)(B - 1) * nlay + (lay - 1)) * W.ncolb + col;
             W.odcld[o] = od;
             if (mode == 1) W.efcl[o] = ef;
         }
@@ -634,6 +637,20 @@ __host__ __device__ constexpr int region_minor_base(const Region &R, bool lower,
     return n;
 }
 
+// g-point "quads": every band is padded to a multiple of 4 g-points; quad q of the 38 holds g-points
+// QG0(band) + 4*(q - QSTART(band)) ... +3 of one band.  Scratch arrays are [array][quad][layer][column][4].
+__host__ __device__ constexpr int band_ng(int B) { return B == 1 ? 10 : B == 2 ? 12 : B == 3 ? 16 : B == 4 ? 14 : B == 5 ? 16 : B == 6 ? 8 : B == 7 ? 12 :
+                                                    B == 8 ? 8 : B == 9 ? 12 : B == 10 ? 6 : B == 11 ? 8 : B == 12 ? 8 : B == 13 ? 4 : 2; }
+__host__ __device__ constexpr int band_nquad(int B) { return (band_ng(B) + 3) / 4; }
+__host__ __device__ constexpr int band_qstart(int B)     // not recursive: a recursive constexpr function that is not folded becomes a
+{                                                       // real device call with a dynamic stack
+    int s = 0;
+    for (int b = 1; b < B; b++) s += band_nquad(b);
+    return s;
+}
+constexpr int NQUAD = band_qstart(17);      // 38
+static_assert(NQUAD == 38, "quad table");
+
 template <int N>
 struct Rows {
     unsigned off[N > 0 ? N : 1];   // element offsets into the packed k-table buffer (row start, g = 0)
@@ -791,36 +808,95 @@ __device__ __forceinline__ double2 ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned ele
     return d;
 }
 
-// tau and Planck fraction of the four g-points g0..g0+3 of band B
+// tau and Planck fraction of ALL g-points of band B (padded to whole quads with zeros).
+// Measured on MI355X (profiles/round1_pmc_v2_two_phase.md): k_layer is bound by exposed memory latency at one wave
+// per SIMD (VALU 12-20 % busy; making every gather wave-uniform or dropping the stores changes little).  The table
+// loads of a band are all independent, so they are issued as a software pipeline: the band's loads form one list
+// (row-major: N rows x ng/2 16-byte loads, then the Planck-fraction rows), cut into chunks of RRLW_LOAD_CHUNK; chunk
+// c+1 is in flight while chunk c is consumed.  sched_barrier keeps the compiler from hoisting every load to the top
+// (which spills) or sinking them to their uses (which serialises the latency again).
+#ifndef RRLW_LOAD_CHUNK
+#define RRLW_LOAD_CHUNK 8
+#endif
+#ifndef RRLW_CLOUD_QUADS
+#define RRLW_CLOUD_QUADS 2      // quads of a band whose cloudy-layer look-ups are in flight together
+#endif
+
 template <int B, bool LOWER, int N>
-__device__ __forceinline__ void rows_eval(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, unsigned g0, double (&tau)[4], double (&frac)[4])
+struct BandLoads {
+    static constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
+    static constexpr int ng = BT<B>::ng;
+    static constexpr int HP = ng / 2;                                    // 16-byte loads per table row
+    static constexpr int NK = N * HP;                                    // absorption-coefficient loads
+    static constexpr int NF = R.key == K_BINARY ? 2 * HP : HP;           // Planck-fraction loads
+    static constexpr int NL = NK + NF;
+    static constexpr int CH = RRLW_LOAD_CHUNK;
+    static constexpr int NCH = (NL + CH - 1) / CH;
+
+    template <int C>
+    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double2 (&b)[CH])
+    {
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int idx = C * CH + k;
+            if (idx < NK) b[k] = ld2(kt, rw.off[idx / HP] + 2u * (unsigned)(idx % HP));
+            else if (idx < NK + HP) b[k] = ld2(kt, rw.foff + 2u * (unsigned)(idx - NK));
+            else if (idx < NL) b[k] = ld2(kt, rw.foff + (unsigned)ng + 2u * (unsigned)(idx - NK - HP));
+        }
+    }
+
+    template <int C>
+    static __device__ __forceinline__ void consume(const Rows<N> &rw, const double2 (&b)[CH], double *tau, double *frac)
+    {
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int idx = C * CH + k;
+            if (idx < NK) {
+                const int i = idx / HP, p = idx % HP;
+                tau[2 * p] = tau[2 * p] + rw.w[i] * b[k].x;
+                tau[2 * p + 1] = tau[2 * p + 1] + rw.w[i] * b[k].y;
+            } else if (idx < NK + HP) {
+                const int p = idx - NK;
+                frac[2 * p] = b[k].x; frac[2 * p + 1] = b[k].y;
+            } else if (idx < NL) {
+                const int p = idx - NK - HP;
+                frac[2 * p] = frac[2 * p] + rw.fpl * (b[k].x - frac[2 * p]);
+                frac[2 * p + 1] = frac[2 * p + 1] + rw.fpl * (b[k].y - frac[2 * p + 1]);
+            }
+        }
+    }
+
+    template <int C>
+    static __device__ __forceinline__ void step(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double2 (&cur)[CH], double2 (&nxt)[CH],
+                                                double *tau, double *frac)
+    {
+        if constexpr (C < NCH) {
+            if constexpr (C + 1 < NCH) issue<C + 1>(kt, rw, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            consume<C>(rw, cur, tau, frac);
+            __builtin_amdgcn_sched_barrier(0);
+            step<C + 1>(kt, rw, nxt, cur, tau, frac);
+        }
+    }
+};
+
+template <int B, bool LOWER, int N>
+__device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double (&tau)[4 * band_nquad(B)],
+                                               double (&frac)[4 * band_nquad(B)])
 {
-    constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
-    constexpr unsigned ng = BT<B>::ng;
-    if constexpr (R.key == K_ZERO) {
+    using BL = BandLoads<B, LOWER, N>;
+    constexpr int NP = 4 * band_nquad(B);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { tau[j] = 0.0; frac[j] = 0.0; }
-        return;
-    } else {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NP; j++) { tau[j] = 0.0; frac[j] = 0.0; }
+    if constexpr (BL::R.key != K_ZERO) {
+        double2 b0[BL::CH], b1[BL::CH];
+        BL::template issue<0>(kt, rw, b0);
+        BL::template step<0>(kt, rw, b0, b1, tau, frac);
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            const double2 a = ld2(kt, rw.off[i] + g0), b = ld2(kt, rw.off[i] + g0 + 2);
-            acc[0] = acc[0] + rw.w[i] * a.x; acc[1] = acc[1] + rw.w[i] * a.y;
-            acc[2] = acc[2] + rw.w[i] * b.x; acc[3] = acc[3] + rw.w[i] * b.y;
-        }
-        const double2 fa = ld2(kt, rw.foff + g0), fb = ld2(kt, rw.foff + g0 + 2);
-        frac[0] = fa.x; frac[1] = fa.y; frac[2] = fb.x; frac[3] = fb.y;
-        if constexpr (R.key == K_BINARY) {
-            const double2 ga = ld2(kt, rw.foff + ng + g0), gb = ld2(kt, rw.foff + ng + g0 + 2);
-            frac[0] = frac[0] + rw.fpl * (ga.x - frac[0]); frac[1] = frac[1] + rw.fpl * (ga.y - frac[1]);
-            frac[2] = frac[2] + rw.fpl * (gb.x - frac[2]); frac[3] = frac[3] + rw.fpl * (gb.y - frac[3]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            tau[j] = acc[j];
-            if constexpr (R.mult == 4) tau[j] = tau[j] * kMult4[g0 + j];
-            else if constexpr (R.mult == 7) tau[j] = tau[j] * kMult7[g0 + j];
+        for (int j = 0; j < BL::ng; j++) {
+            if constexpr (BL::R.mult == 4) tau[j] = tau[j] * kMult4[j];
+            else if constexpr (BL::R.mult == 7) tau[j] = tau[j] * kMult7[j];
         }
     }
 }
@@ -838,121 +914,156 @@ struct LayerArgs {
     const double *tauaer;      // (nct,nlay,16)
 };
 
-__device__ __forceinline__ void gas_layer(double od, const double *__restrict__ lut, double bpade, double &atrans, double &tfn)
-{
-    // clear-layer transmittance: rtrn :439-451
-    if (od <= 0.06) {
-        atrans = od - 0.5 * od * od;
-        tfn = 0.166667 * od;
-    } else {
-        const int itr = (int)(10000.0 * (od / (bpade + od)) + 0.5);
-        const double2 e = reinterpret_cast<const double2 *>(lut)[itr];
-        atrans = 1. - e.x;
-        tfn = e.y;
-    }
-}
-
-// g-point "quads": every band is padded to a multiple of 4 g-points; quad q of the 38 holds g-points
-// QG0(band) + 4*(q - QSTART(band)) ... +3 of one band.  Scratch arrays are [array][quad][layer][column][4].
-__host__ __device__ constexpr int band_ng(int B) { return B == 1 ? 10 : B == 2 ? 12 : B == 3 ? 16 : B == 4 ? 14 : B == 5 ? 16 : B == 6 ? 8 : B == 7 ? 12 :
-                                                    B == 8 ? 8 : B == 9 ? 12 : B == 10 ? 6 : B == 11 ? 8 : B == 12 ? 8 : B == 13 ? 4 : 2; }
-__host__ __device__ constexpr int band_nquad(int B) { return (band_ng(B) + 3) / 4; }
-__host__ __device__ constexpr int band_qstart(int B)     // not recursive: a recursive constexpr function that is not folded becomes a
-{                                                       // real device call with a dynamic stack
-    int s = 0;
-    for (int b = 1; b < B; b++) s += band_nquad(b);
-    return s;
-}
-constexpr int NQUAD = band_qstart(17);      // 38
-static_assert(NQUAD == 38, "quad table");
-
 struct alignas(16) scr4 { scr_t v[4]; };
 
-// cells of quad `qi` (g-points 4*qi .. 4*qi+3 of band B) of one (layer, column)
+// transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
+__device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * (od / (bpade + od)) + 0.5); }
+
+// all cells (g-points) of band B of one (layer, column).
 // CLOUD: 0 clear-sky set, 1 one cloud optical depth per band (rtrn / rtrnmr), 2 one per g-point (rtrnmc)
 template <int B, int CLOUD, bool LOWER, int N>
-__device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, int qi, int lay, int col,
-                                          double blay, double dplankup, double dplankdn, double secdiff, double taua,
-                                          int cloudy, double odcld, double pb, double dpb, bool idrv)
+__device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, int lay, int col,
+                                           double blay, double dplankup, double dplankdn, double secdiff, double taua,
+                                           int cloudy, double odcld, double pb, double dpb, bool idrv)
 {
     constexpr int ng = BT<B>::ng;
+    constexpr int NQ = band_nquad(B), NP = 4 * NQ, QS = band_qstart(B);
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
-    const int g0 = 4 * qi;
-    double tau[4], frac[4];
-    rows_eval<B, LOWER, N>(kt, rw, (unsigned)g0, tau, frac);
+    double od[NP], frac[NP];
+    rows_eval_band<B, LOWER, N>(kt, rw, od, frac);
     const double *S = T.stat;
-    const double *__restrict__ lut = S + T.sl.lut;
+    const double2 *__restrict__ lut2 = reinterpret_cast<const double2 *>(S + T.sl.lut);
+    const double *__restrict__ tau_tbl = S + T.sl.tau_tbl;
     const double bpade = T.bpade;
-    constexpr int QS = band_qstart(B);
-    const int quad = QS + qi;
-    if (lay == 1) {               // surface emission seeds: rtrn :476-479
+    // (kept in the basic block of the table loads: an instruction-sinking pass would otherwise move the whole FMA chains
+    // below the next branch and keep every loaded row alive until then)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool valid = g0 + j < ng;
-            W.rad0[(size_t)(quad * 4 + j) * ncb + col] = valid ? frac[j] * pb : 0.0;
-            if (idrv) W.rad0[(size_t)(4 * NQUAD + quad * 4 + j) * ncb + col] = valid ? frac[j] * dpb : 0.0;
+    for (int j = 0; j < NP; j++) {        // optical depth along the diffusivity angle: rtrn :368-369
+        double o = secdiff * (od[j] + taua);
+        if (!(o >= 0.0) || j >= ng) o = 0.0;
+        od[j] = o;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; j++) {        // pin: the values exist here (LLVM's Sink pass may not move their FMA chains past this point)
+        asm volatile("" : "+v"(od[j]));
+        asm volatile("" : "+v"(frac[j]));
+    }
+    if (lay == 1) {               // surface emission seeds: rtrn :476-479 (padding g-points carry zeros)
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            W.rad0[(size_t)(QS * 4 + j) * ncb + col] = frac[j] * pb;
+            if (idrv) W.rad0[(size_t)(4 * NQUAD + QS * 4 + j) * ncb + col] = frac[j] * dpb;
         }
     }
-    double odc[4] = {odcld, odcld, odcld, odcld};
-    if constexpr (CLOUD == 2) {
-        if (cloudy) {
-            const double2 *po = reinterpret_cast<const double2 *>(W.odg + (((size_t)quad * nlay + (lay - 1)) * ncb + col) * 4);
-            const double2 a = po[0], b = po[1];
-            odc[0] = a.x; odc[1] = a.y; odc[2] = b.x; odc[3] = b.y;
-        }
-    }
-    scr4 oatr, obbd, obbu, oatot, obbdt, obbut;
+    const size_t so0 = ((size_t)QS * nlay + (lay - 1)) * ncb + col;     // scratch cell of the band's first quad
+    const size_t qstride = (size_t)nlay * ncb;
+    if (!(CLOUD && cloudy)) {
+        // clear layer: rtrn :439-451.  All table look-ups of the band are issued before the first is used.
+        double2 e[NP];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const bool valid = g0 + j < ng;          // padding lanes of a band's last quad carry zeros
-        double od = secdiff * (tau[j] + taua);
-        if (!(od >= 0.0) || !valid) od = 0.0;
-        const double fr = valid ? frac[j] : 0.0;
-        if (!(CLOUD && cloudy)) {
-            double atr, tfn;
-            gas_layer(od, lut, bpade, atr, tfn);
-            oatr.v[j] = (scr_t)atr;
-            obbd.v[j] = (scr_t)(fr * (blay + tfn * dplankdn));
-            obbu.v[j] = (scr_t)(fr * (blay + tfn * dplankup));
-        } else {
-            // cloudy layer, three sub-branches: rtrn :372-435
-            double odtot = od + odc[j];
-            double atr, tfgas, atot, tftot;
-            if (odtot < 0.06) {
-                atr = od - 0.5 * od * od; tfgas = 0.166667 * od;
-                atot = odtot - 0.5 * odtot * odtot; tftot = 0.166667 * odtot;
-            } else if (od <= 0.06) {
-                atr = od - 0.5 * od * od; tfgas = 0.166667 * od;
-                const int it = (int)(10000.0 * (odtot / (bpade + odtot)) + 0.5);
-                const double2 e = reinterpret_cast<const double2 *>(lut)[it];
-                atot = 1. - e.x; tftot = e.y;
-            } else {
-                const int ig = (int)(10000.0 * (od / (bpade + od)) + 0.5);
-                const double2 e = reinterpret_cast<const double2 *>(lut)[ig];
-                od = (S + T.sl.tau_tbl)[ig];
-                atr = 1. - e.x; tfgas = e.y;
-                odtot = od + odc[j];
-                const int it = (int)(10000.0 * (odtot / (bpade + odtot)) + 0.5);
-                const double2 e2 = reinterpret_cast<const double2 *>(lut)[it];
-                atot = 1. - e2.x; tftot = e2.y;
+        for (int j = 0; j < NP; j++) {
+            int it = 0;
+            if (j < ng && od[j] > 0.06) it = lut_index(od[j], bpade);
+            e[j] = lut2[it];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            scr4 oatr, obbd, obbu;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 4 * q + k;
+                double atr, tfn;
+                if (od[j] <= 0.06) { atr = od[j] - 0.5 * od[j] * od[j]; tfn = 0.166667 * od[j]; }
+                else { atr = 1. - e[j].x; tfn = e[j].y; }
+                oatr.v[k] = (scr_t)atr;
+                obbd.v[k] = (scr_t)(frac[j] * (blay + tfn * dplankdn));
+                obbu.v[k] = (scr_t)(frac[j] * (blay + tfn * dplankup));
             }
-            oatr.v[j] = (scr_t)atr;
-            obbd.v[j] = (scr_t)(fr * (blay + tfgas * dplankdn));
-            obbu.v[j] = (scr_t)(fr * (blay + tfgas * dplankup));
-            oatot.v[j] = (scr_t)atot;
-            obbdt.v[j] = (scr_t)(fr * (blay + tftot * dplankdn));
-            obbut.v[j] = (scr_t)(fr * (blay + tftot * dplankup));
+            const size_t so = so0 + q * qstride;
+            reinterpret_cast<scr4 *>(W.scr[S_ATR])[so] = oatr;
+            reinterpret_cast<scr4 *>(W.scr[S_BBD])[so] = obbd;
+            reinterpret_cast<scr4 *>(W.scr[S_BBU])[so] = obbu;
         }
-    }
-    const size_t so = ((size_t)quad * nlay + (lay - 1)) * ncb + col;
-    reinterpret_cast<scr4 *>(W.scr[S_ATR])[so] = oatr;
-    reinterpret_cast<scr4 *>(W.scr[S_BBD])[so] = obbd;
-    reinterpret_cast<scr4 *>(W.scr[S_BBU])[so] = obbu;
-    if (CLOUD && cloudy) {
-        reinterpret_cast<scr4 *>(W.scr[S_ATOT])[so] = oatot;
-        reinterpret_cast<scr4 *>(W.scr[S_BBDTOT])[so] = obbdt;
-        reinterpret_cast<scr4 *>(W.scr[S_BBUTOT])[so] = obbut;
+    } else {
+        // cloudy layer, the three sub-branches of rtrn :372-435 in predicated form:
+        //   p1: odtot < 0.06              gas and total both from the series
+        //   p2: else if odepth <= 0.06    gas from the series, total from the table
+        //   p3: else                      gas from the table at itgas, odepth := tau_tbl(itgas), total from the table
+        // processed RRLW_CLOUD_QUADS quads at a time (two dependent table look-ups per cell are in flight for all of them)
+        constexpr int QC = RRLW_CLOUD_QUADS < NQ ? RRLW_CLOUD_QUADS : NQ;
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; q0 += QC) {
+            constexpr int GC = 4 * QC;
+            double odc[GC];
+            double2 e[GC], e2[GC];
+            double tg[GC], odtot[GC];
+#pragma unroll
+            for (int k = 0; k < GC; k++) odc[k] = odcld;
+            if constexpr (CLOUD == 2) {
+#pragma unroll
+                for (int q = 0; q < QC; q++) {
+                    if (q0 + q < NQ) {
+                        const double2 *po = reinterpret_cast<const double2 *>(W.odg + (so0 + (q0 + q) * qstride) * 4);
+                        const double2 a = po[0], b = po[1];
+                        odc[4 * q] = a.x; odc[4 * q + 1] = a.y; odc[4 * q + 2] = b.x; odc[4 * q + 3] = b.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GC; k++) {
+                const int j = 4 * q0 + k;
+                if (j < NP) {
+                    int ig = 0;
+                    const bool p3 = !(od[j] + odc[k] < 0.06) && !(od[j] <= 0.06);
+                    if (j < ng && p3) ig = lut_index(od[j], bpade);
+                    e[k] = lut2[ig];
+                    tg[k] = tau_tbl[ig];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GC; k++) {
+                const int j = 4 * q0 + k;
+                if (j < NP) {
+                    const bool p1 = od[j] + odc[k] < 0.06;
+                    const bool p3 = !p1 && !(od[j] <= 0.06);
+                    odtot[k] = (p3 ? tg[k] : od[j]) + odc[k];
+                    int it = 0;
+                    if (j < ng && !p1) it = lut_index(odtot[k], bpade);
+                    e2[k] = lut2[it];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QC; q++) {
+                if (q0 + q < NQ) {
+                    scr4 oatr, obbd, obbu, oatot, obbdt, obbut;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const int k = 4 * q + kk, j = 4 * (q0 + q) + kk;
+                        const bool p1 = od[j] + odc[k] < 0.06;
+                        const bool p3 = !p1 && !(od[j] <= 0.06);
+                        double atr, tfgas, atot, tftot;
+                        if (p3) { atr = 1. - e[k].x; tfgas = e[k].y; }
+                        else { atr = od[j] - 0.5 * od[j] * od[j]; tfgas = 0.166667 * od[j]; }
+                        if (p1) { atot = odtot[k] - 0.5 * odtot[k] * odtot[k]; tftot = 0.166667 * odtot[k]; }
+                        else { atot = 1. - e2[k].x; tftot = e2[k].y; }
+                        oatr.v[kk] = (scr_t)atr;
+                        obbd.v[kk] = (scr_t)(frac[j] * (blay + tfgas * dplankdn));
+                        obbu.v[kk] = (scr_t)(frac[j] * (blay + tfgas * dplankup));
+                        oatot.v[kk] = (scr_t)atot;
+                        obbdt.v[kk] = (scr_t)(frac[j] * (blay + tftot * dplankdn));
+                        obbut.v[kk] = (scr_t)(frac[j] * (blay + tftot * dplankup));
+                    }
+                    const size_t so = so0 + (q0 + q) * qstride;
+                    reinterpret_cast<scr4 *>(W.scr[S_ATR])[so] = oatr;
+                    reinterpret_cast<scr4 *>(W.scr[S_BBD])[so] = obbd;
+                    reinterpret_cast<scr4 *>(W.scr[S_BBU])[so] = obbu;
+                    reinterpret_cast<scr4 *>(W.scr[S_ATOT])[so] = oatot;
+                    reinterpret_cast<scr4 *>(W.scr[S_BBDTOT])[so] = obbdt;
+                    reinterpret_cast<scr4 *>(W.scr[S_BBUTOT])[so] = obbut;
+                }
+            }
+        }
     }
 }
 
@@ -961,21 +1072,21 @@ __device__ __forceinline__ void band_quad(const DevTables &T, const Workspace &W
 #endif
 
 // all quads of band B for one (layer, column)
+// per-band inputs of one (layer, column) that come from global memory: fetched for ALL bands of the launch group in the
+// kernel prologue, in one memory round trip together with the profile inputs (measured: fetching them band by band costs
+// one exposed HBM latency per band, which dominated k_layer at one wave per SIMD)
+struct BandIn { double blay, dplankup, dplankdn, secdiff, taua, odcld; };
+
 template <int B, int CLOUD>
-__device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
-                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, size_t gc, int indlay, double tlayfrac,
-                                           int indhi, double thifrac, int indlo, double tlofrac, int cloudy, int ncbands)
+__device__ __forceinline__ BandIn band_inputs(const DevTables &T, const Workspace &W, const LayerArgs &a, int lay, int col, size_t gc,
+                                              int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
 {
     const size_t ncb = W.ncolb;
     const int nlay = W.nlay, nct = a.nct;
     const double *S = T.stat;
-    double odcld = 0.0;
-    if (CLOUD == 1) {
-        if (cloudy) {
-            const int ibc = ncbands == 1 ? 0 : (ncbands == 5 ? (B <= 2 ? B - 1 : (B <= 5 ? 2 : (B <= 8 ? 3 : 4))) : B - 1);   // rtrn :343-349
-            odcld = W.odcld[((size_t)ibc * nlay + (lay - 1)) * ncb + col];
-        }
-    }
+    BandIn in;
+    in.odcld = 0.0;
+    if constexpr (CLOUD == 1) in.odcld = W.odcld[((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col];     // zero for clear layers (k_cloud)
     // Planck functions of the layer and of its two interfaces: setcoef :203-269
     const bool alt16 = (B == 16 && a.istart == 16);
     const double *tp = alt16 ? S + T.sl.totplk16 : S + T.sl.totplnk + 181 * (B - 1);
@@ -988,9 +1099,25 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
     } else {
         plev_lo = tp[indlo - 1] + tlofrac * (tp[indlo] - tp[indlo - 1]);
     }
-    const double dplankup = plev_hi - blay, dplankdn = plev_lo - blay;
-    const double secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
-    const double taua = a.tauaer[gc + (size_t)nct * ((lay - 1) + (size_t)nlay * (B - 1))];
+    in.blay = blay;
+    in.dplankup = plev_hi - blay;
+    in.dplankdn = plev_lo - blay;
+    in.secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
+    in.taua = a.tauaer[gc + (size_t)nct * ((lay - 1) + (size_t)nlay * (B - 1))];
+    return in;
+}
+
+__device__ __forceinline__ void pin(BandIn &in)
+{
+    asm volatile("" : "+v"(in.blay), "+v"(in.dplankup), "+v"(in.dplankdn), "+v"(in.secdiff), "+v"(in.taua), "+v"(in.odcld));
+}
+
+// all cells of band B for one (layer, column)
+template <int B, int CLOUD>
+__device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
+                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const BandIn &in)
+{
+    const size_t ncb = W.ncolb;
     double pb = 0.0, dpb = 0.0;
     if (lay == 1) {
         pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + col];
@@ -1001,16 +1128,12 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         constexpr int N = region_nrows(BT<B>::lo, true);
         Rows<N> rw;
         rows_prep<B, true, N>(T, C, rw);
-#pragma unroll 1
-        for (int qi = 0; qi < band_nquad(B); qi++)
-            band_quad<B, CLOUD, true, N>(T, W, kt, rw, qi, lay, col, blay, dplankup, dplankdn, secdiff, taua, cloudy, odcld, pb, dpb, idrv);
+        band_cells<B, CLOUD, true, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv);
     } else {
         constexpr int N = region_nrows(BT<B>::up, false);
         Rows<N> rw;
         rows_prep<B, false, N>(T, C, rw);
-#pragma unroll 1
-        for (int qi = 0; qi < band_nquad(B); qi++)
-            band_quad<B, CLOUD, false, N>(T, W, kt, rw, qi, lay, col, blay, dplankup, dplankdn, secdiff, taua, cloudy, odcld, pb, dpb, idrv);
+        band_cells<B, CLOUD, false, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv);
     }
 }
 
@@ -1136,23 +1259,21 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
 
     // "lower atmosphere" for taumol is lay <= laytrop (the count of layers with ln p > 4.56), :312-313
     const bool lower = lay <= W.laytrop[col];
-    int cloudy = 0, ncbands = 1;
-    if (CLOUD) {
-        cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
-        if (CLOUD == 1 && cloudy) ncbands = W.ncbands[col];
-    }
+    int cloudy = 0;
+    if (CLOUD) cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
     // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
     const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
-#define BAND(B)                                                                                                     \
-    if (B >= a.istart && B <= a.iend)                                                                               \
-        layer_band<B, CLOUD>(T, W, a, C, kt, lower, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, cloudy, ncbands);
-    if constexpr (GROUP == 0) { BAND(3) BAND(14) }
-    else if constexpr (GROUP == 1) { BAND(5) BAND(15) }
-    else if constexpr (GROUP == 2) { BAND(4) BAND(10) BAND(16) }
-    else if constexpr (GROUP == 3) { BAND(7) BAND(8) }
-    else if constexpr (GROUP == 4) { BAND(9) BAND(11) BAND(13) }
-    else { BAND(1) BAND(2) BAND(6) BAND(12) }
+#define INPUTS(B) band_inputs<B, CLOUD>(T, W, a, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac)
+#define BAND(B, IN)                                                                                                 \
+    if (B >= a.istart && B <= a.iend) layer_band<B, CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, IN);
+    if constexpr (GROUP == 0) { BandIn i0 = INPUTS(3), i1 = INPUTS(14); pin(i0); pin(i1); BAND(3, i0) BAND(14, i1) }
+    else if constexpr (GROUP == 1) { BandIn i0 = INPUTS(5), i1 = INPUTS(15); pin(i0); pin(i1); BAND(5, i0) BAND(15, i1) }
+    else if constexpr (GROUP == 2) { BandIn i0 = INPUTS(4), i1 = INPUTS(10), i2 = INPUTS(16); pin(i0); pin(i1); pin(i2); BAND(4, i0) BAND(10, i1) BAND(16, i2) }
+    else if constexpr (GROUP == 3) { BandIn i0 = INPUTS(7), i1 = INPUTS(8); pin(i0); pin(i1); BAND(7, i0) BAND(8, i1) }
+    else if constexpr (GROUP == 4) { BandIn i0 = INPUTS(9), i1 = INPUTS(11), i2 = INPUTS(13); pin(i0); pin(i1); pin(i2); BAND(9, i0) BAND(11, i1) BAND(13, i2) }
+    else { BandIn i0 = INPUTS(1), i1 = INPUTS(2), i2 = INPUTS(6), i3 = INPUTS(12); pin(i0); pin(i1); pin(i2); pin(i3); BAND(1, i0) BAND(2, i1) BAND(6, i2) BAND(12, i3) }
 #undef BAND
+#undef INPUTS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1542,13 +1663,8 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
     Part2 *__restrict__ pup = W.pup + ((size_t)quad * (nlay + 1)) * ncb + col;
     Part2 *__restrict__ dbase = W.dpart + ((size_t)quad * (nlay + 1)) * ncb + col;
 
-    int ibc = 0;
     bool colcloud = false;
-    if constexpr (MODE != 0) {
-        const int ncbands = W.ncbands[col];
-        ibc = ncbands == 1 ? 0 : (ncbands == 5 ? (B <= 2 ? B - 1 : (B <= 5 ? 2 : (B <= 8 ? 3 : 4))) : B - 1);
-        colcloud = (W.cflag[col] & 8) != 0;
-    }
+    if constexpr (MODE != 0) colcloud = (W.cflag[col] & 8) != 0;
 
     double radld[NGC], radclrd[NGC], cldrad[NGC], clrrad[NGC], radmr[NGC];
 #pragma unroll
@@ -1570,7 +1686,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
             cloudy = flags & 1;
             if (cloudy) {
                 if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
-                if constexpr (MODE == 1) efcl = W.efcl[((size_t)ibc * nlay + (lev - 1)) * ncb + col];
+                if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
             }
         }
         const size_t so = (size_t)(lev - 1) * ncb;
@@ -1675,7 +1791,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
             cloudy = flags & 1;
             if (cloudy) {
                 if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
-                if constexpr (MODE == 1) efcl = W.efcl[((size_t)ibc * nlay + (lev - 1)) * ncb + col];
+                if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
             }
         }
         const size_t so = (size_t)(lev - 1) * ncb;
