@@ -123,9 +123,9 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         {(void **)&W.scr[S_BBD], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
         {(void **)&W.scr[S_BBU], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
         {(void **)&W.rad0, (size_t)2 * NQUAD * 4 * n * 8},
-        {(void **)&W.pdn, (size_t)NQUAD * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.pup, (size_t)NQUAD * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.dpart, (size_t)NQUAD * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.pdn, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.pup, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.dpart, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.laytrop, n * 4},
         {(void **)&W.ncbands, n * 4},
         {(void **)&W.cflag, (L + 2) * n * 4},
@@ -176,10 +176,12 @@ template <bool GCM>
 int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
               const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
 {
-    const dim3 grid((nb + BLOCK - 1) / BLOCK), block(BLOCK);
-    LAUNCH("k_colprep", (k_colprep<GCM>), grid, block, s, G.D, G.W, g, c, nb, col0, nct, idrv, istart);
+    const dim3 block(BLOCK);
+    // thread-per-column kernels: one wave per workgroup so that a 32768-column batch (512 waves) spreads over all 256 CUs
+    const dim3 cgrid1((nb + 63) / 64), cblock1(64);
+    LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, G.W, g, c, nb, col0, nct, idrv, istart);
     if (mode == 1 || mode == 2)
-        LAUNCH("k_cloud", (k_cloud<GCM>), grid, block, s, G.D, G.W, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+        LAUNCH("k_cloud", (k_cloud<GCM>), cgrid1, cblock1, s, G.D, G.W, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
     if (mode == 3) {
         const dim3 cgrid((nb + BLOCK - 1) / BLOCK, nlay);
         if (mc) LAUNCH("k_cloudmc<arrays>", (k_cloudmc<false>), cgrid, block, s, G.D, G.W, *mc, g, nb, col0, nct, inflag, iceflag, liqflag);
@@ -201,11 +203,22 @@ int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int 
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
     sa.emis = GCM ? g.emis : c.semiss;
     sa.cldfrac = GCM ? g.cldfr : c.cldfrac;
-    const dim3 sgrid(gx, NQUAD);
-    if (mode == 0) LAUNCH("k_sweep<0>", (k_sweep<0>), sgrid, block, s, G.D, G.W, sa);
-    else if (mode == 1) LAUNCH("k_sweep<1>", (k_sweep<1>), sgrid, block, s, G.D, G.W, sa);
-    else if (mode == 3) LAUNCH("k_sweep<3>", (k_sweep<3>), sgrid, block, s, G.D, G.W, sa);
-    else LAUNCH("k_sweep<2>", (k_sweep<2>), sgrid, block, s, G.D, G.W, sa);
+    // one sweep launch per class of bands with the same number of quads (workgroup = 64 columns x that many waves)
+    for (int nq = 4; nq >= 1; nq--) {
+        unsigned long long list = 0ull;
+        int nb_bands = 0;
+        for (int B = 1; B <= NBND; B++)
+            if (band_nquad(B) == nq && B >= istart && B <= iend) list |= (unsigned long long)(B - 1) << (4 * nb_bands++);
+        if (nb_bands == 0) continue;
+        sa.bands = list;
+        const dim3 sgrid((nb + 63) / 64, nb_bands), sblock(64, nq);
+#define SWEEP(M, Q) LAUNCH("k_sweep<" #M ">", (k_sweep<M, Q>), sgrid, sblock, s, G.D, G.W, sa)
+#define SWEEP_MODE(Q)                                                          \
+        if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3) SWEEP(3, Q); else SWEEP(2, Q);
+        if (nq == 4) { SWEEP_MODE(4) } else if (nq == 3) { SWEEP_MODE(3) } else if (nq == 2) { SWEEP_MODE(2) } else { SWEEP_MODE(1) }
+#undef SWEEP_MODE
+#undef SWEEP
+    }
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
     LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, G.W, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);
     LAUNCH("k_rates", k_rates, rgrid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct);

@@ -52,7 +52,7 @@ enum MrFac { MR_FACCLD1, MR_FACCLD2, MR_FACCLR1, MR_FACCLR2, MR_FACCMB1, MR_FACC
              MR_FACCLD1D, MR_FACCLD2D, MR_FACCLR1D, MR_FACCLR2D, MR_FACCMB1D, MR_FACCMB2D, NMRFAC };
 // per-cell terms handed from k_layer to k_sweep, each [NQUAD][nlay][ncolb][4]
 enum Scr { S_ATR, S_BBD, S_BBU, S_ATOT, S_BBDTOT, S_BBUTOT, NSCR };
-// per-quad partial fluxes, each [quad][level][column] of {total-sky, clear-sky}: downward, upward, d(upward)/dT
+// per-band partial fluxes, each [band][level][column] of {total-sky, clear-sky}: downward, upward, d(upward)/dT
 struct alignas(16) Part2 { double a, b; };
 
 // storage type of the per-cell terms handed from k_layer to k_sweep (all arithmetic stays float64)
@@ -75,8 +75,8 @@ struct Workspace {
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcld, bit2 istcldd; cflag[0] bit3 = column has cloud
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
     double *rad0;       // [2][4*NQUAD][ncolb]  fracs(1,g)*plankbnd, fracs(1,g)*dplankbnd_dt
-    Part2 *pdn, *pup;   // [NQUAD][nlay+1][ncolb]
-    Part2 *dpart;       // [NQUAD][nlay+1][ncolb]  (idrv = 1)
+    Part2 *pdn, *pup;   // [16 bands][nlay+1][ncolb]
+    Part2 *dpart;       // [16 bands][nlay+1][ncolb]  (idrv = 1)
     int *err;           // [1] first physics error code
     // McICA (rtrnmc): per-g-point cloud terms, written by k_cloudmc
     double *odg;        // [NQUAD][nlay][ncolb][4]     secdiff(band) * taucmc(g)
@@ -1622,32 +1622,36 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 #endif
 
 struct SweepArgs {
+    unsigned long long bands;  // the launch's bands (all with the same number of quads), one nibble (band - 1) per blockIdx.y
     int ncol, col0, nct, idrv;
     int istart, iend;          // only bands in [istart, iend] are swept
     const double *emis;        // semiss (nct,16)
     const double *cldfrac;     // (nct,nlay)
 };
 
-__device__ __forceinline__ int quad_band(int q)     // 1-based band of quad q
-{
-    constexpr int qs[17] = {band_qstart(1), band_qstart(2), band_qstart(3), band_qstart(4), band_qstart(5), band_qstart(6),
-                            band_qstart(7), band_qstart(8), band_qstart(9), band_qstart(10), band_qstart(11), band_qstart(12),
-                            band_qstart(13), band_qstart(14), band_qstart(15), band_qstart(16), band_qstart(17)};
-    int b = 1;
-#pragma unroll
-    for (int B = 2; B <= 16; B++) b += (q >= qs[B - 1]) ? 1 : 0;
-    return b;
-}
+constexpr int SWEEP_LV = 4;       // levels per reduction round == quad slots per workgroup (blockDim.y)
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepArgs a)
+// Workgroup = 64 columns x the NQ quads of ONE band (blockIdx.y indexes the launch's list of bands with NQ quads).  Each wave sweeps one quad; every SWEEP_LV levels the
+// waves' partial flux sums meet in LDS and are added in quad order, so only one slab per BAND (not per quad) goes to HBM:
+// measured (profiles/round1_pmc_v2_two_phase.md) k_sweep runs at 5.3 TB/s of HBM traffic, a quarter of it these partials.
+#ifndef RRLW_SWEEP_WAVES
+#define RRLW_SWEEP_WAVES 2         // waves per SIMD the sweep is compiled for (HBM-bound: memory-level parallelism comes from occupancy)
+#endif
+
+template <int MODE, int NQ>
+__global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T, Workspace W, SweepArgs a)
 {
     constexpr int NGC = 4;
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= a.ncol) return;
-    const int quad = blockIdx.y;
-    const int B = quad_band(quad);
-    if (B < a.istart || B > a.iend) return;
+    constexpr int LV = SWEEP_LV;
+    __shared__ Part2 red[NQ > 1 ? NQ * LV * 64 : 1];            // [slot][level-in-round][column]
+    const int tx = threadIdx.x, slot = threadIdx.y;
+    const int col = blockIdx.x * 64 + tx;
+    const int B = (int)((a.bands >> (4 * blockIdx.y)) & 15ull) + 1;     // bands with NQ quads, packed as nibbles (band - 1)
+    if (B < a.istart || B > a.iend) return;         // uniform over the workgroup
+    constexpr int nq = NQ;
+    const bool active = col < a.ncol;
+    const bool incol = active;
+    const int quad = band_qstart(B) + slot;
     const size_t gc = (size_t)a.col0 + col;
     const int nlay = W.nlay, nct = a.nct;
     const size_t ncb = W.ncolb;
@@ -1659,220 +1663,307 @@ __global__ __launch_bounds__(256) void k_sweep(DevTables T, Workspace W, SweepAr
     const scr4 *__restrict__ sT = reinterpret_cast<const scr4 *>(W.scr[S_ATOT]) + (size_t)quad * nlay * ncb + col;
     const scr4 *__restrict__ sTd = reinterpret_cast<const scr4 *>(W.scr[S_BBDTOT]) + (size_t)quad * nlay * ncb + col;
     const scr4 *__restrict__ sTu = reinterpret_cast<const scr4 *>(W.scr[S_BBUTOT]) + (size_t)quad * nlay * ncb + col;
-    Part2 *__restrict__ pdn = W.pdn + ((size_t)quad * (nlay + 1)) * ncb + col;
-    Part2 *__restrict__ pup = W.pup + ((size_t)quad * (nlay + 1)) * ncb + col;
-    Part2 *__restrict__ dbase = W.dpart + ((size_t)quad * (nlay + 1)) * ncb + col;
+    Part2 *__restrict__ pdn = W.pdn + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    Part2 *__restrict__ pup = W.pup + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+
+    // adds the round's partials of the band's quads in quad order; wave `slot` finishes levels lev0 + dir * (slot, slot + NQ, ..)
+    auto reduce_store = [&](const Part2 (&acc)[LV], Part2 *__restrict__ dst, int lev0, int dir) {
+        if constexpr (NQ == 1) {
+#pragma unroll
+            for (int i = 0; i < LV; i++) {
+                const int lv = lev0 + dir * i;
+                if (incol && lv >= 0 && lv <= nlay) dst[(size_t)lv * ncb] = acc[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LV; i++) red[(slot * LV + i) * 64 + tx] = acc[i];
+            __syncthreads();
+#pragma unroll
+            for (int i0 = 0; i0 < LV; i0 += NQ) {
+                const int i = i0 + slot;
+                const int lv = lev0 + dir * i;
+                if (i < LV && incol && lv >= 0 && lv <= nlay) {
+                    Part2 sum = red[i * 64 + tx];
+#pragma unroll
+                    for (int q = 1; q < NQ; q++) {
+                        const Part2 v = red[(q * LV + i) * 64 + tx];
+                        sum.a = sum.a + v.a;
+                        sum.b = sum.b + v.b;
+                    }
+                    dst[(size_t)lv * ncb] = sum;
+                }
+            }
+            __syncthreads();
+        }
+    };
 
     bool colcloud = false;
-    if constexpr (MODE != 0) colcloud = (W.cflag[col] & 8) != 0;
+    if constexpr (MODE != 0) { if (incol) colcloud = (W.cflag[col] & 8) != 0; }
 
     double radld[NGC], radclrd[NGC], cldrad[NGC], clrrad[NGC], radmr[NGC];
 #pragma unroll
     for (int j = 0; j < NGC; j++) { radld[j] = 0.0; radclrd[j] = 0.0; cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
     int iclddn = 0;
-    {   // downward flux at the top level is zero
+    if (slot == 0 && incol) {   // downward flux at the top level is zero
         Part2 z{0.0, 0.0};
         pdn[(size_t)nlay * ncb] = z;
     }
 
-    // ------------------------------------------------------------------ downward sweep
-    // (unrolled so that the independent per-cell loads of several levels are in flight while the recurrence runs)
-#pragma unroll 4
-    for (int lev = nlay; lev >= 1; lev--) {
-        int cloudy = 0, flags = 0;
-        double cf = 0.0, efcl = 0.0;
-        if constexpr (MODE != 0) {
-            flags = W.cflag[(size_t)lev * ncb + col];
-            cloudy = flags & 1;
-            if (cloudy) {
-                if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
-                if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
+    // ------------------------------------------------------------------ downward sweep, SWEEP_LV levels per round
+    // (the unrolled round keeps the independent per-cell loads of several levels in flight while the recurrence runs)
+    // the unconditional loads of a round (gas terms, layer flags) are issued one round ahead, before the reduction's
+    // barriers, so that they are in flight while the previous round's partial sums meet in LDS
+    scr4 pA[LV], pB[LV];
+    int pF[LV];
+    auto prefetch_down = [&](int top) {
+#pragma unroll
+        for (int i = 0; i < LV; i++) {
+            const int lev = top - i;
+            pF[i] = 0;
+            if (active && lev >= 1) {
+                const size_t so = (size_t)(lev - 1) * ncb;
+                pA[i] = sA[so];
+                pB[i] = sBd[so];
+                if constexpr (MODE != 0) pF[i] = W.cflag[(size_t)lev * ncb + col];
             }
         }
-        const size_t so = (size_t)(lev - 1) * ncb;
-        const scr4 vatr = sA[so], vbbd = sBd[so];
-        double dsum = 0.0, dsumc = 0.0;
-        if (!cloudy) {
+    };
+    prefetch_down(nlay);
+    for (int top = nlay; top >= 1; top -= LV) {
+        Part2 acc[LV];
+        scr4 cA[LV], cB[LV];
+        int cF[LV];
 #pragma unroll
-            for (int j = 0; j < NGC; j++) {
-                const double atr = vatr.v[j], bbd = vbbd.v[j];
-                radld[j] = radld[j] + (bbd - radld[j]) * atr;
-                dsum = dsum + radld[j];
-                if constexpr (MODE != 0) {
-                    if (iclddn) radclrd[j] = radclrd[j] + (bbd - radclrd[j]) * atr;
-                    else radclrd[j] = radld[j];
-                    dsumc = dsumc + radclrd[j];
+        for (int i = 0; i < LV; i++) { cA[i] = pA[i]; cB[i] = pB[i]; cF[i] = pF[i]; }
+        prefetch_down(top - LV);
+#pragma unroll
+        for (int i = 0; i < LV; i++) {
+            const int lev = top - i;
+            acc[i] = Part2{0.0, 0.0};
+            if (!(active && lev >= 1)) continue;
+            int cloudy = 0, flags = 0;
+            double cf = 0.0, efcl = 0.0;
+            if constexpr (MODE != 0) {
+                flags = cF[i];
+                cloudy = flags & 1;
+                if (cloudy) {
+                    if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
+                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
                 }
             }
-        } else {
-            if constexpr (MODE != 0) {
-                iclddn = 1;
-                const scr4 vatot = sT[so], vbbdt = sTd[so];
-                double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
-                if constexpr (MODE == 2) {
-                    const size_t mo = (size_t)(lev - 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
-                    fclr1 = W.mrfac[MR_FACCLR1D * ms + mo]; fcld1 = W.mrfac[MR_FACCLD1D * ms + mo];
-                    fcmb1 = W.mrfac[MR_FACCMB1D * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2D * ms + mo];
-                    fclr2 = W.mrfac[MR_FACCLR2D * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2D * ms + mo];
-                }
-                double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
-                if constexpr (MODE == 3) {          // rtrnmc: cloud fraction and effective emissivity per g-point
-                    const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
-                    const float4 c4 = pc[0], e4 = pc[1];
-                    cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
-                    efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
-                }
+            const size_t so = (size_t)(lev - 1) * ncb;
+            const scr4 vatr = cA[i], vbbd = cB[i];
+            double dsum = 0.0, dsumc = 0.0;
+            if (!cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    const double atr = vatr.v[j], bbd = vbbd.v[j], atot = vatot.v[j], bbdtot = vbbdt.v[j];
-                    const double gassrc = bbd * atr;
-                    if constexpr (MODE == 1 || MODE == 3) {
-                        radld[j] = radld[j] - radld[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbdtot * atot - gassrc);
-                    } else {            // rtrnmr :591-615
-                        if (flags & 4) {        // istcldd(lev) == 1
-                            cldrad[j] = cf * radld[j];
-                            clrrad[j] = radld[j] - cldrad[j];
-                            radmr[j] = 0.0;
-                        }
-                        const double ttot = 1. - atot;
-                        const double cldsrc = bbdtot * atot;
-                        cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                        clrrad[j] = clrrad[j] * (1. - atr) + (1. - cf) * gassrc;
-                        radld[j] = cldrad[j] + clrrad[j];
-                        const double radmod = radmr[j] * (fclr1 * (1. - atr) + fcld1 * ttot) - fcmb1 * gassrc + fcmb2 * cldsrc;
-                        const double oldcld = cldrad[j] - radmod;
-                        const double oldclr = clrrad[j] + radmod;
-                        radmr[j] = -radmod + fclr2 * oldclr - fcld2 * oldcld;
-                        cldrad[j] = cldrad[j] + radmr[j];
-                        clrrad[j] = clrrad[j] - radmr[j];
-                    }
+                    const double atr = vatr.v[j], bbd = vbbd.v[j];
+                    radld[j] = radld[j] + (bbd - radld[j]) * atr;
                     dsum = dsum + radld[j];
-                    radclrd[j] = radclrd[j] + (bbd - radclrd[j]) * atr;
-                    dsumc = dsumc + radclrd[j];
+                    if constexpr (MODE != 0) {
+                        if (iclddn) radclrd[j] = radclrd[j] + (bbd - radclrd[j]) * atr;
+                        else radclrd[j] = radld[j];
+                        dsumc = dsumc + radclrd[j];
+                    }
+                }
+            } else {
+                if constexpr (MODE != 0) {
+                    iclddn = 1;
+                    const scr4 vatot = sT[so], vbbdt = sTd[so];
+                    double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
+                    if constexpr (MODE == 2) {
+                        const size_t mo = (size_t)(lev - 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
+                        fclr1 = W.mrfac[MR_FACCLR1D * ms + mo]; fcld1 = W.mrfac[MR_FACCLD1D * ms + mo];
+                        fcmb1 = W.mrfac[MR_FACCMB1D * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2D * ms + mo];
+                        fclr2 = W.mrfac[MR_FACCLR2D * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2D * ms + mo];
+                    }
+                    double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
+                    if constexpr (MODE == 3) {          // rtrnmc: cloud fraction and effective emissivity per g-point
+                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
+                        const float4 c4 = pc[0], e4 = pc[1];
+                        cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
+                        efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NGC; j++) {
+                        const double atr = vatr.v[j], bbd = vbbd.v[j], atot = vatot.v[j], bbdtot = vbbdt.v[j];
+                        const double gassrc = bbd * atr;
+                        if constexpr (MODE == 1 || MODE == 3) {
+                            radld[j] = radld[j] - radld[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbdtot * atot - gassrc);
+                        } else {            // rtrnmr :591-615
+                            if (flags & 4) {        // istcldd(lev) == 1
+                                cldrad[j] = cf * radld[j];
+                                clrrad[j] = radld[j] - cldrad[j];
+                                radmr[j] = 0.0;
+                            }
+                            const double ttot = 1. - atot;
+                            const double cldsrc = bbdtot * atot;
+                            cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
+                            clrrad[j] = clrrad[j] * (1. - atr) + (1. - cf) * gassrc;
+                            radld[j] = cldrad[j] + clrrad[j];
+                            const double radmod = radmr[j] * (fclr1 * (1. - atr) + fcld1 * ttot) - fcmb1 * gassrc + fcmb2 * cldsrc;
+                            const double oldcld = cldrad[j] - radmod;
+                            const double oldclr = clrrad[j] + radmod;
+                            radmr[j] = -radmod + fclr2 * oldclr - fcld2 * oldcld;
+                            cldrad[j] = cldrad[j] + radmr[j];
+                            clrrad[j] = clrrad[j] - radmr[j];
+                        }
+                        dsum = dsum + radld[j];
+                        radclrd[j] = radclrd[j] + (bbd - radclrd[j]) * atr;
+                        dsumc = dsumc + radclrd[j];
+                    }
                 }
             }
+            acc[i] = Part2{(dsum * 0.5) * wtdelw, (dsumc * 0.5) * wtdelw};
         }
-        {
-            Part2 o{(dsum * 0.5) * wtdelw, (dsumc * 0.5) * wtdelw};
-            pdn[(size_t)(lev - 1) * ncb] = o;
-        }
+        reduce_store(acc, pdn, top - 1, -1);
     }
 
     // ------------------------------------------------------------------ surface: rtrn :476-495
-    const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
     double radlu[NGC], radclru[NGC], drad[NGC], dradc[NGC];
-    double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
+    Part2 surf{0.0, 0.0}, dsurf{0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < NGC; j++) {
-        const double rad0 = W.rad0[(size_t)(quad * 4 + j) * ncb + col];
-        radlu[j] = rad0 + reflect * radld[j];
-        radclru[j] = rad0 + reflect * radclrd[j];
-        usum = usum + radlu[j];
-        usumc = usumc + radclru[j];
-        drad[j] = idrv ? W.rad0[(size_t)(4 * NQUAD + quad * 4 + j) * ncb + col] : 0.0;
-        dradc[j] = drad[j];
-        dusum = dusum + drad[j];
-    }
-    {
-        Part2 o{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
-        pup[0] = o;
-        if (idrv) { Part2 od{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusum * 0.5) * wtdelw) * T.fluxfac}; dbase[0] = od; }
+    for (int j = 0; j < NGC; j++) { radlu[j] = 0.0; radclru[j] = 0.0; drad[j] = 0.0; dradc[j] = 0.0; }
+    if (active) {
+        const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
+        double usum = 0.0, usumc = 0.0, dusum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NGC; j++) {
+            const double rad0 = W.rad0[(size_t)(quad * 4 + j) * ncb + col];
+            radlu[j] = rad0 + reflect * radld[j];
+            radclru[j] = rad0 + reflect * radclrd[j];
+            usum = usum + radlu[j];
+            usumc = usumc + radclru[j];
+            drad[j] = idrv ? W.rad0[(size_t)(4 * NQUAD + quad * 4 + j) * ncb + col] : 0.0;
+            dradc[j] = drad[j];
+            dusum = dusum + drad[j];
+        }
+        surf = Part2{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
+        dsurf = Part2{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusum * 0.5) * wtdelw) * T.fluxfac};
     }
 #pragma unroll
     for (int j = 0; j < NGC; j++) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
 
-    // ------------------------------------------------------------------ upward sweep
-#pragma unroll 4
-    for (int lev = 1; lev <= nlay; lev++) {
-        int cloudy = 0, flags = 0;
-        double cf = 0.0, efcl = 0.0;
-        if constexpr (MODE != 0) {
-            flags = W.cflag[(size_t)lev * ncb + col];
-            cloudy = flags & 1;
-            if (cloudy) {
-                if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
-                if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
+    // ------------------------------------------------------------------ upward sweep: round r covers levels base .. base+LV-1,
+    // level 0 being the surface value computed above
+    auto prefetch_up = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < LV; i++) {
+            const int lev = base + i;
+            pF[i] = 0;
+            if (active && lev >= 1 && lev <= nlay) {
+                const size_t so = (size_t)(lev - 1) * ncb;
+                pA[i] = sA[so];
+                pB[i] = sBu[so];
+                if constexpr (MODE != 0) pF[i] = W.cflag[(size_t)lev * ncb + col];
             }
         }
-        const size_t so = (size_t)(lev - 1) * ncb;
-        const scr4 vatr = sA[so], vbbu = sBu[so];
-        usum = 0.0; usumc = 0.0; dusum = 0.0; dusumc = 0.0;
-        if (!cloudy) {
+    };
+    prefetch_up(0);
+    for (int base = 0; base <= nlay; base += LV) {
+        Part2 acc[LV], accd[LV];
+        scr4 cA[LV], cB[LV];
+        int cF[LV];
 #pragma unroll
-            for (int j = 0; j < NGC; j++) {
-                const double atr = vatr.v[j], bbu = vbbu.v[j];
-                radlu[j] = radlu[j] + (bbu - radlu[j]) * atr;
-                usum = usum + radlu[j];
-                if (idrv) { drad[j] = drad[j] * (1.0 - atr); dusum = dusum + drad[j]; }
-                if constexpr (MODE != 0) {
-                    if (colcloud) {
-                        radclru[j] = radclru[j] + (bbu - radclru[j]) * atr;
-                        if (idrv) { dradc[j] = dradc[j] * (1.0 - atr); dusumc = dusumc + dradc[j]; }
-                    } else {
-                        radclru[j] = radlu[j];
-                        if (idrv) { dradc[j] = drad[j]; dusumc = dusumc + dradc[j]; }
-                    }
-                    usumc = usumc + radclru[j];
+        for (int i = 0; i < LV; i++) { cA[i] = pA[i]; cB[i] = pB[i]; cF[i] = pF[i]; }
+        prefetch_up(base + LV);
+#pragma unroll
+        for (int i = 0; i < LV; i++) {
+            const int lev = base + i;
+            acc[i] = Part2{0.0, 0.0};
+            accd[i] = Part2{0.0, 0.0};
+            if (!(active && lev <= nlay)) continue;
+            if (lev == 0) { acc[i] = surf; accd[i] = dsurf; continue; }
+            int cloudy = 0, flags = 0;
+            double cf = 0.0, efcl = 0.0;
+            if constexpr (MODE != 0) {
+                flags = cF[i];
+                cloudy = flags & 1;
+                if (cloudy) {
+                    if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
+                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
                 }
             }
-        } else {
-            if constexpr (MODE != 0) {
-                const scr4 vatot = sT[so], vbbut = sTu[so];
-                double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
-                if constexpr (MODE == 2) {
-                    const size_t mo = (size_t)(lev + 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
-                    fclr1 = W.mrfac[MR_FACCLR1 * ms + mo]; fcld1 = W.mrfac[MR_FACCLD1 * ms + mo];
-                    fcmb1 = W.mrfac[MR_FACCMB1 * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2 * ms + mo];
-                    fclr2 = W.mrfac[MR_FACCLR2 * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2 * ms + mo];
-                }
-                double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
-                if constexpr (MODE == 3) {
-                    const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
-                    const float4 c4 = pc[0], e4 = pc[1];
-                    cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
-                    efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
-                }
+            const size_t so = (size_t)(lev - 1) * ncb;
+            const scr4 vatr = cA[i], vbbu = cB[i];
+            double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
+            if (!cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    const double atr = vatr.v[j], bbu = vbbu.v[j], atot = vatot.v[j], bbutot = vbbut.v[j];
-                    const double gassrc = bbu * atr;
-                    if constexpr (MODE == 1 || MODE == 3) {
-                        radlu[j] = radlu[j] - radlu[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbutot * atot - gassrc);
-                    } else {            // rtrnmr :680-703
-                        if (flags & 2) {        // istcld(lev) == 1
-                            cldrad[j] = cf * radlu[j];
-                            clrrad[j] = radlu[j] - cldrad[j];
-                            radmr[j] = 0.0;
-                        }
-                        const double ttot = 1. - atot;
-                        const double cldsrc = bbutot * atot;
-                        cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                        clrrad[j] = clrrad[j] * (1.0 - atr) + (1. - cf) * gassrc;
-                        radlu[j] = cldrad[j] + clrrad[j];
-                        const double radmod = radmr[j] * (fclr1 * (1.0 - atr) + fcld1 * ttot) - fcmb1 * gassrc + fcmb2 * cldsrc;
-                        const double oldcld = cldrad[j] - radmod;
-                        const double oldclr = clrrad[j] + radmod;
-                        radmr[j] = -radmod + fclr2 * oldclr - fcld2 * oldcld;
-                        cldrad[j] = cldrad[j] + radmr[j];
-                        clrrad[j] = clrrad[j] - radmr[j];
-                    }
+                    const double atr = vatr.v[j], bbu = vbbu.v[j];
+                    radlu[j] = radlu[j] + (bbu - radlu[j]) * atr;
                     usum = usum + radlu[j];
-                    if (idrv) {
-                        drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr);
-                        dusum = dusum + drad[j];
-                        dradc[j] = dradc[j] * (1.0 - atr);
-                        dusumc = dusumc + dradc[j];
+                    if (idrv) { drad[j] = drad[j] * (1.0 - atr); dusum = dusum + drad[j]; }
+                    if constexpr (MODE != 0) {
+                        if (colcloud) {
+                            radclru[j] = radclru[j] + (bbu - radclru[j]) * atr;
+                            if (idrv) { dradc[j] = dradc[j] * (1.0 - atr); dusumc = dusumc + dradc[j]; }
+                        } else {
+                            radclru[j] = radlu[j];
+                            if (idrv) { dradc[j] = drad[j]; dusumc = dusumc + dradc[j]; }
+                        }
+                        usumc = usumc + radclru[j];
                     }
-                    radclru[j] = radclru[j] + (bbu - radclru[j]) * atr;
-                    usumc = usumc + radclru[j];
+                }
+            } else {
+                if constexpr (MODE != 0) {
+                    const scr4 vatot = sT[so], vbbut = sTu[so];
+                    double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
+                    if constexpr (MODE == 2) {
+                        const size_t mo = (size_t)(lev + 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
+                        fclr1 = W.mrfac[MR_FACCLR1 * ms + mo]; fcld1 = W.mrfac[MR_FACCLD1 * ms + mo];
+                        fcmb1 = W.mrfac[MR_FACCMB1 * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2 * ms + mo];
+                        fclr2 = W.mrfac[MR_FACCLR2 * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2 * ms + mo];
+                    }
+                    double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
+                    if constexpr (MODE == 3) {
+                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
+                        const float4 c4 = pc[0], e4 = pc[1];
+                        cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
+                        efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NGC; j++) {
+                        const double atr = vatr.v[j], bbu = vbbu.v[j], atot = vatot.v[j], bbutot = vbbut.v[j];
+                        const double gassrc = bbu * atr;
+                        if constexpr (MODE == 1 || MODE == 3) {
+                            radlu[j] = radlu[j] - radlu[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbutot * atot - gassrc);
+                        } else {            // rtrnmr :680-703
+                            if (flags & 2) {        // istcld(lev) == 1
+                                cldrad[j] = cf * radlu[j];
+                                clrrad[j] = radlu[j] - cldrad[j];
+                                radmr[j] = 0.0;
+                            }
+                            const double ttot = 1. - atot;
+                            const double cldsrc = bbutot * atot;
+                            cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
+                            clrrad[j] = clrrad[j] * (1.0 - atr) + (1. - cf) * gassrc;
+                            radlu[j] = cldrad[j] + clrrad[j];
+                            const double radmod = radmr[j] * (fclr1 * (1.0 - atr) + fcld1 * ttot) - fcmb1 * gassrc + fcmb2 * cldsrc;
+                            const double oldcld = cldrad[j] - radmod;
+                            const double oldclr = clrrad[j] + radmod;
+                            radmr[j] = -radmod + fclr2 * oldclr - fcld2 * oldcld;
+                            cldrad[j] = cldrad[j] + radmr[j];
+                            clrrad[j] = clrrad[j] - radmr[j];
+                        }
+                        usum = usum + radlu[j];
+                        if (idrv) {
+                            drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr);
+                            dusum = dusum + drad[j];
+                            dradc[j] = dradc[j] * (1.0 - atr);
+                            dusumc = dusumc + dradc[j];
+                        }
+                        radclru[j] = radclru[j] + (bbu - radclru[j]) * atr;
+                        usumc = usumc + radclru[j];
+                    }
                 }
             }
+            acc[i] = Part2{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
+            if (idrv) accd[i] = Part2{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusumc * 0.5) * wtdelw) * T.fluxfac};
         }
-        {
-            Part2 o{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
-            pup[(size_t)lev * ncb] = o;
-            if (idrv) { Part2 od{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusumc * 0.5) * wtdelw) * T.fluxfac}; dbase[(size_t)lev * ncb] = od; }
-        }
+        reduce_store(acc, pup, base, +1);
+        if (idrv) reduce_store(accd, dbase, base, +1);
     }
 }
 
@@ -1893,14 +1984,8 @@ __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut 
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
-    unsigned long long active = 0ull;          // quads of the bands in [istart, iend] (wave-uniform)
-    for (int k = 0; k < NQUAD; k++) {
-        const int qb = quad_band(k);
-        if (qb >= istart && qb <= iend) active |= 1ull << k;
-    }
-#pragma unroll 2
-    for (int k = 0; k < NQUAD; k++) {
-        if (!((active >> k) & 1ull)) continue;
+#pragma unroll 4
+    for (int k = istart - 1; k < iend; k++) {       // band slabs in band order (rtrn :549-574)
         const size_t po = ((size_t)k * (nlay + 1) + lev) * ncb + col;
         const Part2 pu = W.pup[po], pd = W.pdn[po];
         u = u + pu.a;
