@@ -32,6 +32,10 @@ struct State {
     int ws_nlay = 0, ws_ncolb = 0;
     bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
+    // per-column / cloud-property arrays exist twice: k_colprep + k_cloud of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *taucloud, *odcld, *efcl, *mrfac; int *cflag; } prep[2] = {};
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_in = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     // McICA sub-column masks of all columns of the current call
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
@@ -118,7 +122,6 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     Workspace &W = G.W;
     W = Workspace{};
     std::vector<Item> items = {
-        {(void **)&W.percol, (size_t)NPERCOL * n * 8},
         {(void **)&W.scr[S_ATR], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
         {(void **)&W.scr[S_BBD], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
         {(void **)&W.scr[S_BBU], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
@@ -126,18 +129,24 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         {(void **)&W.pdn, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.pup, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.dpart, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.laytrop, n * 4},
-        {(void **)&W.ncbands, n * 4},
-        {(void **)&W.cflag, (L + 2) * n * 4},
     };
+    for (auto &ps : G.prep) {
+        ps = State::PrepSet{};
+        items.push_back({(void **)&ps.percol, (size_t)NPERCOL * n * 8});
+        items.push_back({(void **)&ps.laytrop, n * 4});
+        items.push_back({(void **)&ps.ncbands, n * 4});
+        items.push_back({(void **)&ps.cflag, (L + 2) * n * 4});
+    }
     if (cloud) {
         items.push_back({(void **)&W.scr[S_ATOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
         items.push_back({(void **)&W.scr[S_BBDTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
         items.push_back({(void **)&W.scr[S_BBUTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-        items.push_back({(void **)&W.taucloud, 16 * L * n * 8});
-        items.push_back({(void **)&W.odcld, 16 * L * n * 8});
-        items.push_back({(void **)&W.efcl, 16 * L * n * 8});
-        items.push_back({(void **)&W.mrfac, (size_t)NMRFAC * (L + 2) * n * 8});
+        for (auto &ps : G.prep) {
+            items.push_back({(void **)&ps.taucloud, 16 * L * n * 8});
+            items.push_back({(void **)&ps.odcld, 16 * L * n * 8});
+            items.push_back({(void **)&ps.efcl, 16 * L * n * 8});
+            items.push_back({(void **)&ps.mrfac, (size_t)NMRFAC * (L + 2) * n * 8});
+        }
     }
     if (mc) {
         items.push_back({(void **)&W.odg, (size_t)NQUAD * 4 * L * n * 8});
@@ -151,6 +160,11 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     W.ncolb = ncolb;
     W.nlay = nlay;
     W.err = G.d_err;
+    {   // G.W itself carries prep set 0
+        const State::PrepSet &ps = G.prep[0];
+        W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
+        W.taucloud = ps.taucloud; W.odcld = ps.odcld; W.efcl = ps.efcl; W.mrfac = ps.mrfac;
+    }
     G.ws_bytes = total;
     G.ws_nlay = nlay;
     G.ws_ncolb = ncolb;
@@ -170,22 +184,43 @@ int ensure_mask(int nlay, size_t ncol)
     return 0;
 }
 
-// one column batch, everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr, 3 rtrnmc (McICA; `mc` = the
-// sub-column arrays, or null when the sub-columns come from the generator's mask in G.W.mask)
-template <bool GCM>
-int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
-              const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
+// the workspace view of prep set k (see State::prep)
+Workspace ws_for(int k)
 {
-    const dim3 block(BLOCK);
+    Workspace w = G.W;
+    const State::PrepSet &ps = G.prep[k];
+    w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
+    w.taucloud = ps.taucloud; w.odcld = ps.odcld; w.efcl = ps.efcl; w.mrfac = ps.mrfac;
+    return w;
+}
+
+// per-column part of one batch: k_colprep (+ k_cloud for rtrn / rtrnmr).  Few threads, long serial loops: it runs on the
+// auxiliary stream one batch ahead of the heavy kernels (run_pipelined).
+template <bool GCM>
+int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int mode, int idrv, int istart,
+             const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag)
+{
     // thread-per-column kernels: one wave per workgroup so that a 32768-column batch (512 waves) spreads over all 256 CUs
     const dim3 cgrid1((nb + 63) / 64), cblock1(64);
-    LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, G.W, g, c, nb, col0, nct, idrv, istart);
+    LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, idrv, istart);
     if (mode == 1 || mode == 2)
-        LAUNCH("k_cloud", (k_cloud<GCM>), cgrid1, cblock1, s, G.D, G.W, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+        LAUNCH("k_cloud", (k_cloud<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// the heavy part of one batch, everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr, 3 rtrnmc (McICA; `mc` = the
+// sub-column arrays, or null when the sub-columns come from the generator's mask in Wk.mask)
+template <bool GCM>
+int run_main(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
+             const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
+{
+    const dim3 block(BLOCK);
     if (mode == 3) {
         const dim3 cgrid((nb + BLOCK - 1) / BLOCK, nlay);
-        if (mc) LAUNCH("k_cloudmc<arrays>", (k_cloudmc<false>), cgrid, block, s, G.D, G.W, *mc, g, nb, col0, nct, inflag, iceflag, liqflag);
-        else LAUNCH("k_cloudmc<mask>", (k_cloudmc<true>), cgrid, block, s, G.D, G.W, McIn{}, g, nb, col0, nct, inflag, iceflag, liqflag);
+        if (mc) LAUNCH("k_cloudmc<arrays>", (k_cloudmc<false>), cgrid, block, s, G.D, Wk, *mc, g, nb, col0, nct, inflag, iceflag, liqflag);
+        else LAUNCH("k_cloudmc<mask>", (k_cloudmc<true>), cgrid, block, s, G.D, Wk, McIn{}, g, nb, col0, nct, inflag, iceflag, liqflag);
     }
     LayerArgs la;
     la.ncol = nb; la.col0 = col0; la.nct = nct; la.idrv = idrv; la.istart = istart; la.iend = iend;
@@ -194,10 +229,22 @@ int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int 
     const unsigned gx = (nb + BLOCK - 1) / BLOCK;
     const dim3 lgrid(gx, nlay);
 #define LAYER_GROUP(GR)                                                                                              \
-    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, block, s, G.D, G.W, g, c, la);         \
-    else if (mode == 3) { if constexpr (GCM) LAUNCH("k_layer<mcica," #GR ">", (k_layer<true, 2, GR>), lgrid, block, s, G.D, G.W, g, c, la); } \
-    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, block, s, G.D, G.W, g, c, la);
-    LAYER_GROUP(0) LAYER_GROUP(1) LAYER_GROUP(2) LAYER_GROUP(3) LAYER_GROUP(4) LAYER_GROUP(5)
+    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, block, s, G.D, Wk, g, c, la);         \
+    else if (mode == 3) { if constexpr (GCM) LAUNCH("k_layer<mcica," #GR ">", (k_layer<true, 2, GR>), lgrid, block, s, G.D, Wk, g, c, la); } \
+    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, block, s, G.D, Wk, g, c, la);
+    LAYER_GROUP(0)
+#if RRLW_LAYER_GROUPS > 1
+    LAYER_GROUP(1)
+#endif
+#if RRLW_LAYER_GROUPS > 2
+    LAYER_GROUP(2)
+#endif
+#if RRLW_LAYER_GROUPS > 3
+    LAYER_GROUP(3) LAYER_GROUP(4) LAYER_GROUP(5)
+#endif
+#if RRLW_LAYER_GROUPS > 6
+    LAYER_GROUP(6) LAYER_GROUP(7) LAYER_GROUP(8)
+#endif
 #undef LAYER_GROUP
     SweepArgs sa;
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
@@ -212,7 +259,7 @@ int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int 
         if (nb_bands == 0) continue;
         sa.bands = list;
         const dim3 sgrid((nb + 63) / 64, nb_bands), sblock(64, nq);
-#define SWEEP(M, Q) LAUNCH("k_sweep<" #M ">", (k_sweep<M, Q>), sgrid, sblock, s, G.D, G.W, sa)
+#define SWEEP(M, Q) LAUNCH("k_sweep<" #M "," #Q ">", (k_sweep<M, Q>), sgrid, sblock, s, G.D, Wk, sa)
 #define SWEEP_MODE(Q)                                                          \
         if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3) SWEEP(3, Q); else SWEEP(2, Q);
         if (nq == 4) { SWEEP_MODE(4) } else if (nq == 3) { SWEEP_MODE(3) } else if (nq == 2) { SWEEP_MODE(2) } else { SWEEP_MODE(1) }
@@ -220,10 +267,57 @@ int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int 
 #undef SWEEP
     }
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
-    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, G.W, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);
+    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);
     LAUNCH("k_rates", k_rates, rgrid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+
+// one batch on one stream (host-pointer entries, whose staging buffer serialises the batches anyway)
+template <bool GCM>
+int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
+              const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
+{
+    const Workspace Wk = ws_for(0);
+    if (int rc = run_prep<GCM>(s, Wk, nb, col0, nct, mode, idrv, istart, g, c, inflag, iceflag, liqflag)) return rc;
+    return run_main<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out, mc);
+}
+
+int ensure_pipeline()
+{
+    if (G.aux) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&G.aux, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&G.ev_in, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(hipEventCreateWithFlags(&G.ev_ready[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&G.ev_done[k], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// all batches of a device-resident call on the caller's stream `s`, the per-column kernels of batch i+1 overlapping the
+// heavy kernels of batch i on the auxiliary stream (two prep sets)
+int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const GcmIn &g, int inflag, int iceflag, int liqflag,
+                  const FluxOut &out, const McIn *mc)
+{
+    if (int rc = ensure_pipeline()) return rc;
+    const int nbmax = std::min(ncol, G.batch);
+    ColIn c{};
+    HIP_TRY(hipEventRecord(G.ev_in, s));                 // inputs are ready when the caller's stream gets here
+    HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_in, 0));
+    int i = 0;
+    for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
+        const int nb = std::min(nbmax, ncol - col0), k = i & 1;
+        const Workspace Wk = ws_for(k);
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_done[k], 0));       // prep set k is free again
+        if (int rc = run_prep<true>(G.aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
+        HIP_TRY(hipEventRecord(G.ev_ready[k], G.aux));
+        HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
+        if (int rc = run_main<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, out, mc)) return rc;
+        HIP_TRY(hipEventRecord(G.ev_done[k], s));
+    }
     return 0;
 }
 
@@ -451,6 +545,11 @@ void rrtmg_lw_hip_finalize(void)
     if (G.d_stat) (void)hipFree(G.d_stat);
     if (G.d_err) (void)hipFree(G.d_err);
     if (G.stream) (void)hipStreamDestroy(G.stream);
+    if (G.aux) {
+        (void)hipStreamDestroy(G.aux);
+        (void)hipEventDestroy(G.ev_in);
+        for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_ready[k]); (void)hipEventDestroy(G.ev_done[k]); }
+    }
     G = State();
 }
 
@@ -537,14 +636,8 @@ int rrtmg_lw_hip_run_nomcica_device(
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
-    ColIn c{};
     FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
-    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
-        const int nb = std::min(nbmax, ncol - col0);
-        if (int rc = run_batch<true>((hipStream_t)stream, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out))
-            return rc;
-    }
-    return 0;
+    return run_pipelined((hipStream_t)stream, ncol, nlay, mode, idrv, g, inflglw, iceflglw, liqflglw, out, nullptr);
 }
 
 int rrtmg_lw_hip_run_nomcica(
@@ -712,14 +805,8 @@ int rrtmg_lw_hip_run_mcica_device(
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tauaer};
     McIn m{cldfmcl, taucmcl, ciwpmcl, clwpmcl, reicmcl, relqmcl};
-    ColIn c{};
     FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
-    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
-        const int nb = std::min(nbmax, ncol - col0);
-        if (int rc = run_batch<true>((hipStream_t)stream, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, &m))
-            return rc;
-    }
-    return 0;
+    return run_pipelined((hipStream_t)stream, ncol, nlay, mode, idrv, g, inflglw, iceflglw, liqflglw, out, &m);
 }
 
 int rrtmg_lw_hip_run_mcica(
@@ -869,13 +956,8 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
         if (int rc = generate_mask(s, ncol, nlay, icld_gen, permuteseed, *irng, play, cldfr, alpha)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
-    ColIn c{};
     FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
-    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
-        const int nb = std::min(nbmax, ncol - col0);
-        if (int rc = run_batch<true>(s, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, nullptr)) return rc;
-    }
-    return 0;
+    return run_pipelined(s, ncol, nlay, mode, idrv, g, inflglw, iceflglw, liqflglw, out, nullptr);
 }
 
 int rrtmg_lw_hip_run_mcica_subcol(

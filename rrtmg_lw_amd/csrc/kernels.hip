@@ -19,6 +19,8 @@
 // Reference lines are cited per routine.  No CPU fallback exists anywhere in this file.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "tables.hpp"
 
 namespace rrlw {
@@ -1138,9 +1140,37 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
 }
 
 
-// band groups: one k_layer launch covers the bands of one group; its threads do the inatm/setcoef prologue once
-//   0: 3,14   1: 5,15   2: 4,10,16   3: 7,8   4: 9,11,13   5: 1,2,6,12
-constexpr int NLGROUP = 6;
+// band groups: one k_layer launch covers the bands of one group; its threads do the inatm/setcoef prologue once.
+// Fewer groups = less repeated prologue work, more groups = shorter kernels (RRLW_LAYER_GROUPS: 6, 3, 2 or 1).
+#ifndef RRLW_LAYER_GROUPS
+#define RRLW_LAYER_GROUPS 6
+#endif
+constexpr int NLGROUP = RRLW_LAYER_GROUPS;
+
+template <int NG, int G> struct GroupBands;
+#define GROUP_BANDS(NG, G, ...)                                                \
+    template <> struct GroupBands<NG, G> {                                     \
+        static constexpr int b[] = {__VA_ARGS__};                              \
+        static constexpr int n = sizeof(b) / sizeof(int);                      \
+    };
+GROUP_BANDS(6, 0, 3, 14) GROUP_BANDS(6, 1, 5, 15) GROUP_BANDS(6, 2, 4, 10, 16) GROUP_BANDS(6, 3, 7, 8) GROUP_BANDS(6, 4, 9, 11, 13)
+GROUP_BANDS(6, 5, 1, 2, 6, 12)
+GROUP_BANDS(3, 0, 3, 14, 5, 15) GROUP_BANDS(3, 1, 4, 10, 16, 7, 8) GROUP_BANDS(3, 2, 9, 11, 13, 1, 2, 6, 12)
+GROUP_BANDS(2, 0, 3, 14, 5, 15, 4, 10, 16) GROUP_BANDS(2, 1, 7, 8, 9, 11, 13, 1, 2, 6, 12)
+GROUP_BANDS(1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16)
+GROUP_BANDS(9, 0, 3) GROUP_BANDS(9, 1, 5) GROUP_BANDS(9, 2, 4) GROUP_BANDS(9, 3, 7, 14) GROUP_BANDS(9, 4, 9, 15) GROUP_BANDS(9, 5, 8, 16, 13)
+GROUP_BANDS(9, 6, 1, 10) GROUP_BANDS(9, 7, 2, 11) GROUP_BANDS(9, 8, 6, 12)
+#undef GROUP_BANDS
+
+template <class GB, int CLOUD, int... K>
+__device__ __forceinline__ void group_run(std::integer_sequence<int, K...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
+                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, size_t gc, int cloudy,
+                                          int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
+{
+    BandIn in[GB::n] = {band_inputs<GB::b[K], CLOUD>(T, W, a, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac)...};
+    (pin(in[K]), ...);
+    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, in[K]) : (void)0), ...);
+}
 
 template <bool GCM, int CLOUD, int GROUP>
 __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
@@ -1263,17 +1293,9 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
     if (CLOUD) cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
     // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
     const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
-#define INPUTS(B) band_inputs<B, CLOUD>(T, W, a, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac)
-#define BAND(B, IN)                                                                                                 \
-    if (B >= a.istart && B <= a.iend) layer_band<B, CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, IN);
-    if constexpr (GROUP == 0) { BandIn i0 = INPUTS(3), i1 = INPUTS(14); pin(i0); pin(i1); BAND(3, i0) BAND(14, i1) }
-    else if constexpr (GROUP == 1) { BandIn i0 = INPUTS(5), i1 = INPUTS(15); pin(i0); pin(i1); BAND(5, i0) BAND(15, i1) }
-    else if constexpr (GROUP == 2) { BandIn i0 = INPUTS(4), i1 = INPUTS(10), i2 = INPUTS(16); pin(i0); pin(i1); pin(i2); BAND(4, i0) BAND(10, i1) BAND(16, i2) }
-    else if constexpr (GROUP == 3) { BandIn i0 = INPUTS(7), i1 = INPUTS(8); pin(i0); pin(i1); BAND(7, i0) BAND(8, i1) }
-    else if constexpr (GROUP == 4) { BandIn i0 = INPUTS(9), i1 = INPUTS(11), i2 = INPUTS(13); pin(i0); pin(i1); pin(i2); BAND(9, i0) BAND(11, i1) BAND(13, i2) }
-    else { BandIn i0 = INPUTS(1), i1 = INPUTS(2), i2 = INPUTS(6), i3 = INPUTS(12); pin(i0); pin(i1); pin(i2); pin(i3); BAND(1, i0) BAND(2, i1) BAND(6, i2) BAND(12, i3) }
-#undef BAND
-#undef INPUTS
+    using GB = GroupBands<NLGROUP, GROUP>;
+    group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, lower, lay, col, gc, cloudy,
+                         indlay, tlayfrac, indhi, thifrac, indlo, tlofrac);
 }
 
 // ------------------------------------------------------------------------------------------------
