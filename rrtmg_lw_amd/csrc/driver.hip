@@ -230,7 +230,8 @@ int run_main(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
     const dim3 lgrid(gx, nlay);
 #define LAYER_GROUP(GR)                                                                                              \
     if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, block, s, G.D, Wk, g, c, la);         \
-    else if (mode == 3) { if constexpr (GCM) LAUNCH("k_layer<mcica," #GR ">", (k_layer<true, 2, GR>), lgrid, block, s, G.D, Wk, g, c, la); } \
+    else if (mode == 3) { if constexpr (GCM) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<true, 2, GR>), lgrid, block, s, G.D, Wk, g, c, la); \
+                                               else LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, block, s, G.D, Wk, g, c, la); } } \
     else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, block, s, G.D, Wk, g, c, la);
     LAYER_GROUP(0)
 #if RRLW_LAYER_GROUPS > 1
@@ -261,7 +262,7 @@ int run_main(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
         const dim3 sgrid((nb + 63) / 64, nb_bands), sblock(64, nq);
 #define SWEEP(M, Q) LAUNCH("k_sweep<" #M "," #Q ">", (k_sweep<M, Q>), sgrid, sblock, s, G.D, Wk, sa)
 #define SWEEP_MODE(Q)                                                          \
-        if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3) SWEEP(3, Q); else SWEEP(2, Q);
+        if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q);
         if (nq == 4) { SWEEP_MODE(4) } else if (nq == 3) { SWEEP_MODE(3) } else if (nq == 2) { SWEEP_MODE(2) } else { SWEEP_MODE(1) }
 #undef SWEEP_MODE
 #undef SWEEP
@@ -299,8 +300,12 @@ int ensure_pipeline()
 
 // all batches of a device-resident call on the caller's stream `s`, the per-column kernels of batch i+1 overlapping the
 // heavy kernels of batch i on the auxiliary stream (two prep sets)
+int launch_kiss(hipStream_t s, const Workspace &Wk, int ncol, int col0, int nb, int nlay, int icld, int permuteseed, const SubcolIn &in);
+
+struct KissGen { bool on; int icld, permuteseed; const double *alpha; };      // kissvec generator folded into the per-batch prep
+
 int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const GcmIn &g, int inflag, int iceflag, int liqflag,
-                  const FluxOut &out, const McIn *mc)
+                  const FluxOut &out, const McIn *mc, KissGen gen = KissGen{false, 0, 0, nullptr})
 {
     if (int rc = ensure_pipeline()) return rc;
     const int nbmax = std::min(ncol, G.batch);
@@ -313,6 +318,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         const Workspace Wk = ws_for(k);
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_done[k], 0));       // prep set k is free again
         if (int rc = run_prep<true>(G.aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
+        if (gen.on) launch_kiss(G.aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha});
         HIP_TRY(hipEventRecord(G.ev_ready[k], G.aux));
         HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
         if (int rc = run_main<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, out, mc)) return rc;
@@ -420,9 +426,25 @@ struct MT19937 {
     }
 };
 
-// Sub-column masks of all `ncol` columns into G.mask (device arrays play, cldfrac, alpha are (ncol,nlay)).
-int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, int irng, const double *play,
-                  const double *cldfrac, const double *alpha)
+// kissvec masks of columns col0 .. col0+nb-1 (of ncol) on stream s; G.W.mask must be set up (prepare_mask)
+int launch_kiss(hipStream_t s, const Workspace &Wk, int ncol, int col0, int nb, int nlay, int icld, int permuteseed, const SubcolIn &in)
+{
+    const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned);
+    const dim3 grid((nb + SUBCOL_BLOCK - 1) / SUBCOL_BLOCK), block(SUBCOL_BLOCK);
+    if (G.profile) {
+        State::ProfRec r{"k_subcol_kiss", get_event(), get_event()};
+        (void)hipEventRecord(r.a, s);
+        hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, Wk, in, ncol, col0, nb, nlay, icld, permuteseed);
+        (void)hipEventRecord(r.b, s);
+        G.prof.push_back(r);
+    } else {
+        hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, Wk, in, ncol, col0, nb, nlay, icld, permuteseed);
+    }
+    return 0;
+}
+
+// mask buffer for all `ncol` columns of the call + argument checks of the generator
+int prepare_mask(int ncol, int nlay, int icld, int irng, const double *alpha)
 {
     if (nlay < 4 && irng == 0) return fail(RRTMG_LW_HIP_EARG, "the kissvec generator needs at least four layers");
     if ((icld == 4 || icld == 5) && !alpha) return fail(RRTMG_LW_HIP_EARG, "icld = 4/5 needs alpha");
@@ -431,22 +453,23 @@ int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, 
     G.W.mask_stride = (size_t)ncol;
     G.W.mask_col0 = 0;
     G.W.err = G.d_err;
-    SubcolIn in{play, cldfrac, alpha};
     if (irng == 0) {
         const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned);
         if (lds > 160 * 1024) return fail(RRTMG_LW_HIP_EARG, "nlay=%d exceeds the generator's LDS budget", nlay);
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const dim3 grid((ncol + SUBCOL_BLOCK - 1) / SUBCOL_BLOCK), block(SUBCOL_BLOCK);
-        if (G.profile) {
-            State::ProfRec r{"k_subcol_kiss", get_event(), get_event()};
-            (void)hipEventRecord(r.a, s);
-            hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, G.W, in, ncol, nlay, icld, permuteseed);
-            (void)hipEventRecord(r.b, s);
-            G.prof.push_back(r);
-        } else {
-            hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, G.W, in, ncol, nlay, icld, permuteseed);
-        }
+    }
+    return 0;
+}
+
+// Sub-column masks of all `ncol` columns into G.mask (device arrays play, cldfrac, alpha are (ncol,nlay)).
+int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, int irng, const double *play,
+                  const double *cldfrac, const double *alpha)
+{
+    if (int rc = prepare_mask(ncol, nlay, icld, irng, alpha)) return rc;
+    SubcolIn in{play, cldfrac, alpha};
+    if (irng == 0) {
+        launch_kiss(s, G.W, ncol, 0, ncol, nlay, icld, permuteseed, in);
     } else {
         // one stream over (sub-column, column, layer): drawn here, applied per sub-column slab on the device
         HIP_TRY(hipMemsetAsync(G.mask, 0, (size_t)5 * nlay * ncol * sizeof(unsigned), s));
@@ -951,13 +974,18 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     const int mode = icld_gen == 0 ? 0 : 3;
     hipStream_t s = (hipStream_t)stream;
     const int nbmax = std::min(ncol, G.batch);
-    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, mode == 3)) return rc;
-    if (mode == 3)
-        if (int rc = generate_mask(s, ncol, nlay, icld_gen, permuteseed, *irng, play, cldfr, alpha)) return rc;
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false)) return rc;      // mask path: no per-g-point cloud arrays
+    KissGen gen{false, icld_gen, permuteseed, alpha};
+    if (mode == 3) {
+        if (*irng == 0) {          // kissvec: every column owns its stream -> generated batch by batch on the auxiliary stream
+            if (int rc = prepare_mask(ncol, nlay, icld_gen, 0, alpha)) return rc;
+            gen.on = true;
+        } else if (int rc = generate_mask(s, ncol, nlay, icld_gen, permuteseed, *irng, play, cldfr, alpha)) return rc;
+    }
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
     FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
-    return run_pipelined(s, ncol, nlay, mode, idrv, g, inflglw, iceflglw, liqflglw, out, nullptr);
+    return run_pipelined(s, ncol, nlay, mode, idrv, g, inflglw, iceflglw, liqflglw, out, nullptr, gen);
 }
 
 int rrtmg_lw_hip_run_mcica_subcol(
@@ -974,7 +1002,7 @@ int rrtmg_lw_hip_run_mcica_subcol(
     const int mode = icld_gen == 0 ? 0 : 3;
     const bool cloud = mode == 3, two = icld_gen == 4 || icld_gen == 5;
     const int nbmax = std::min(ncol, G.batch);
-    if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud)) return rc;
+    if (int rc = ensure_workspace(nlay, nbmax, cloud, false)) return rc;
     const size_t L = (size_t)nlay, n = (size_t)ncol;
     hipStream_t s = G.stream;
     // 1. masks of all columns (the Mersenne-Twister stream couples the columns): needs play, cldfr, alpha of every column

@@ -651,6 +651,13 @@ __host__ __device__ constexpr int band_qstart(int B)     // not recursive: a rec
     return s;
 }
 constexpr int NQUAD = band_qstart(17);      // 38
+__host__ __device__ constexpr int band_g0(int B)      // 0-based first g-point of band B among the 140
+{
+    int s = 0;
+    for (int b = 1; b < B; b++) s += band_ng(b);
+    return s;
+}
+static_assert(band_g0(17) == NGPT, "g-point table");
 static_assert(NQUAD == 38, "quad table");
 
 template <int N>
@@ -922,11 +929,12 @@ struct alignas(16) scr4 { scr_t v[4]; };
 __device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * (od / (bpade + od)) + 0.5); }
 
 // all cells (g-points) of band B of one (layer, column).
-// CLOUD: 0 clear-sky set, 1 one cloud optical depth per band (rtrn / rtrnmr), 2 one per g-point (rtrnmc)
+// CLOUD: 0 clear-sky set, 1 one cloud optical depth per band (rtrn / rtrnmr), 2 one per g-point from W.odg (rtrnmc, sub-column
+// arrays), 3 the band's value where the sub-column mask has a bit (rtrnmc, generator mask; gbits = the band's ng mask bits)
 template <int B, int CLOUD, bool LOWER, int N>
 __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, int lay, int col,
                                            double blay, double dplankup, double dplankdn, double secdiff, double taua,
-                                           int cloudy, double odcld, double pb, double dpb, bool idrv)
+                                           int cloudy, double odcld, double pb, double dpb, bool idrv, unsigned gbits)
 {
     constexpr int ng = BT<B>::ng;
     constexpr int NQ = band_nquad(B), NP = 4 * NQ, QS = band_qstart(B);
@@ -1002,6 +1010,10 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
             double tg[GC], odtot[GC];
 #pragma unroll
             for (int k = 0; k < GC; k++) odc[k] = odcld;
+            if constexpr (CLOUD == 3) {
+#pragma unroll
+                for (int k = 0; k < GC; k++) odc[k] = ((gbits >> (4 * q0 + k)) & 1u) ? odcld : 0.0;
+            }
             if constexpr (CLOUD == 2) {
 #pragma unroll
                 for (int q = 0; q < QC; q++) {
@@ -1088,7 +1100,7 @@ __device__ __forceinline__ BandIn band_inputs(const DevTables &T, const Workspac
     const double *S = T.stat;
     BandIn in;
     in.odcld = 0.0;
-    if constexpr (CLOUD == 1) in.odcld = W.odcld[((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col];     // zero for clear layers (k_cloud)
+    if constexpr (CLOUD == 1 || CLOUD == 3) in.odcld = W.odcld[((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col];   // zero for clear layers (k_cloud / k_cloudmc)
     // Planck functions of the layer and of its two interfaces: setcoef :203-269
     const bool alt16 = (B == 16 && a.istart == 16);
     const double *tp = alt16 ? S + T.sl.totplk16 : S + T.sl.totplnk + 181 * (B - 1);
@@ -1117,8 +1129,15 @@ __device__ __forceinline__ void pin(BandIn &in)
 // all cells of band B for one (layer, column)
 template <int B, int CLOUD>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
-                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const BandIn &in)
+                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const BandIn &in,
+                                           const unsigned (&mw)[5])
 {
+    unsigned gbits = 0u;
+    if constexpr (CLOUD == 3) {
+        constexpr int g0 = band_g0(B), ng = BT<B>::ng, w0 = g0 >> 5;
+        const unsigned long long lo = mw[w0], hi = w0 < 4 ? mw[w0 + 1 < 5 ? w0 + 1 : 4] : 0u;
+        gbits = (unsigned)(((lo | (hi << 32)) >> (g0 & 31)) & ((1ull << ng) - 1ull));
+    }
     const size_t ncb = W.ncolb;
     double pb = 0.0, dpb = 0.0;
     if (lay == 1) {
@@ -1130,12 +1149,12 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         constexpr int N = region_nrows(BT<B>::lo, true);
         Rows<N> rw;
         rows_prep<B, true, N>(T, C, rw);
-        band_cells<B, CLOUD, true, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv);
+        band_cells<B, CLOUD, true, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv, gbits);
     } else {
         constexpr int N = region_nrows(BT<B>::up, false);
         Rows<N> rw;
         rows_prep<B, false, N>(T, C, rw);
-        band_cells<B, CLOUD, false, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv);
+        band_cells<B, CLOUD, false, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv, gbits);
     }
 }
 
@@ -1165,11 +1184,12 @@ GROUP_BANDS(9, 6, 1, 10) GROUP_BANDS(9, 7, 2, 11) GROUP_BANDS(9, 8, 6, 12)
 template <class GB, int CLOUD, int... K>
 __device__ __forceinline__ void group_run(std::integer_sequence<int, K...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
                                           const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, size_t gc, int cloudy,
-                                          int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
+                                          int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac,
+                                          const unsigned (&mw)[5])
 {
     BandIn in[GB::n] = {band_inputs<GB::b[K], CLOUD>(T, W, a, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac)...};
     (pin(in[K]), ...);
-    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, in[K]) : (void)0), ...);
+    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, in[K], mw) : (void)0), ...);
 }
 
 template <bool GCM, int CLOUD, int GROUP>
@@ -1293,9 +1313,16 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
     if (CLOUD) cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
     // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
     const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
+    unsigned mw[5] = {0u, 0u, 0u, 0u, 0u};
+    if constexpr (CLOUD == 3) {
+        if (cloudy) {
+#pragma unroll
+            for (int w = 0; w < 5; w++) mw[w] = W.mask[((size_t)w * W.nlay + (lay - 1)) * W.mask_stride + W.mask_col0 + gc];
+        }
+    }
     using GB = GroupBands<NLGROUP, GROUP>;
     group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, lower, lay, col, gc, cloudy,
-                         indlay, tlayfrac, indhi, thifrac, indlo, tlofrac);
+                         indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, mw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1307,13 +1334,6 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
 //                     properties - the same values the generator would have expanded into those arrays
 //                     (src/mcica_subcol_gen_lw.f90:664-680).
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int band_g0(int B)      // 0-based first g-point of band B among the 140
-{
-    int s = 0;
-    for (int b = 1; b < B; b++) s += band_ng(b);
-    return s;
-}
-static_assert(band_g0(17) == NGPT, "g-point table");
 
 template <bool FROMMASK>
 __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn m, GcmIn g, int ncol, int col0, int nct,
@@ -1382,6 +1402,34 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
             else if (liqflag == 1) { const double *t = absliq1 + 58 * (B - 1); al = t[index_l - 1] + fint_l * (t[index_l] - t[index_l - 1]); }
         }
         const double tband = FROMMASK ? g.taucld[(B - 1) + (size_t)NBND * cl] : 0.0;
+        if constexpr (FROMMASK) {
+            // every cloudy cell of this band and layer carries the same values (src/mcica_subcol_gen_lw.f90:664-680): one
+            // optical depth / emissivity per band; k_layer<..,3,..> and k_sweep<4,..> combine them with the mask bits
+            const unsigned long long lo = mw[g0 >> 5], hi = (g0 >> 5) < 4 ? mw[(g0 >> 5) + 1] : 0u;
+            const unsigned bits = (unsigned)(((lo | (hi << 32)) >> (g0 & 31)) & ((1ull << ng) - 1ull));
+            double t = tband, od = 0.0, ef = 0.0;
+            if (bits) {
+                if (mciwp + mclwp >= cldmin || t >= cldmin) {                                 // cldprmc :181-183 with cldfmc = 1
+                    if (inflag == 1) err = E_MC_INFLAG1;
+                    else if (inflag == 2) {
+                        double a_i = 0.0, a_l = 0.0;
+                        if (mciwp != 0.0 && iceflag >= 0 && iceflag <= 3) { a_i = ai; if (ice_err) err = ice_err; }
+                        if (mclwp != 0.0) {
+                            if (liqflag == 0) a_l = al;
+                            else if (liqflag == 1) { a_l = al; if (liq_err) err = liq_err; }
+                        }
+                        t = mciwp * a_i + mclwp * a_l;
+                    }
+                }
+                od = secdiff * t;                                                               // rtrnmc :311-317
+                ef = (double)(float)(1. - exp(-od));      // rounded as the array path stores it (cfef is float)
+                any = 1;
+            }
+            const size_t o = ((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col;
+            W.odcld[o] = od;
+            W.efcl[o] = ef;
+            continue;
+        }
 #pragma unroll 1
         for (int qi = 0; qi < (ng + 3) / 4; qi++, quad++) {
             double cf[4], tau[4], ci[4], cw[4];
@@ -1498,13 +1546,14 @@ __device__ __forceinline__ double overlap_rule(int icld, int l, double x, double
 
 constexpr int SUBCOL_BLOCK = 64;
 
-__global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn in, int ncol, int nlay, int icld, int permuteseed)
+// columns col0 .. col0 + nb - 1 of the call's ncol columns (ncol is the column stride of the inputs and of the mask)
+__global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn in, int ncol, int col0, int nb, int nlay, int icld, int permuteseed)
 {
 #pragma clang fp contract(off)
     extern __shared__ unsigned acc[];                           // [nlay][SUBCOL_BLOCK]
     const int tid = threadIdx.x;
-    const size_t gc = (size_t)blockIdx.x * SUBCOL_BLOCK + tid;
-    if (gc >= (size_t)ncol) return;
+    if (blockIdx.x * SUBCOL_BLOCK + tid >= nb) return;
+    const size_t gc = (size_t)col0 + (size_t)blockIdx.x * SUBCOL_BLOCK + tid;
     const double cldmin = 1.0e-20;
     Kiss s;
     {
@@ -1527,17 +1576,31 @@ __global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, Subco
             double r3 = 0.0;
             if (icld == 3) r3 = kiss_next(s);
             double prev = 0.0, cf_below = 0.0;
+            // layers in chunks of 8: the chunk's cloud fractions / overlap parameters are loaded together (independent of the
+            // serial random stream), then the eight dependent steps run from registers
 #pragma unroll 1
-            for (int l = 0; l < nlay; l++) {
-                double x, x2 = 0.0;
-                if (icld == 3) x = r3;
-                else { x = kiss_next(s); if (two) x2 = kiss_next(s); }
-                double cf = in.cldfrac[gc + (size_t)ncol * l];
-                if (cf < cldmin) cf = 0.0;
-                const double al = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
-                x = overlap_rule(icld, l, x, x2, prev, cf_below, al);
-                prev = x; cf_below = cf;
-                if (x >= 1. - cf) acc[l * SUBCOL_BLOCK + tid] |= 1u << k;               // :655-661
+            for (int l0 = 0; l0 < nlay; l0 += 8) {
+                double cfc[8], alc[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int l = l0 + i < nlay ? l0 + i : nlay - 1;
+                    cfc[i] = in.cldfrac[gc + (size_t)ncol * l];
+                    alc[i] = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int l = l0 + i;
+                    if (l < nlay) {
+                        double x, x2 = 0.0;
+                        if (icld == 3) x = r3;
+                        else { x = kiss_next(s); if (two) x2 = kiss_next(s); }
+                        double cf = cfc[i];
+                        if (cf < cldmin) cf = 0.0;
+                        x = overlap_rule(icld, l, x, x2, prev, cf_below, alc[i]);
+                        prev = x; cf_below = cf;
+                        if (x >= 1. - cf) acc[l * SUBCOL_BLOCK + tid] |= 1u << k;               // :655-661
+                    }
+                }
             }
         }
         for (int l = 0; l < nlay; l++) W.mask[((size_t)w * nlay + l) * W.mask_stride + gc] = acc[l * SUBCOL_BLOCK + tid];
@@ -1637,6 +1700,7 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 //   MODE 1 rtrn   (random overlap)                                 src/rrtmg_lw_rtrn.f90:361-540
 //   MODE 2 rtrnmr (maximum-random overlap)                         src/rrtmg_lw_rtrnmr.f90:531-738
 //   MODE 3 rtrnmc (McICA: cloud terms per g-point, k_cloudmc)      src/rrtmg_lw_rtrnmc.f90:331-520
+//   MODE 4 rtrnmc with the cloud terms given per band + the generator's sub-column mask
 // Writes the chunk's flux contribution (sum over its g-points x 0.5 x delwave, rtrn :549-562) per level.
 // ------------------------------------------------------------------------------------------------
 #ifndef RRLW_SWEEP_UNROLL
@@ -1720,6 +1784,16 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
         }
     };
 
+    // MODE 4: the four sub-column mask bits of this thread's quad in layer `lev` (bits of padding g-points cleared)
+    auto quad_bits = [&](int lev) -> unsigned {
+        const int ig0 = band_g0(B) + 4 * slot, w0 = ig0 >> 5;
+        const int nvalid = min(4, band_ng(B) - 4 * slot);
+        const size_t mo = (size_t)(lev - 1) * W.mask_stride + W.mask_col0 + gc;
+        const unsigned long long lo = W.mask[(size_t)w0 * nlay * W.mask_stride + mo];
+        const unsigned long long hi = (w0 < 4 && (ig0 & 31) > 28) ? W.mask[(size_t)(w0 + 1) * nlay * W.mask_stride + mo] : 0u;
+        return (unsigned)(((lo | (hi << 32)) >> (ig0 & 31)) & ((1u << nvalid) - 1u));
+    };
+
     bool colcloud = false;
     if constexpr (MODE != 0) { if (incol) colcloud = (W.cflag[col] & 8) != 0; }
 
@@ -1770,7 +1844,7 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
                 flags = cF[i];
                 cloudy = flags & 1;
                 if (cloudy) {
-                    if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
+                    if constexpr (MODE != 3 && MODE != 4) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
                     if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
                 }
             }
@@ -1807,11 +1881,17 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
                         cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
                         efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
                     }
+                    if constexpr (MODE == 4) {
+                        const unsigned bits = quad_bits(lev);
+                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
+#pragma unroll
+                        for (int j = 0; j < NGC; j++) { const bool on = (bits >> j) & 1u; cfj[j] = on ? 1.0 : 0.0; efj[j] = on ? ef : 0.0; }
+                    }
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
                         const double atr = vatr.v[j], bbd = vbbd.v[j], atot = vatot.v[j], bbdtot = vbbdt.v[j];
                         const double gassrc = bbd * atr;
-                        if constexpr (MODE == 1 || MODE == 3) {
+                        if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
                             radld[j] = radld[j] - radld[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbdtot * atot - gassrc);
                         } else {            // rtrnmr :591-615
                             if (flags & 4) {        // istcldd(lev) == 1
@@ -1903,7 +1983,7 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
                 flags = cF[i];
                 cloudy = flags & 1;
                 if (cloudy) {
-                    if constexpr (MODE != 3) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
+                    if constexpr (MODE != 3 && MODE != 4) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
                     if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
                 }
             }
@@ -1945,11 +2025,17 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
                         cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
                         efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
                     }
+                    if constexpr (MODE == 4) {
+                        const unsigned bits = quad_bits(lev);
+                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
+#pragma unroll
+                        for (int j = 0; j < NGC; j++) { const bool on = (bits >> j) & 1u; cfj[j] = on ? 1.0 : 0.0; efj[j] = on ? ef : 0.0; }
+                    }
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
                         const double atr = vatr.v[j], bbu = vbbu.v[j], atot = vatot.v[j], bbutot = vbbut.v[j];
                         const double gassrc = bbu * atr;
-                        if constexpr (MODE == 1 || MODE == 3) {
+                        if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
                             radlu[j] = radlu[j] - radlu[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbutot * atot - gassrc);
                         } else {            // rtrnmr :680-703
                             if (flags & 2) {        // istcld(lev) == 1
