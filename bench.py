@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--cpu-cols-per-core", type=int, default=6000)
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N > 1)")
     ap.add_argument("--check", action="store_true", help="compare 256 columns with the CPU oracle before timing")
+    ap.add_argument("--host-cols", type=int, default=131072,
+                    help="columns of the end-to-end (host-pointer, PCIe-inclusive) measurement after the timed region; 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,16 +123,16 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     alpha = None
     if args.mcica:
-        # overlap parameter of get_alpha for a constant 2 km decorrelation length and hydrostatic layer depths
-        z = 7000.0 * torch.log(d["plev"][:, :1] / d["plev"])                       # (ncol, nlay+1), column-fastest
-        dz = z[:, 1:] - z[:, :-1]
-        a = torch.exp(-0.5 * (dz[:, 1:] + dz[:, :-1]) / 2000.0)
+        # get_alpha's overlap parameter (src/mcica_subcol_gen_lw.f90:160-166) for idcor = 0, decorr_con = 2500 m, layer depths
+        # from the hypsometric equation; computed with torch because it is an INPUT of the timed call
+        dz = 29.2717 * d["tlay"] * torch.log(d["plev"][:, :-1] / d["plev"][:, 1:])        # R_d / g = 29.27 m K-1
+        a = torch.exp(-0.5 * (dz[:, 1:] + dz[:, :-1]) / 2500.0)
         alpha = torch.cat([torch.zeros_like(a[:, :1]), a], dim=1).t().contiguous().t()
-        del z, dz, a
+        del dz, a
 
     def step():
         if args.mcica:
-            api.rrtmg_lw_mcica_subcol_device(d, out, 140, 0, alpha=alpha, icld=args.mcica, stream=stream)
+            api.rrtmg_lw_mcica_subcol_device(d, out, 1, 0, alpha=alpha, icld=args.mcica, stream=stream)
         else:
             api.rrtmg_lw_device(d, out, stream=stream)
         if do_gather:
@@ -146,7 +148,7 @@ def main():
         orc = Oracle(kdata=api.default_kdata())
         if args.mcica:
             al = np.asfortranarray(alpha[:n].cpu().numpy())
-            sub = orc.mcica_subcol(n, nlay, args.mcica, 140, 0, dn["play"], dn["cldfr"], dn["cicewp"], dn["cliqwp"], dn["reice"],
+            sub = orc.mcica_subcol(n, nlay, args.mcica, 1, 0, dn["play"], dn["cldfr"], dn["cicewp"], dn["cliqwp"], dn["reice"],
                                    dn["reliq"], dn["taucld"], al)
             dn.update({k: sub[k] for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")})
         ref = orc.rrtmg_lw(n, nlay, args.mcica or dn["icld"], dn["idrv"], dn, mcica=bool(args.mcica))
@@ -177,6 +179,24 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- end to end through the host-pointer entry (what the Fortran shim calls): pageable host arrays in, H2D staging,
+    # kernels, D2H, host arrays out.  Reported beside `value`, never as `value`.
+    e2e = None
+    if rank == 0 and world == 1 and args.host_cols > 0 and not args.mcica:
+        nh = min(args.host_cols, args.ncol)
+        dh = make_gcm_inputs(nh, nlay, args.config, col0=col0)
+        api.rrtmg_lw_from_dict(dh)                       # warm-up: staging buffers
+        t1 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            api.rrtmg_lw_from_dict(dh)
+        th = (time.perf_counter() - t1) / reps
+        hbytes = algo_bytes_per_col(nlay, idrv) * nh
+        e2e = dict(value=round(nh / th, 1), unit="columns/s", columns=nh, ms=round(1e3 * th, 2),
+                   host_GBps=round(hbytes / th / 1e9, 2),
+                   note="rrtmg_lw_hip_run_nomcica with pageable numpy arrays: H2D staging + kernels + D2H, synchronous per batch")
+        del dh
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -228,7 +248,7 @@ def main():
                                ncol_total=args.ncol, nlay=nlay, columns_per_gpu=per, parallelism=f"columns/{world}",
                                gather="rccl all_gather" if do_gather else "none",
                                kdata="stand-in (real k-data absent from the reference mount)" if api.kdata_is_standin() else "real"),
-                   roofline=roof, path=path, cpu_baseline=cpu)
+                   roofline=roof, path=path, cpu_baseline=cpu, end_to_end=e2e)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -32,7 +32,7 @@ def short_name(k):
     m = re.match(r"(k_colprep|k_cloud)<\w+>", k)
     if m:
         return m.group(1)
-    return k
+    return k.replace(", ", ",")
 
 
 def load(dirname):
