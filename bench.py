@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols-per-core", type=int, default=6000)
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N > 1)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="initialise RCCL and run the all-gather even with one rank (plumbing check under torchrun with N = 1)")
     ap.add_argument("--check", action="store_true", help="compare 256 columns with the CPU oracle before timing")
     ap.add_argument("--host-cols", type=int, default=131072,
                     help="columns of the end-to-end (host-pointer, PCIe-inclusive) measurement after the timed region; 0 = skip")
@@ -80,7 +82,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the solver has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or (args.force_gather and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -111,12 +114,15 @@ def main():
 
     # packed output block: rows = uflx, dflx, uflxc, dflxc, duflx_dt, duflxc_dt (nlay+1 each), hr, hrc (nlay each)
     rows = output_rows(nlay)
-    outbuf = torch.zeros((rows, ncol), dtype=torch.float64, device=dev)
-    out = output_views(outbuf, nlay)
-    gathered = None
-    do_gather = world > 1 and not args.no_gather
+    # two output blocks: the all-gather of step k (RCCL's own stream) overlaps the kernels of step k+1
+    outbufs = [torch.zeros((rows, ncol), dtype=torch.float64, device=dev) for _ in range(2)]
+    outs = [output_views(b, nlay) for b in outbufs]
+    outbuf, out = outbufs[0], outs[0]
+    gathered = [None, None]
+    pending = [None, None]
+    do_gather = use_dist and not args.no_gather
     if do_gather:
-        gathered = torch.empty((world * rows, per), dtype=torch.float64, device=dev)   # rank-major concatenation
+        gathered = [torch.empty((world * rows, per), dtype=torch.float64, device=dev) for _ in range(2)]   # rank-major concatenation
         if ncol != per:
             raise SystemExit("--ncol must be divisible by --gpus for the all-gather")
 
@@ -130,18 +136,33 @@ def main():
         alpha = torch.cat([torch.zeros_like(a[:, :1]), a], dim=1).t().contiguous().t()
         del dz, a
 
+    step_no = [0]
+
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if pending[k] is not None:          # the gather that last read this output block must be done before it is overwritten
+            pending[k].wait()
+            pending[k] = None
         if args.mcica:
-            api.rrtmg_lw_mcica_subcol_device(d, out, 1, 0, alpha=alpha, icld=args.mcica, stream=stream)
+            api.rrtmg_lw_mcica_subcol_device(d, outs[k], 1, 0, alpha=alpha, icld=args.mcica, stream=stream)
         else:
-            api.rrtmg_lw_device(d, out, stream=stream)
+            api.rrtmg_lw_device(d, outs[k], stream=stream)
         if do_gather:
-            dist.all_gather_into_tensor(gathered, outbuf)
+            pending[k] = dist.all_gather_into_tensor(gathered[k], outbufs[k], async_op=True)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     if args.check and rank == 0:
         import numpy as np
         from oracle.bindings import Oracle
+        step_no[0] = 0
         step()
+        drain()
         api.check(stream)
         n = min(256, ncol)
         dn = make_gcm_inputs(n, nlay, args.config, col0=col0)
@@ -158,10 +179,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     api.check(stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,11 +193,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                  # every all-gather of the timed steps completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     api.lib().rrtmg_lw_hip_profile_end(buf, len(buf))
     api.check(stream)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -246,11 +269,11 @@ def main():
                                            f"(icld={d['icld']}: {'rtrnmr max-random overlap' if d['icld'] == 2 else 'clear'}, idrv={idrv}), ") +
                                         f"sharded {world}x{per}",
                                ncol_total=args.ncol, nlay=nlay, columns_per_gpu=per, parallelism=f"columns/{world}",
-                               gather="rccl all_gather" if do_gather else "none",
+                               gather="rccl all_gather_into_tensor of the packed outputs, overlapped with the next step's kernels" if do_gather else "none",
                                kdata="stand-in (real k-data absent from the reference mount)" if api.kdata_is_standin() else "real"),
                    roofline=roof, path=path, cpu_baseline=cpu, end_to_end=e2e)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     api.finalize()
 
