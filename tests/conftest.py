@@ -22,6 +22,9 @@ def oracle():
 @pytest.fixture(scope="session")
 def hip():
     """The product library, initialised on cuda:0 with the stand-in k-data.  Fails loudly if it is not built."""
+    # tests that hand torch tensors to the device entries need ONE HIP runtime in the process: torch bundles its own
+    # libamdhip64, so it has to be loaded before librrtmg_lw_hip.so pulls in the system one (bench.py does the same)
+    import torch  # noqa: F401
     from rrtmg_lw_amd import api
     api.rrtmg_lw_ini(1004.0, kdata=api.STANDIN_KDATA, device=0)
     yield api

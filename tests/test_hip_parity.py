@@ -112,3 +112,71 @@ def test_prepared_column_entry(hip, oracle):
         for k in ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc"):
             assert np.abs(got[k][0] - ref[k]).max() <= TIGHT_FLUX, (k, istart)
             assert np.array_equal(got[k][0], got[k][1])
+
+
+@pytest.mark.parametrize("ncol,nlay", [(1, 72), (63, 51), (65, 72), (257, 33), (3, 4), (5, 200)])
+def test_ragged_and_extreme_shapes(hip, oracle, ncol, nlay):
+    """Single column, column counts that are not multiples of a wave / workgroup, four layers (the kissvec minimum) and
+    more layers than any reference example (the reference's static arrays stop at mxlay = 203, parrrtm.f90)."""
+    d = make_gcm_inputs(ncol, nlay, "cloudy" if nlay > 8 else "clear", col0=17)
+    for icld in (1, 2):
+        got = hip.rrtmg_lw_from_dict(d, icld=icld)
+        ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+        _compare(got, ref, d["idrv"], f"ncol={ncol} nlay={nlay} icld={icld}")
+
+
+def test_device_entry_with_caller_stream(hip, oracle):
+    """Device-pointer entry: inputs and outputs are torch tensors in HBM, work is enqueued on the caller's stream and
+    spans several internal batches (two-stream pipeline of the driver)."""
+    import torch
+    from rrtmg_lw_amd.shard import output_rows, output_views
+    ncol, nlay = 1500, 72
+    dev = torch.device("cuda", 0)
+    d = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=9, backend="torch", device=dev)
+    outbuf = torch.full((output_rows(nlay), ncol), float("nan"), dtype=torch.float64, device=dev)
+    out = output_views(outbuf, nlay)
+    hip.set_batch(256)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            hip.rrtmg_lw_device(d, out, stream=side.cuda_stream)
+            hip.rrtmg_lw_device(d, out, stream=side.cuda_stream)        # back to back: prep sets are reused safely
+        hip.check(side.cuda_stream)
+    finally:
+        hip.set_batch(32768)
+    dn = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=9)
+    ref = oracle.rrtmg_lw(ncol, nlay, dn["icld"], dn["idrv"], dn)
+    got = {k: out[k].T.cpu().numpy() for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")}
+    got["icld"] = ref["icld"]
+    _compare(got, ref, dn["idrv"], "device entry, 6 batches")
+
+
+def test_calls_from_several_threads(hip, oracle):
+    """Entry points are serialised by a process-wide lock (SURVEY.md 8b threading): concurrent callers get correct results."""
+    import threading
+    ds = [make_gcm_inputs(200, 40, "cloudy", col0=100 * k) for k in range(4)]
+    res = [None] * 4
+
+    def work(k):
+        res[k] = hip.rrtmg_lw_from_dict(ds[k])
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for k in range(4):
+        ref = oracle.rrtmg_lw(200, 40, ds[k]["icld"], ds[k]["idrv"], ds[k])
+        _compare(res[k], ref, ds[k]["idrv"], f"thread {k}")
+
+
+def test_reinitialisation(hip, oracle):
+    """rrtmg_lw_ini may be called again (e.g. another cpdair): heating rates scale with 1/cpdair, fluxes do not change."""
+    d = make_gcm_inputs(64, 40, "clear")
+    a = hip.rrtmg_lw_from_dict(d)
+    hip.rrtmg_lw_ini(1003.5, kdata=hip.STANDIN_KDATA, device=0)
+    b = hip.rrtmg_lw_from_dict(d)
+    hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+    assert np.array_equal(a["uflx"], b["uflx"])
+    np.testing.assert_allclose(b["hr"] * 1003.5, a["hr"] * 1004.0, rtol=1e-12, atol=1e-12)
