@@ -9,12 +9,15 @@
 //              terms                                                    1 thread / column
 //   k_cloud    cldprop + cloud-overlap factors of rtrnmr (serial in the vertical)
 //                                                                       1 thread / column
-//   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for all 16 bands / 140 g-points,
+//   k_cloudmc  cldprmc + the cloud set-up of rtrnmc (McICA)             1 thread / (column, layer)
+//   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for the bands of one group,
 //              then each cell's transmittance and Planck sources (the exp/LUT part of rtrn)
 //                                                                       1 thread / (column, layer)
-//   k_sweep    the only vertically serial part: the down/up recurrences of rtrn / rtrnmr, streaming the
-//              per-cell terms written by k_layer                        1 thread / (column, g-chunk)
-//   k_final    band-chunk partial fluxes -> fluxes, net flux, heating rates   1 thread / column
+//   k_sweep    the only vertically serial part: the down/up recurrences of rtrn / rtrnmr / rtrnmc, streaming
+//              the per-cell terms written by k_layer; workgroup = 64 columns x the quads of one band,
+//              flux partials reduced over the band in LDS                 1 thread / (column, quad)
+//   k_flux     band slabs -> fluxes;  k_rates  net flux -> heating rates   1 thread / (column, level)
+//   k_subcol_* McICA sub-column generator (bit masks), k_alpha           see the section below
 //
 // Reference lines are cited per routine.  No CPU fallback exists anywhere in this file.
 #include <hip/hip_runtime.h>
@@ -113,6 +116,24 @@ enum ErrCode { E_NONE = 0, E_ICE_SMALL = 1, E_ICE_BOUNDS = 2, E_ICE_GEN_BOUNDS =
                E_MC_INFLAG1 = 6, E_KISS_PMID = 7 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// a / b for normal, finite operands in k_layer: hardware reciprocal seed, two Newton steps, one residual correction (8 VALU
+// operations in one dependency chain instead of the ~13 of the IEEE sequence with its scale / fix-up steps; a third of
+// k_layer's VALU instructions were divisions).  The quotient is within an ulp of the correctly rounded one; where it feeds
+// an index (`int(...)`, the 1e-4-quantised transmittance table) a different index needs the exact quotient to sit within
+// ~1e-16 of a boundary.  -DRRLW_EXACT_DIV restores the IEEE division.
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+#ifdef RRLW_EXACT_DIV
+    return a / b;
+#else
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_colprep : the per-column reductions of inatm (src/rrtmg_lw_rad.nomcica.f90:785-870: amttl, wvttl ->
@@ -579,7 +600,7 @@ __device__ __forceinline__ Spec spec_calc(double cola, double rat, double colb, 
 {
     Spec s;                                         // taumol :523-528
     s.speccomb = cola + rat * colb;
-    s.specparm = cola / s.speccomb;
+    s.specparm = fdiv(cola, s.speccomb);
     if (s.specparm >= oneminus) s.specparm = oneminus;
     const double specmult = mult * s.specparm;
     s.js = 1 + (int)specmult;
@@ -686,8 +707,8 @@ __device__ __forceinline__ void rows_prep_minor(const DevTables &T, const LayerC
     else {                                              // A_ADJ: taumol :547-554
         const double colx = C.f[F_COLH2O + M.sp], coldry = C.f[F_COLDRY];
         const double chiref = M.chiconst > 0. ? M.chiconst : (T.stat + T.sl.chi)[M.sp * 59 + C.jp];     // chi_mls(sp+1, jp+1)
-        const double chi = colx / coldry;
-        const double ratx = 1.e20 * chi / chiref;
+        const double chi = fdiv(colx, coldry);
+        const double ratx = fdiv(1.e20 * chi, chiref);
         amount = colx;
         if (ratx > M.thr) amount = (M.base + pow(ratx - M.base, M.expo)) * chiref * coldry * 1.e-20;
     }
@@ -926,7 +947,7 @@ struct LayerArgs {
 struct alignas(16) scr4 { scr_t v[4]; };
 
 // transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
-__device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * (od / (bpade + od)) + 0.5); }
+__device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * fdiv(od, bpade + od) + 0.5); }
 
 // all cells (g-points) of band B of one (layer, column).
 // CLOUD: 0 clear-sky set, 1 one cloud optical depth per band (rtrn / rtrnmr), 2 one per g-point from W.odg (rtrnmc, sub-column
@@ -1217,7 +1238,7 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
         w1 = g.h2ovmr[gi]; w2 = g.co2vmr[gi]; w3 = g.o3vmr[gi]; w4 = g.n2ovmr[gi];
         w5 = 0.0; w6 = g.ch4vmr[gi]; w7 = g.o2vmr[gi];
         const double amm = (1. - w1) * amd + w1 * amw;
-        coldry = (pz_lo - pz_hi) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + w1));
+        coldry = fdiv((pz_lo - pz_hi) * 1.e3 * avogad, 1.e2 * grav * amm * (1. + w1));
         double summol = 0.0;
         summol = summol + w2; summol = summol + w3; summol = summol + w4;
         summol = summol + w5; summol = summol + w6; summol = summol + w7;
@@ -1256,35 +1277,36 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
     const double plog = log(pavel);
     const int jp = clampi((int)(36. - 5 * (plog + 0.04)), 1, 58);
     const double fp = 5. * (preflog[jp - 1] - plog);
-    const int jt = clampi((int)(3. + (tavel - tref[jp - 1]) / 15.), 1, 4);
-    const double ft = ((tavel - tref[jp - 1]) / 15.) - (double)(jt - 3);
-    const int jt1 = clampi((int)(3. + (tavel - tref[jp]) / 15.), 1, 4);
-    const double ft1 = ((tavel - tref[jp]) / 15.) - (double)(jt1 - 3);
-    const double water = w1 / coldry;
-    const double scalefac = pavel * stpfac / tavel;
+    const double dt0 = fdiv(tavel - tref[jp - 1], 15.), dt1 = fdiv(tavel - tref[jp], 15.);
+    const int jt = clampi((int)(3. + dt0), 1, 4);
+    const double ft = dt0 - (double)(jt - 3);
+    const int jt1 = clampi((int)(3. + dt1), 1, 4);
+    const double ft1 = dt1 - (double)(jt1 - 3);
+    const double water = fdiv(w1, coldry);
+    const double scalefac = fdiv(pavel * stpfac, tavel);
     int indself = 1, indfor, indminor;
     double forfac, forfrac, selffac, selffrac = 0.0, factor;
     if (!(plog <= 4.56)) {            // :312-334
-        forfac = scalefac / (1. + water);
-        factor = (332.0 - tavel) / 36.0;
+        forfac = fdiv(scalefac, 1. + water);
+        factor = fdiv(332.0 - tavel, 36.0);
         indfor = min(2, max(1, (int)factor));
         forfrac = factor - (double)indfor;
         selffac = water * forfac;
-        factor = (tavel - 188.0) / 7.2;
+        factor = fdiv(tavel - 188.0, 7.2);
         indself = min(9, max(1, (int)factor - 7));
         selffrac = factor - (double)(indself + 7);
     } else {                          // :369-377
-        forfac = scalefac / (1. + water);
-        factor = (tavel - 188.0) / 36.0;
+        forfac = fdiv(scalefac, 1. + water);
+        factor = fdiv(tavel - 188.0, 36.0);
         indfor = 3;
         forfrac = factor - 1.0;
         selffac = water * forfac;
     }
-    factor = (tavel - 180.8) / 7.2;
+    factor = fdiv(tavel - 180.8, 7.2);
     indminor = min(18, max(1, (int)factor));
     C.f[F_MINORFRAC] = factor - (double)indminor;
-    C.f[F_SCALEMINOR] = pavel / tavel;
-    C.f[F_SCALEMINORN2] = (pavel / tavel) * (wbrodl / (coldry + w1));
+    C.f[F_SCALEMINOR] = fdiv(pavel, tavel);
+    C.f[F_SCALEMINORN2] = C.f[F_SCALEMINOR] * fdiv(wbrodl, coldry + w1);
     double colh2o = 1.e-20 * w1, colco2 = 1.e-20 * w2, colo3 = 1.e-20 * w3, coln2o = 1.e-20 * w4;
     double colco = 1.e-20 * w5, colch4 = 1.e-20 * w6, colo2 = 1.e-20 * w7;
     if (colco2 == 0.) colco2 = 1.e-32 * coldry;
