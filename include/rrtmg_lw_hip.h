@@ -100,6 +100,21 @@ int rrtmg_lw_hip_run_columns(
     double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
     double *dtotuflux_dt, double *dtotuclfl_dt);
 
+/* McICA flavour of the prepared-column entry (HOST pointers): one Monte-Carlo sample of the column driver with imca = 1,
+ * cldprmc -> setcoef -> taumol -> rtrnmc (src/rrtmg_lw.1col.f90:471-580), for `ncol` (column, sample) pairs.  Arrays as for
+ * rrtmg_lw_hip_run_columns, the cloud arguments replaced by the sub-columns cldfmc, taucmc, ciwpmc, clwpmc (140,ncol,nlayers)
+ * and reicmc, relqmc (ncol,nlayers).  The driver's result is the mean over its nmca = 200 samples, sample `ims` being generated
+ * with permuteseed = ims * 140 (src/mcica_subcol_gen_lw.1col.f90:248-251). */
+int rrtmg_lw_hip_run_columns_mcica(
+    int ncol, int nlayers, int istart, int iend, int icld, int idrv,
+    const double *pavel, const double *tavel, const double *pz, const double *tz, const double *tbound,
+    const double *semiss, const double *coldry, const double *wkl, const double *wbrodl, const double *wx,
+    const double *pwvcm, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *taucmc,
+    const double *ciwpmc, const double *clwpmc, const double *reicmc, const double *relqmc, const double *taua,
+    double *totuflux, double *totdflux, double *fnet, double *htr,
+    double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
+    double *dtotuflux_dt, double *dtotuclfl_dt);
+
 /* McICA flavour ---------------------------------------------------------------------------------- */
 /* rrtmg_lw, McICA  -  reference: src/rrtmg_lw_rad.f90:99-594 (cldprmc src/rrtmg_lw_cldprmc.f90:49, rtrnmc
  * src/rrtmg_lw_rtrnmc.f90:51).  HOST pointers; same contract as rrtmg_lw_hip_run_nomcica with the cloud

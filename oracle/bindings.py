@@ -87,6 +87,33 @@ def _column_call(fn, col, istart, iend, iout, icld, idrv, byref_scalars):
     return rc, res
 
 
+def _column_mc_call(fn, col, sub, istart, iend, iout, icld, idrv):
+    """Prepared column + one set of sub-columns (cldfmc, taucmc, ciwpmc, clwpmc (140,nlayers); reicmc, relqmc (nlayers))."""
+    nl = int(col["nlayers"])
+    z = lambda *s: np.zeros(s, order="F")
+    outs = [z(nl + 1) for _ in range(10)]
+    taug, fracs = z(nl, NGPT), z(nl, NGPT)
+    ncb = C.c_int(0)
+    a = dict(pavel=_f(col["pavel"], (nl,)), tavel=_f(col["tavel"], (nl,)), pz=_f(col["pz"], (nl + 1,)),
+             tz=_f(col["tz"], (nl + 1,)), semiss=_f(col["semiss"], (NBND,)), coldry=_f(col["coldry"], (nl,)),
+             wkl=_f(col["wkl"], (7, nl)), wbrodl=_f(col["wbrodl"], (nl,)), wx=_f(col["wx"], (4, nl)),
+             cldfmc=_f(sub["cldfmc"], (NGPT, nl)), taucmc=_f(sub["taucmc"], (NGPT, nl)), ciwpmc=_f(sub["ciwpmc"], (NGPT, nl)),
+             clwpmc=_f(sub["clwpmc"], (NGPT, nl)), reicmc=_f(sub["reicmc"], (nl,)), relqmc=_f(sub["relqmc"], (nl,)),
+             taua=_f(col["tauaer"], (nl, NBND)))
+    args = [C.c_int(nl), C.c_int(istart), C.c_int(iend), C.c_int(iout), C.c_int(icld), C.c_int(idrv),
+            _p(a["pavel"]), _p(a["tavel"]), _p(a["pz"]), _p(a["tz"]), C.c_double(float(col["tbound"])),
+            _p(a["semiss"]), _p(a["coldry"]), _p(a["wkl"]), _p(a["wbrodl"]), _p(a["wx"]),
+            C.c_double(float(col["pwvcm"])), C.c_int(int(col["inflag"])), C.c_int(int(col["iceflag"])),
+            C.c_int(int(col["liqflag"])), _p(a["cldfmc"]), _p(a["taucmc"]), _p(a["ciwpmc"]), _p(a["clwpmc"]),
+            _p(a["reicmc"]), _p(a["relqmc"]), _p(a["taua"])]
+    args += [_p(o) for o in outs] + [_p(taug), _p(fracs), C.byref(ncb)]
+    rc = fn(*args)
+    names = ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc", "dtotuflux_dt", "dtotuclfl_dt")
+    res = dict(zip(names, outs))
+    res.update(taug=taug, fracs=fracs, ncbands=ncb.value)
+    return rc, res
+
+
 class Oracle:
     """The plain-C restatement (oracle/rrtmg_lw_oracle.c)."""
 
@@ -115,6 +142,15 @@ class Oracle:
         icld = int(col["icld"]) if icld is None else icld
         idrv = int(col["idrv"]) if idrv is None else idrv
         rc, res = _column_call(self.lib.orc_column, col, istart, iend, iout, icld, idrv, False)
+        if rc != 0:
+            raise RuntimeError(f"oracle: {self.errmsg()}")
+        return res
+
+    def column_mc(self, col, sub, istart=1, iend=16, iout=0, icld=None, idrv=None):
+        """One McICA sample of the column driver: cldprmc -> setcoef -> taumol -> rtrnmc on the given sub-columns."""
+        icld = int(col["icld"]) if icld is None else icld
+        idrv = int(col["idrv"]) if idrv is None else idrv
+        rc, res = _column_mc_call(self.lib.orc_column_mc, col, sub, istart, iend, iout, icld, idrv)
         if rc != 0:
             raise RuntimeError(f"oracle: {self.errmsg()}")
         return res
@@ -185,6 +221,12 @@ class Reference:
         icld = int(col["icld"]) if icld is None else icld
         idrv = int(col["idrv"]) if idrv is None else idrv
         _, res = _column_call(self.lib.ref_column, col, istart, iend, iout, icld, idrv, True)
+        return res
+
+    def column_mc(self, col, sub, istart=1, iend=16, iout=0, icld=None, idrv=None):
+        icld = int(col["icld"]) if icld is None else icld
+        idrv = int(col["idrv"]) if idrv is None else idrv
+        _, res = _column_mc_call(self.lib.ref_column_mc, col, sub, istart, iend, iout, icld, idrv)
         return res
 
     def get_alpha_1col(self, nlay, icld, idcor, decorr_con, dz, lat, juldat, cldfrac):

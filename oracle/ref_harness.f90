@@ -202,6 +202,97 @@ contains
     fracs_out = fracs
     ncbands_out = ncbands
   end subroutine ref_column
+#else
+  ! McICA flavour of the prepared-column entry: cldprmc -> setcoef -> taumol -> rtrnmc (src/rrtmg_lw.1col.f90:497-580, imca = 1)
+  subroutine ref_column_mc(nlayers, istart, iend, iout, icld, idrv, &
+       pavel, tavel, pz, tz, tbound, semiss, coldry, wkl7, wbrodl, wx4, pwvcm, &
+       inflag, iceflag, liqflag, cldfmc, taucmc_in, ciwpmc, clwpmc, reicmc, relqmc, taua, &
+       totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, &
+       dtotuflux_dt, dtotuclfl_dt, taug_out, fracs_out, ncbands_out) bind(C, name='ref_column_mc')
+    use rrlw_con, only: fluxfac, oneminus, pi
+    use rrlw_wvn, only: ngb
+    use rrtmg_lw_cldprmc, only: cldprmc
+    use rrtmg_lw_setcoef, only: setcoef
+    use rrtmg_lw_taumol, only: taumol
+    use rrtmg_lw_rtrnmc, only: rtrnmc
+    integer(c_int), value :: nlayers, istart, iend, iout, icld, idrv, inflag, iceflag, liqflag
+    real(c_double), intent(in) :: pavel(nlayers), tavel(nlayers), pz(0:nlayers), tz(0:nlayers)
+    real(c_double), value :: tbound, pwvcm
+    real(c_double), intent(in) :: semiss(nbndlw), coldry(nlayers), wkl7(7,nlayers), wbrodl(nlayers), wx4(4,nlayers)
+    real(c_double), intent(in) :: cldfmc(ngptlw,nlayers), taucmc_in(ngptlw,nlayers), ciwpmc(ngptlw,nlayers), clwpmc(ngptlw,nlayers)
+    real(c_double), intent(in) :: reicmc(nlayers), relqmc(nlayers), taua(nlayers,nbndlw)
+    real(c_double), intent(out) :: totuflux(0:nlayers), totdflux(0:nlayers), fnet(0:nlayers), htr(0:nlayers)
+    real(c_double), intent(out) :: totuclfl(0:nlayers), totdclfl(0:nlayers), fnetc(0:nlayers), htrc(0:nlayers)
+    real(c_double), intent(out) :: dtotuflux_dt(0:nlayers), dtotuclfl_dt(0:nlayers)
+    real(c_double), intent(out) :: taug_out(nlayers,ngptlw), fracs_out(nlayers,ngptlw)
+    integer(c_int), intent(out) :: ncbands_out
+
+    integer(im) :: nl, ncbands, laytrop, k, ig
+    integer(im) :: jp(nlayers), jt(nlayers), jt1(nlayers), indself(nlayers), indfor(nlayers), indminor(nlayers)
+    real(rb) :: wkl(mxmol,nlayers), wx(maxxsec,nlayers)
+    real(rb) :: taucmc(ngptlw,nlayers), planklay(nlayers,nbndlw), planklev(0:nlayers,nbndlw)
+    real(rb) :: plankbnd(nbndlw), dplankbnd_dt(nbndlw)
+    real(rb), dimension(nlayers) :: colh2o, colco2, colo3, coln2o, colco, colch4, colo2, colbrd
+    real(rb), dimension(nlayers) :: fac00, fac01, fac10, fac11
+    real(rb), dimension(nlayers) :: rat_h2oco2, rat_h2oco2_1, rat_h2oo3, rat_h2oo3_1, rat_h2on2o, rat_h2on2o_1
+    real(rb), dimension(nlayers) :: rat_h2och4, rat_h2och4_1, rat_n2oco2, rat_n2oco2_1, rat_o3co2, rat_o3co2_1
+    real(rb), dimension(nlayers) :: selffac, selffrac, forfac, forfrac, minorfrac, scaleminor, scaleminorn2
+    real(rb) :: fracs(nlayers,ngptlw), taug(nlayers,ngptlw), taut(nlayers,ngptlw)
+    real(rb) :: tb, pw
+
+    nl = nlayers
+    oneminus = 1._rb - 1.e-6_rb
+    pi = 2._rb * asin(1._rb)
+    fluxfac = pi * 2.e4_rb
+    wkl = 0._rb
+    wkl(1:7,:) = wkl7
+    wx = 0._rb
+    wx(1:4,:) = wx4
+    tb = tbound
+    pw = pwvcm
+    dplankbnd_dt = 0._rb
+    dtotuflux_dt = 0._rb
+    dtotuclfl_dt = 0._rb
+
+    taucmc = taucmc_in
+    call cldprmc(nl, int(inflag,im), int(iceflag,im), int(liqflag,im), cldfmc, ciwpmc, &
+                 clwpmc, reicmc, relqmc, ncbands, taucmc)
+    call setcoef(nl, int(istart,im), pavel, tavel, tz, tb, semiss, &
+                 coldry, wkl, wbrodl, &
+                 laytrop, jp, jt, jt1, planklay, planklev, plankbnd, &
+                 int(idrv,im), dplankbnd_dt, &
+                 colh2o, colco2, colo3, coln2o, colco, colch4, colo2, &
+                 colbrd, fac00, fac01, fac10, fac11, &
+                 rat_h2oco2, rat_h2oco2_1, rat_h2oo3, rat_h2oo3_1, &
+                 rat_h2on2o, rat_h2on2o_1, rat_h2och4, rat_h2och4_1, &
+                 rat_n2oco2, rat_n2oco2_1, rat_o3co2, rat_o3co2_1, &
+                 selffac, selffrac, indself, forfac, forfrac, indfor, &
+                 minorfrac, scaleminor, scaleminorn2, indminor)
+    call taumol(nl, pavel, wx, coldry, &
+                laytrop, jp, jt, jt1, planklay, planklev, plankbnd, &
+                colh2o, colco2, colo3, coln2o, colco, colch4, colo2, &
+                colbrd, fac00, fac01, fac10, fac11, &
+                rat_h2oco2, rat_h2oco2_1, rat_h2oo3, rat_h2oo3_1, &
+                rat_h2on2o, rat_h2on2o_1, rat_h2och4, rat_h2och4_1, &
+                rat_n2oco2, rat_n2oco2_1, rat_o3co2, rat_o3co2_1, &
+                selffac, selffrac, indself, forfac, forfrac, indfor, &
+                minorfrac, scaleminor, scaleminorn2, indminor, &
+                fracs, taug)
+    do k = 1, nl
+       do ig = 1, ngptlw
+          taut(k,ig) = taug(k,ig) + taua(k,ngb(ig))
+       enddo
+    enddo
+    call rtrnmc(nl, int(istart,im), int(iend,im), int(iout,im), pz, semiss, ncbands, &
+                cldfmc, taucmc, planklay, planklev, plankbnd, &
+                pw, fracs, taut, &
+                totuflux, totdflux, fnet, htr, &
+                totuclfl, totdclfl, fnetc, htrc, &
+                int(idrv,im), dplankbnd_dt, dtotuflux_dt, dtotuclfl_dt)
+    taug_out = taug
+    fracs_out = fracs
+    ncbands_out = ncbands
+  end subroutine ref_column_mc
 #endif
 
 

@@ -2151,6 +2151,61 @@ int orc_column(int nlayers, int istart, int iend, int iout, int icld, int idrv,
     return 0;
 }
 
+/* McICA flavour of the prepared-column entry: cldprmc -> setcoef -> taumol -> rtrnmc, the per-sample physics sequence of the
+ * column driver with imca = 1 (src/rrtmg_lw.1col.f90:497-580).  cldfmc, taucmc, ciwpmc, clwpmc are (140,nlayers). */
+int orc_column_mc(int nlayers, int istart, int iend, int iout, int icld, int idrv,
+                  const double *pavel, const double *tavel, const double *pz, const double *tz, double tbound,
+                  const double *semiss, const double *coldry, const double *wkl7, const double *wbrodl, const double *wx4,
+                  double pwvcm, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *taucmc,
+                  const double *ciwpmc, const double *clwpmc, const double *reicmc, const double *relqmc, const double *taua,
+                  double *totuflux, double *totdflux, double *fnet, double *htr,
+                  double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
+                  double *dtotuflux_dt, double *dtotuclfl_dt, double *taug_out, double *fracs_out, int *ncbands_out)
+{
+    (void)icld;
+    if (ensure_col()) return -1;
+    col_t *c = C;
+    int nl = nlayers;
+    c->nlayers = nl;
+    c->tbound = tbound;
+    c->pwvcm = pwvcm;
+    c->inflag = inflag; c->iceflag = iceflag; c->liqflag = liqflag;
+    for (int b = 1; b <= NBND; b++) c->semiss[b] = semiss[b - 1];
+    for (int l = 0; l <= nl; l++) { c->pz[l] = pz[l]; c->tz[l] = tz[l]; }
+    for (int l = 1; l <= nl; l++) {
+        c->pavel[l] = pavel[l - 1]; c->tavel[l] = tavel[l - 1];
+        c->coldry[l] = coldry[l - 1]; c->wbrodl[l] = wbrodl[l - 1];
+        for (int m = 1; m <= 7; m++) c->wkl[l][m] = wkl7[(m - 1) + 7 * (l - 1)];
+        for (int m = 1; m <= 4; m++) c->wx[l][m] = wx4[(m - 1) + 4 * (l - 1)];
+        c->rei[l] = reicmc[l - 1]; c->rel[l] = relqmc[l - 1];
+        for (int ig = 1; ig <= NGPT; ig++) {
+            size_t o = (size_t)(ig - 1) + (size_t)NGPT * (l - 1);
+            c->cldfmc[l][ig] = cldfmc[o]; c->taucmc[l][ig] = taucmc[o];
+            c->ciwpmc[l][ig] = ciwpmc[o]; c->clwpmc[l][ig] = clwpmc[o];
+        }
+        for (int b = 1; b <= NBND; b++) c->taua[l][b] = taua[(l - 1) + nl * (b - 1)];
+    }
+    for (int b = 1; b <= NBND; b++) c->dplankbnd_dt[b] = 0.0;
+    if (cldprmc(c)) return 1;
+    setcoef(c, istart, idrv);
+    taumol(c);
+    combine_taut(c);
+    rtrn_generic(c, istart, iend, iout, idrv, 1);
+    for (int k = 0; k <= nl; k++) {
+        totuflux[k] = c->totuflux[k]; totdflux[k] = c->totdflux[k]; fnet[k] = c->fnet[k]; htr[k] = c->htr[k];
+        totuclfl[k] = c->totuclfl[k]; totdclfl[k] = c->totdclfl[k]; fnetc[k] = c->fnetc[k]; htrc[k] = c->htrc[k];
+        dtotuflux_dt[k] = idrv == 1 ? c->dtotuflux_dt[k] : 0.0;
+        dtotuclfl_dt[k] = idrv == 1 ? c->dtotuclfl_dt[k] : 0.0;
+    }
+    for (int l = 1; l <= nl; l++)
+        for (int ig = 1; ig <= NGPT; ig++) {
+            taug_out[(l - 1) + nl * (ig - 1)] = c->taug[l][ig];
+            fracs_out[(l - 1) + nl * (ig - 1)] = c->fracs[l][ig];
+        }
+    *ncbands_out = c->ncbands;
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * McICA sub-column generator.  The GCM routine (src/mcica_subcol_gen_lw.f90:183-703) does not compile as
  * shipped; its compilable statement is the one-column generator

@@ -295,6 +295,51 @@ def rrtmg_lw_mcica_subcol_device(d, out, permuteseed, irng, alpha=None, icld=Non
     return icld_c.value
 
 
+def run_columns_mcica(cols, subs, istart=1, iend=16, icld=None, idrv=None):
+    """Prepared-column McICA entry: cols[k] (rrtmg_lw_amd.io_rrtm.read_input_rrtm dicts) with sub-columns subs[k] =
+    dict(cldfmc, taucmc, ciwpmc, clwpmc (140, nlayers), reicmc, relqmc (nlayers)); one (column, sample) pair per entry.
+    Returns dict of arrays (n, 0:nlayers)."""
+    n = len(cols)
+    nl = int(cols[0]["nlayers"])
+    icld = int(cols[0]["icld"]) if icld is None else icld
+    idrv = int(cols[0]["idrv"]) if idrv is None else idrv
+    st = lambda src, key, shape: _f(np.stack([np.asarray(c[key], dtype=np.float64).reshape(shape[1:], order="F") for c in src]), shape)
+    a = dict(pavel=st(cols, "pavel", (n, nl)), tavel=st(cols, "tavel", (n, nl)), pz=st(cols, "pz", (n, nl + 1)), tz=st(cols, "tz", (n, nl + 1)),
+             tbound=_f(np.array([float(c["tbound"]) for c in cols]), (n,)), semiss=st(cols, "semiss", (n, NBND)),
+             coldry=st(cols, "coldry", (n, nl)), wkl=st(cols, "wkl", (n, 7, nl)), wbrodl=st(cols, "wbrodl", (n, nl)), wx=st(cols, "wx", (n, 4, nl)),
+             pwvcm=_f(np.array([float(c["pwvcm"]) for c in cols]), (n,)), reicmc=st(subs, "reicmc", (n, nl)), relqmc=st(subs, "relqmc", (n, nl)),
+             taua=st(cols, "tauaer", (n, nl, NBND)))
+    for k in ("cldfmc", "taucmc", "ciwpmc", "clwpmc"):          # (140, n, nlayers)
+        a[k] = _f(np.stack([np.asarray(s_[k], dtype=np.float64) for s_ in subs], axis=1), (NGPT, n, nl))
+    names = ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc", "dtotuflux_dt", "dtotuclfl_dt")
+    out = {k: np.zeros((n, nl + 1), order="F") for k in names}
+    c0 = cols[0]
+    args = [C.c_int(n), C.c_int(nl), C.c_int(istart), C.c_int(iend), C.c_int(icld), C.c_int(idrv)]
+    args += [_p(a[k]) for k in ("pavel", "tavel", "pz", "tz", "tbound", "semiss", "coldry", "wkl", "wbrodl", "wx", "pwvcm")]
+    args += [C.c_int(int(c0["inflag"])), C.c_int(int(c0["iceflag"])), C.c_int(int(c0["liqflag"]))]
+    args += [_p(a[k]) for k in ("cldfmc", "taucmc", "ciwpmc", "clwpmc", "reicmc", "relqmc", "taua")]
+    args += [_p(out[k]) for k in names]
+    _check(lib().rrtmg_lw_hip_run_columns_mcica(*args))
+    return out
+
+
+def column_mcica_samples(col, samples, irng=1, alpha=None):
+    """The column driver's McICA loop for one prepared column (src/rrtmg_lw.1col.f90:471-660): sub-columns of sample `ims`
+    from mcica_subcol_lw with permuteseed = ims * 140, then cldprmc -> rtrnmc; returns the per-sample results (n, 0:nlayers)
+    and the generated sub-columns.  The driver's output is the mean over ims = 1..200."""
+    nl = int(col["nlayers"])
+    r2 = lambda v: np.asfortranarray(np.asarray(v, dtype=np.float64).reshape((1, nl)))
+    al = None if alpha is None else r2(alpha)
+    subs = []
+    for ims in samples:
+        g = mcica_subcol_lw(1, nl, int(col["icld"]), ims * NGPT, irng, r2(col["pavel"]), r2(col["cldfrac"]), r2(col["ciwp"]),
+                            r2(col["clwp"]), r2(col["rei"]), r2(col["rel"]),
+                            np.asfortranarray(np.asarray(col["tauc"], dtype=np.float64).reshape((NBND, 1, nl), order="F")), al)
+        subs.append(dict(cldfmc=g["cldfmcl"][:, 0, :], taucmc=g["taucmcl"][:, 0, :], ciwpmc=g["ciwpmcl"][:, 0, :],
+                         clwpmc=g["clwpmcl"][:, 0, :], reicmc=g["reicmcl"][0], relqmc=g["relqmcl"][0]))
+    return run_columns_mcica([col] * len(subs), subs), subs
+
+
 def finalize():
     global _initialised
     if _lib is not None:

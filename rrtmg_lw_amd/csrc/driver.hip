@@ -230,8 +230,8 @@ int run_main(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
     const dim3 lgrid(gx, nlay);
 #define LAYER_GROUP(GR)                                                                                              \
     if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, block, s, G.D, Wk, g, c, la);         \
-    else if (mode == 3) { if constexpr (GCM) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<true, 2, GR>), lgrid, block, s, G.D, Wk, g, c, la); \
-                                               else LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, block, s, G.D, Wk, g, c, la); } } \
+    else if (mode == 3) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<GCM, 2, GR>), lgrid, block, s, G.D, Wk, g, c, la); \
+                          else if constexpr (GCM) LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, block, s, G.D, Wk, g, c, la); } \
     else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, block, s, G.D, Wk, g, c, la);
     LAYER_GROUP(0)
 #if RRLW_LAYER_GROUPS > 1
@@ -776,6 +776,56 @@ int rrtmg_lw_hip_run_columns(
     HIP_TRY(hipMemsetAsync(o[9], 0, n * (L + 1) * 8, s));
     FluxOut out{o[0], o[1], o[3], o[4], o[5], o[7], o[8], o[9], o[2], o[6]};
     if (int rc = run_batch<false>(s, ncol, 0, ncol, nlayers, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out)) return rc;
+    double *ho[10] = {totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, dtotuflux_dt, dtotuclfl_dt};
+    for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(ho[k], o[k], n * (L + 1) * 8, hipMemcpyDeviceToHost, s));
+    return read_physics_error(s);
+}
+
+// McICA flavour of the prepared-column entry: cldprmc -> setcoef -> taumol -> rtrnmc for `ncol` (column, sample) pairs.
+int rrtmg_lw_hip_run_columns_mcica(
+    int ncol, int nlayers, int istart, int iend, int icld, int idrv,
+    const double *pavel, const double *tavel, const double *pz, const double *tz, const double *tbound,
+    const double *semiss, const double *coldry, const double *wkl, const double *wbrodl, const double *wx,
+    const double *pwvcm, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *taucmc,
+    const double *ciwpmc, const double *clwpmc, const double *reicmc, const double *relqmc, const double *taua,
+    double *totuflux, double *totdflux, double *fnet, double *htr,
+    double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
+    double *dtotuflux_dt, double *dtotuclfl_dt)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = check_common(ncol, nlayers)) return rc;
+    if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
+    if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns_mcica handles at most one batch (%d columns)", G.batch);
+    const int mode = icld == 0 ? 0 : 3;
+    if (int rc = ensure_workspace(nlayers, ncol, true, true)) return rc;
+    const size_t n = (size_t)ncol, L = (size_t)nlayers;
+    struct In { const double *h; size_t cnt; double *d; };
+    In ins[] = {{pavel, n * L, 0}, {tavel, n * L, 0}, {pz, n * (L + 1), 0}, {tz, n * (L + 1), 0}, {tbound, n, 0}, {semiss, 16 * n, 0},
+                {coldry, n * L, 0}, {wkl, 7 * n * L, 0}, {wbrodl, n * L, 0}, {wx, 4 * n * L, 0}, {pwvcm, n, 0},
+                {cldfmc, NGPT * n * L, 0}, {taucmc, NGPT * n * L, 0}, {ciwpmc, NGPT * n * L, 0}, {clwpmc, NGPT * n * L, 0},
+                {reicmc, n * L, 0}, {relqmc, n * L, 0}, {taua, 16 * n * L, 0}};
+    size_t tot = 0;
+    for (auto &i : ins) { if (!i.h) return fail(RRTMG_LW_HIP_EARG, "null input array"); tot += i.cnt; }
+    const size_t out_d = 10 * n * (L + 1);
+    if (int rc = ensure_stage((tot + out_d) * 8 + 4096)) return rc;
+    double *p = (double *)G.stage_base;
+    hipStream_t s = G.stream;
+    for (auto &i : ins) {
+        i.d = p; p += i.cnt;
+        HIP_TRY(hipMemcpyAsync(i.d, i.h, i.cnt * 8, hipMemcpyHostToDevice, s));
+    }
+    double *o[10];
+    for (auto &q : o) { q = p; p += n * (L + 1); }
+    ColIn c{ins[0].d, ins[1].d, ins[2].d, ins[3].d, ins[4].d, ins[5].d, ins[6].d, ins[7].d, ins[8].d, ins[9].d, ins[10].d,
+            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ins[17].d};
+    McIn m{ins[11].d, ins[12].d, ins[13].d, ins[14].d, ins[15].d, ins[16].d};
+    GcmIn g{};
+    HIP_TRY(hipMemsetAsync(o[3], 0, n * (L + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(o[7], 0, n * (L + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(o[8], 0, n * (L + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(o[9], 0, n * (L + 1) * 8, s));
+    FluxOut out{o[0], o[1], o[3], o[4], o[5], o[7], o[8], o[9], o[2], o[6]};
+    if (int rc = run_batch<false>(s, ncol, 0, ncol, nlayers, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out, &m)) return rc;
     double *ho[10] = {totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, dtotuflux_dt, dtotuclfl_dt};
     for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(ho[k], o[k], n * (L + 1) * 8, hipMemcpyDeviceToHost, s));
     return read_physics_error(s);

@@ -21,6 +21,29 @@ CASES = [("MLS-clr", "input_rrtm_MLS-clr", None, None), ("MLS-clr-aer12", "input
          ("MLW-clr", "input_rrtm_MLW-clr", None, None), ("SAW-clr", "input_rrtm_SAW-clr", None, None), ("TROP-clr", "input_rrtm_TROP-clr", None, None)]
 
 
+MC_CASES = [("MLS-cld5-imca1-icld2", "input_rrtm_MLS-cld-imca1-icld2", "in_cld_rrtm-cld5"),
+            ("MLS-cld7-imca1-icld2", "input_rrtm_MLS-cld-imca1-icld2", "in_cld_rrtm-cld7"),
+            ("MLS-cld7-imca1-icld4-idcor0", "input_rrtm_MLS-cld-imca1-icld4-idcor0", "in_cld_rrtm-cld7"),
+            ("MLS-cld7-imca1-icld5-idcor0", "input_rrtm_MLS-cld-imca1-icld5-idcor0", "in_cld_rrtm-cld7"),
+            ("MLS-cld7-imca1-icld5-idcor1", "input_rrtm_MLS-cld-imca1-icld5-idcor1", "in_cld_rrtm-cld7")]
+NMCA = 200      # src/rrtmg_lw.1col.f90:460
+
+
+def _run_mcica(alpha_fn, samples_fn, name, inp, cld):
+    """The driver's imca = 1 output is the mean over 200 Mersenne-Twister samples (seed ims * 140), :471-660."""
+    j = lambda n: os.path.join(G, n)
+    col = read_input_rrtm(j(inp), j(cld), None)
+    nl = int(col["nlayers"])
+    alpha = np.zeros(nl)
+    if int(col["icld"]) in (4, 5):
+        alpha = alpha_fn(col)
+    res = samples_fn(col, list(range(1, NMCA + 1)), alpha)
+    blk = read_output_rrtm(j(f"output_rrtm_{name}"))[0]
+    assert np.abs(res["totuflux"].mean(axis=0) - blk["uflx"]).max() <= 0.01 + 1e-4
+    assert np.abs(res["totdflux"].mean(axis=0) - blk["dflx"]).max() <= 0.01 + 1e-4
+    assert np.abs(res["htr"].mean(axis=0) - blk["htr"]).max() <= 0.001 + 1e-5
+
+
 def _run(engine_column, name, inp, cld, aer):
     j = lambda n: os.path.join(G, n) if n else None
     col = read_input_rrtm(j(inp), j(cld), j(aer))
@@ -50,3 +73,48 @@ def test_oracle_matches_golden(name, inp, cld, aer):
 def test_hip_matches_golden(name, inp, cld, aer):
     api.rrtmg_lw_ini(1004.0, kdata=api.REAL_KDATA, device=0)
     _run(lambda c, a, b, io: {k: v[0] for k, v in api.run_columns([c], a, b).items()}, name, inp, cld, aer)
+
+
+@needs_kdata
+@pytest.mark.parametrize("name,inp,cld", MC_CASES, ids=[c[0] for c in MC_CASES])
+def test_oracle_matches_mcica_golden(name, inp, cld):
+    from oracle.bindings import Oracle
+    o = Oracle(kdata=api.REAL_KDATA)
+
+    def alpha_fn(col):
+        nl = int(col["nlayers"])
+        r2 = lambda v: np.asarray(v, dtype=np.float64).reshape((1, nl))
+        return o.get_alpha(1, nl, int(col["icld"]), int(col["idcor"]), float(col["decorr_con"]), r2(col["dz"]),
+                           np.array([float(col["lat"])]), int(col["juldat"]), r2(col["cldfrac"]))[0]
+
+    def samples_fn(col, samples, alpha):
+        nl = int(col["nlayers"])
+        r2 = lambda v: np.asfortranarray(np.asarray(v, dtype=np.float64).reshape((1, nl)))
+        out = {k: [] for k in ("totuflux", "totdflux", "htr")}
+        for ims in samples:
+            g = o.mcica_subcol(1, nl, int(col["icld"]), ims * 140, 1, r2(col["pavel"]), r2(col["cldfrac"]), r2(col["ciwp"]),
+                               r2(col["clwp"]), r2(col["rei"]), r2(col["rel"]),
+                               np.asfortranarray(np.asarray(col["tauc"]).reshape((16, 1, nl), order="F")), r2(alpha))
+            sub = dict(cldfmc=g["cldfmcl"][:, 0, :], taucmc=g["taucmcl"][:, 0, :], ciwpmc=g["ciwpmcl"][:, 0, :],
+                       clwpmc=g["clwpmcl"][:, 0, :], reicmc=g["reicmcl"][0], relqmc=g["relqmcl"][0])
+            r = o.column_mc(col, sub)
+            for k in out:
+                out[k].append(r[k])
+        return {k: np.array(v) for k, v in out.items()}
+
+    _run_mcica(alpha_fn, samples_fn, name, inp, cld)
+
+
+@needs_kdata
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,inp,cld", MC_CASES, ids=[c[0] for c in MC_CASES])
+def test_hip_matches_mcica_golden(name, inp, cld):
+    api.rrtmg_lw_ini(1004.0, kdata=api.REAL_KDATA, device=0)
+
+    def alpha_fn(col):
+        nl = int(col["nlayers"])
+        r2 = lambda v: np.asarray(v, dtype=np.float64).reshape((1, nl))
+        return api.get_alpha(1, nl, int(col["icld"]), int(col["idcor"]), float(col["decorr_con"]), r2(col["dz"]),
+                             np.array([float(col["lat"])]), int(col["juldat"]), r2(col["cldfrac"]))[0]
+
+    _run_mcica(alpha_fn, lambda col, samples, alpha: api.column_mcica_samples(col, samples, irng=1, alpha=alpha)[0], name, inp, cld)

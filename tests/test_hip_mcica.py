@@ -238,3 +238,26 @@ def test_against_reference_fixture(hip, path):
         fused = hip.rrtmg_lw_mcica_subcol_from_dict(d, seed, 0, alpha=alpha, icld=icld)
         for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
             assert np.array_equal(fused[k], got[k]), k
+
+
+def test_column_mode_mcica_samples(hip, oracle):
+    """The column driver's imca = 1 loop (src/rrtmg_lw.1col.f90:471-660) for a reference example input: Mersenne-Twister
+    sub-columns with seed ims * 140 per sample (bit-exact), cldprmc -> rtrnmc per sample on the prepared column."""
+    from rrtmg_lw_amd.io_rrtm import read_input_rrtm
+    col = read_input_rrtm(os.path.join(G, "input_rrtm_MLS-cld-imca1-icld2"), os.path.join(G, "in_cld_rrtm-cld5"), None)
+    assert int(col["imca"]) == 1
+    nl = int(col["nlayers"])
+    samples = [1, 2, 3, 50, 200]
+    got, subs = hip.column_mcica_samples(col, samples, irng=1)
+    for k, ims in enumerate(samples):
+        r2 = lambda v: np.asfortranarray(np.asarray(v, dtype=np.float64).reshape((1, nl)))
+        osub = oracle.mcica_subcol(1, nl, int(col["icld"]), ims * 140, 1, r2(col["pavel"]), r2(col["cldfrac"]), r2(col["ciwp"]),
+                                   r2(col["clwp"]), r2(col["rei"]), r2(col["rel"]),
+                                   np.asfortranarray(np.asarray(col["tauc"]).reshape((16, 1, nl), order="F")), np.zeros((1, nl)))
+        assert np.array_equal(subs[k]["cldfmc"], osub["cldfmcl"][:, 0, :])
+        ref = oracle.column_mc(col, subs[k])
+        for key, tol in (("totuflux", FLUX_TOL), ("totdflux", FLUX_TOL), ("totuclfl", FLUX_TOL), ("totdclfl", FLUX_TOL),
+                         ("fnet", FLUX_TOL), ("htr", HR_TOL), ("htrc", HR_TOL)):
+            d = np.abs(got[key][k] - ref[key]).max()
+            assert d <= tol and d <= TIGHT_FLUX, (ims, key, d)
+    assert np.ptp(got["totdflux"][:, 0]) > 1.0          # the samples differ: different sub-columns

@@ -117,6 +117,24 @@ def test_live_mcica_reference_if_built(oracle):
             assert np.abs(a[k] - b[k]).max() <= TOL, (icld, k)
 
 
+def test_live_column_mcica_reference_if_built(oracle):
+    """McICA flavour of the prepared-column entry (one sample of the column driver with imca = 1): reference example input,
+    sub-columns from the reference's own generator, cldprmc -> rtrnmc."""
+    from oracle.bindings import Reference
+    if not Reference.available("mcica"):
+        pytest.skip("oracle/_ref not built (needs /root/reference and flang)")
+    ref = Reference("mcica")
+    col = read_input_rrtm(os.path.join(G, "input_rrtm_MLS-cld-imca1-icld2"), os.path.join(G, "in_cld_rrtm-cld7"), None)
+    nl = int(col["nlayers"])
+    for ims, irng in ((1, 1), (5, 1), (2, 0)):
+        sub = ref.mcica_subcol_1col(nl, int(col["icld"]), ims, irng, col["pavel"], col["cldfrac"], col["ciwp"], col["clwp"], col["rei"],
+                                    col["rel"], col["tauc"], np.zeros(nl))
+        a, b = oracle.column_mc(col, sub), ref.column_mc(col, sub)
+        assert sub["cldfmc"].any()
+        for k in ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc"):
+            assert np.abs(a[k] - b[k]).max() <= TOL, (ims, k)
+
+
 def test_live_reference_if_built(oracle):
     from oracle.bindings import Reference
     if not Reference.available("nomcica"):
