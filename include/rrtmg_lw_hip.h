@@ -198,6 +198,9 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
 /* Tuning / introspection ------------------------------------------------------------------------- */
 /* Columns processed per internal batch (bounds the device workspace); default 32768. */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
+/* Device-pointer entries run k_sweep/k_flux of column batch i on a second stream while k_layer of batch i+1 runs on the
+ * caller's stream (two scratch sets).  on = 0 serialises them again (halves the scratch workspace actually touched). */
+int rrtmg_lw_hip_set_overlap(int on);
 /* Bytes of device workspace currently allocated. */
 long long rrtmg_lw_hip_workspace_bytes(void);
 /* Number of g-point chunks the sweep kernel distributes over threads (one partial flux slab each). */

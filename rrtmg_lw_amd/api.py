@@ -72,6 +72,10 @@ def set_batch(n):
     _check(lib().rrtmg_lw_hip_set_batch(C.c_int(int(n))))
 
 
+def set_overlap(on):
+    _check(lib().rrtmg_lw_hip_set_overlap(C.c_int(1 if on else 0)))
+
+
 def _f(a, shape):
     a = np.asfortranarray(a, dtype=np.float64)
     if tuple(a.shape) != tuple(shape):

@@ -34,12 +34,16 @@ struct State {
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloud of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
     struct PrepSet { double *percol; int *laytrop, *ncbands; double *taucloud, *odcld, *efcl, *mrfac; int *cflag; } prep[2] = {};
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_in = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    // the per-cell scratch written by k_layer and read by k_sweep exists twice as well: k_sweep/k_flux of batch i (HBM-bound)
+    // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
+    struct ScrSet { scr_t *scr[NSCR]; double *rad0; } scrset[2] = {};
+    hipStream_t aux = nullptr, sw = nullptr;
+    hipEvent_t ev_in = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_layer[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     // McICA sub-column masks of all columns of the current call
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
     int batch = 32768;
+    bool split_sweep = true;     // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries)
     // host-entry staging
     void *stage_base = nullptr;
     size_t stage_bytes = 0;
@@ -122,14 +126,22 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     Workspace &W = G.W;
     W = Workspace{};
     std::vector<Item> items = {
-        {(void **)&W.scr[S_ATR], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
-        {(void **)&W.scr[S_BBD], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
-        {(void **)&W.scr[S_BBU], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)},
-        {(void **)&W.rad0, (size_t)2 * NQUAD * 4 * n * 8},
         {(void **)&W.pdn, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.pup, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.dpart, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
     };
+    for (auto &ss : G.scrset) {
+        ss = State::ScrSet{};
+        items.push_back({(void **)&ss.scr[S_ATR], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        items.push_back({(void **)&ss.scr[S_BBD], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        items.push_back({(void **)&ss.scr[S_BBU], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        items.push_back({(void **)&ss.rad0, (size_t)2 * NQUAD * 4 * n * 8});
+        if (cloud) {
+            items.push_back({(void **)&ss.scr[S_ATOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+            items.push_back({(void **)&ss.scr[S_BBDTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+            items.push_back({(void **)&ss.scr[S_BBUTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        }
+    }
     for (auto &ps : G.prep) {
         ps = State::PrepSet{};
         items.push_back({(void **)&ps.percol, (size_t)NPERCOL * n * 8});
@@ -138,9 +150,6 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         items.push_back({(void **)&ps.cflag, (L + 2) * n * 4});
     }
     if (cloud) {
-        items.push_back({(void **)&W.scr[S_ATOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-        items.push_back({(void **)&W.scr[S_BBDTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-        items.push_back({(void **)&W.scr[S_BBUTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
         for (auto &ps : G.prep) {
             items.push_back({(void **)&ps.taucloud, 16 * L * n * 8});
             items.push_back({(void **)&ps.odcld, 16 * L * n * 8});
@@ -160,7 +169,9 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     W.ncolb = ncolb;
     W.nlay = nlay;
     W.err = G.d_err;
-    {   // G.W itself carries prep set 0
+    for (int a = 0; a < NSCR; a++) W.scr[a] = G.scrset[0].scr[a];
+    W.rad0 = G.scrset[0].rad0;
+    {   // G.W itself carries prep set 0 and scratch set 0
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
         W.taucloud = ps.taucloud; W.odcld = ps.odcld; W.efcl = ps.efcl; W.mrfac = ps.mrfac;
@@ -191,6 +202,8 @@ Workspace ws_for(int k)
     const State::PrepSet &ps = G.prep[k];
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
     w.taucloud = ps.taucloud; w.odcld = ps.odcld; w.efcl = ps.efcl; w.mrfac = ps.mrfac;
+    for (int a = 0; a < NSCR; a++) w.scr[a] = G.scrset[k].scr[a];
+    w.rad0 = G.scrset[k].rad0;
     return w;
 }
 
@@ -210,11 +223,11 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
     return 0;
 }
 
-// the heavy part of one batch, everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr, 3 rtrnmc (McICA; `mc` = the
-// sub-column arrays, or null when the sub-columns come from the generator's mask in Wk.mask)
+// layer-local part of one batch (k_cloudmc, k_layer groups), everything device-resident.  mode: 0 clear, 1 rtrn, 2 rtrnmr,
+// 3 rtrnmc (McICA; `mc` = the sub-column arrays, or null when the sub-columns come from the generator's mask in Wk.mask)
 template <bool GCM>
-int run_main(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
-             const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
+int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
+              const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const McIn *mc = nullptr)
 {
     const dim3 block(BLOCK);
     if (mode == 3) {
@@ -247,6 +260,18 @@ int run_main(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
     LAYER_GROUP(6) LAYER_GROUP(7) LAYER_GROUP(8)
 #endif
 #undef LAYER_GROUP
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// vertical part of one batch: k_sweep launches, k_flux, k_rates
+template <bool GCM>
+int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
+              const GcmIn &g, const ColIn &c, const FluxOut &out, const McIn *mc = nullptr)
+{
+    const dim3 block(BLOCK);
+    const unsigned gx = (nb + BLOCK - 1) / BLOCK;
     SweepArgs sa;
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
     sa.emis = GCM ? g.emis : c.semiss;
@@ -283,16 +308,19 @@ int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int 
 {
     const Workspace Wk = ws_for(0);
     if (int rc = run_prep<GCM>(s, Wk, nb, col0, nct, mode, idrv, istart, g, c, inflag, iceflag, liqflag)) return rc;
-    return run_main<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out, mc);
+    if (int rc = run_layer<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, mc)) return rc;
+    return run_sweep<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, out, mc);
 }
 
 int ensure_pipeline()
 {
     if (G.aux) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&G.aux, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&G.sw, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&G.ev_in, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
         HIP_TRY(hipEventCreateWithFlags(&G.ev_ready[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&G.ev_layer[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&G.ev_done[k], hipEventDisableTiming));
     }
     return 0;
@@ -310,19 +338,36 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
     if (int rc = ensure_pipeline()) return rc;
     const int nbmax = std::min(ncol, G.batch);
     ColIn c{};
+    // sub-column arrays mode keeps per-g-point cloud arrays (odg/cfef) in one set only: no layer/sweep overlap there
+    const bool split = G.split_sweep && !(mode == 3 && mc);
     HIP_TRY(hipEventRecord(G.ev_in, s));                 // inputs are ready when the caller's stream gets here
     HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_in, 0));
     int i = 0;
     for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
         const Workspace Wk = ws_for(k);
-        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_done[k], 0));       // prep set k is free again
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_done[k], 0));       // prep set k is free again (sweep of batch i-2 done)
         if (int rc = run_prep<true>(G.aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
         if (gen.on) launch_kiss(G.aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha});
         HIP_TRY(hipEventRecord(G.ev_ready[k], G.aux));
         HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
-        if (int rc = run_main<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, out, mc)) return rc;
-        HIP_TRY(hipEventRecord(G.ev_done[k], s));
+        if (split) {
+            // k_layer of this batch on the caller's stream, its sweep on `sw`: the HBM-bound sweep of batch i overlaps the
+            // latency-bound k_layer of batch i+1 (scratch set k is free once the sweep of batch i-2 is done)
+            if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, G.ev_done[k], 0));
+            if (int rc = run_layer<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc)) return rc;
+            HIP_TRY(hipEventRecord(G.ev_layer[k], s));
+            HIP_TRY(hipStreamWaitEvent(G.sw, G.ev_layer[k], 0));
+            if (int rc = run_sweep<true>(G.sw, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc)) return rc;
+            HIP_TRY(hipEventRecord(G.ev_done[k], G.sw));
+        } else {
+            if (int rc = run_layer<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc)) return rc;
+            if (int rc = run_sweep<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc)) return rc;
+            HIP_TRY(hipEventRecord(G.ev_done[k], s));
+        }
+    }
+    if (split) {                                  // the caller's stream sees the results of every batch
+        for (int k = 0; k < std::min(i, 2); k++) HIP_TRY(hipStreamWaitEvent(s, G.ev_done[k], 0));
     }
     return 0;
 }
@@ -570,8 +615,9 @@ void rrtmg_lw_hip_finalize(void)
     if (G.stream) (void)hipStreamDestroy(G.stream);
     if (G.aux) {
         (void)hipStreamDestroy(G.aux);
+        (void)hipStreamDestroy(G.sw);
         (void)hipEventDestroy(G.ev_in);
-        for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_ready[k]); (void)hipEventDestroy(G.ev_done[k]); }
+        for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_ready[k]); (void)hipEventDestroy(G.ev_layer[k]); (void)hipEventDestroy(G.ev_done[k]); }
     }
     G = State();
 }
@@ -580,6 +626,12 @@ int rrtmg_lw_hip_set_batch(int ncol_batch)
 {
     if (ncol_batch < 64) return fail(RRTMG_LW_HIP_EARG, "batch must be >= 64 columns");
     G.batch = ncol_batch;
+    return 0;
+}
+
+int rrtmg_lw_hip_set_overlap(int on)
+{
+    G.split_sweep = on != 0;
     return 0;
 }
 
