@@ -211,6 +211,11 @@ int rrtmg_lw_hip_num_chunks(void);
 void rrtmg_lw_hip_profile_begin(void);
 int rrtmg_lw_hip_profile_end(char *buf, int len);
 
+/* Optional: pin a host array that will be passed to the host-pointer entries again and again (hipHostRegister).  Their H2D / D2H
+ * copies then run as asynchronous DMA overlapped with the kernels of the neighbouring column batches. */
+int rrtmg_lw_hip_host_register(void *ptr, long long bytes);
+int rrtmg_lw_hip_host_unregister(void *ptr);
+
 /* PMC calibration: one kernel that reads `bytes` and writes `bytes` with 16 B per lane (known HBM traffic), so that a
  * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can fix the counters' unit and scale in the same session. */
 int rrtmg_lw_hip_calibrate_stream(long long bytes);

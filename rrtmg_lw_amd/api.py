@@ -72,6 +72,15 @@ def set_batch(n):
     _check(lib().rrtmg_lw_hip_set_batch(C.c_int(int(n))))
 
 
+def host_register(a):
+    """Pin a numpy array that will be passed to the host-pointer entries repeatedly (rrtmg_lw_hip_host_register)."""
+    _check(lib().rrtmg_lw_hip_host_register(C.c_void_p(a.ctypes.data), C.c_longlong(a.nbytes)))
+
+
+def host_unregister(a):
+    _check(lib().rrtmg_lw_hip_host_unregister(C.c_void_p(a.ctypes.data)))
+
+
 def set_overlap(on):
     _check(lib().rrtmg_lw_hip_set_overlap(C.c_int(1 if on else 0)))
 
@@ -89,20 +98,17 @@ def _p(a):
 
 def rrtmg_lw(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr,
              cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp,
-             cliqwp, reice, reliq, tauaer):
-    """Non-McICA rrtmg_lw with host arrays.  Returns dict(uflx, dflx, hr, uflxc, dflxc, hrc[, duflx_dt, duflxc_dt], icld)."""
+             cliqwp, reice, reliq, tauaer, out=None):
+    """Non-McICA rrtmg_lw with host arrays.  Returns dict(uflx, dflx, hr, uflxc, dflxc, hrc[, duflx_dt, duflxc_dt], icld);
+    `out` may hold preallocated (e.g. host_register'ed) Fortran-ordered output arrays."""
     a2 = [_f(x, (ncol, nlay)) for x in (play,)] + [_f(plev, (ncol, nlay + 1)), _f(tlay, (ncol, nlay)),
                                                   _f(tlev, (ncol, nlay + 1)), _f(tsfc, (ncol,))]
     gases = [_f(x, (ncol, nlay)) for x in (h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr)]
     em = _f(emis, (ncol, NBND))
     cld = [_f(cldfr, (ncol, nlay)), _f(taucld, (NBND, ncol, nlay)), _f(cicewp, (ncol, nlay)), _f(cliqwp, (ncol, nlay)),
            _f(reice, (ncol, nlay)), _f(reliq, (ncol, nlay)), _f(tauaer, (ncol, nlay, NBND))]
-    out = {k: np.empty((ncol, nlay + 1), order="F") for k in ("uflx", "dflx", "uflxc", "dflxc")}
-    out["hr"] = np.empty((ncol, nlay), order="F")
-    out["hrc"] = np.empty((ncol, nlay), order="F")
-    if idrv == 1:
-        out["duflx_dt"] = np.empty((ncol, nlay + 1), order="F")
-        out["duflxc_dt"] = np.empty((ncol, nlay + 1), order="F")
+    if out is None:
+        out = _out_arrays(ncol, nlay, idrv)
     icld_c = C.c_int(int(icld))
     null = C.cast(None, _dp)
     args = [C.c_int(ncol), C.c_int(nlay), C.byref(icld_c), C.c_int(int(idrv))]
@@ -121,12 +127,12 @@ _GCM_ORDER = ("play", "plev", "tlay", "tlev", "tsfc", "h2ovmr", "o3vmr", "co2vmr
 _CLD_ORDER = ("cldfr", "taucld", "cicewp", "cliqwp", "reice", "reliq", "tauaer")
 
 
-def rrtmg_lw_from_dict(d, icld=None, idrv=None):
+def rrtmg_lw_from_dict(d, icld=None, idrv=None, out=None):
     """Convenience: call rrtmg_lw with the dictionaries produced by rrtmg_lw_amd.synth.make_gcm_inputs."""
     icld = d["icld"] if icld is None else icld
     idrv = d["idrv"] if idrv is None else idrv
     return rrtmg_lw(d["ncol"], d["nlay"], icld, idrv, *[d[k] for k in _GCM_ORDER], d["inflglw"], d["iceflglw"],
-                    d["liqflglw"], *[d[k] for k in _CLD_ORDER])
+                    d["liqflglw"], *[d[k] for k in _CLD_ORDER], out=out)
 
 
 def rrtmg_lw_device(d, out, icld=None, idrv=None, stream=None):

@@ -48,6 +48,8 @@ struct State {
     void *stage_base = nullptr;
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
+    hipStream_t cp_in = nullptr, cp_out = nullptr;      // host-pointer entries: H2D and D2H copy streams
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
     std::string err;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profile = false;
@@ -441,6 +443,70 @@ int stage_out(std::vector<HostOut> &outs, size_t ncol, size_t col0, size_t nb, h
     return 0;
 }
 
+int ensure_copy_streams()
+{
+    if (G.cp_in) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&G.cp_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&G.cp_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(hipEventCreateWithFlags(&G.ev_h2d[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&G.ev_cmp[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&G.ev_d2h[k], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// Host-pointer entries as a three-stage pipeline over the column batches: H2D of batch i+1 (copy stream) | kernels of
+// batch i (G.stream) | D2H of batch i-1 (second copy stream), two staging sets.  With pageable host arrays the copies
+// block the calling thread, which still overlaps them with the kernels of the previous batch; with arrays pinned through
+// rrtmg_lw_hip_host_register they are asynchronous DMA at PCIe rate.  body(stream, nb, in_ptrs, out_ptrs) enqueues the
+// kernels of one batch whose staged arrays start at column 0.
+template <class Body>
+int host_pipeline(int ncol, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body)
+{
+    if (int rc = ensure_copy_streams()) return rc;
+    size_t set = 0;
+    for (auto &a : ins) set += a.h ? a.inner * a.rows * (size_t)nbmax : 0;
+    for (auto &a : outs) set += a.rows * (size_t)nbmax;
+    set = align_up(set * 8, 256);
+    if (int rc = ensure_stage(2 * set + 4096)) return rc;
+    auto bind = [&](int k) {                 // point the descriptors at staging set k
+        double *p = (double *)((char *)G.stage_base + (size_t)k * set);
+        for (auto &a : ins) { a.d = a.h ? p : nullptr; p += a.h ? a.inner * a.rows * (size_t)nbmax : 0; }
+        for (auto &a : outs) { a.d = p; p += a.rows * (size_t)nbmax; }
+    };
+    auto copy_out = [&](int k, int col0, int nb) -> int {
+        bind(k);
+        HIP_TRY(hipStreamWaitEvent(G.cp_out, G.ev_cmp[k], 0));
+        for (auto &a : outs) {
+            if (!a.active || !a.h) continue;
+            const size_t w = (size_t)nb * 8, sp = (size_t)ncol * 8;
+            HIP_TRY(hipMemcpy2DAsync(a.h + col0, sp, a.d, w, w, a.rows, hipMemcpyDeviceToHost, G.cp_out));
+        }
+        HIP_TRY(hipEventRecord(G.ev_d2h[k], G.cp_out));
+        return 0;
+    };
+    int i = 0, prev_col0 = 0, prev_nb = 0;
+    for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
+        const int nb = std::min(nbmax, ncol - col0), k = i & 1;
+        bind(k);
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.cp_in, G.ev_cmp[k], 0));          // kernels of batch i-2 have read staging set k
+        if (int rc = stage_in(ins, (size_t)ncol, (size_t)col0, (size_t)nb, G.cp_in)) return rc;
+        HIP_TRY(hipEventRecord(G.ev_h2d[k], G.cp_in));
+        HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_h2d[k], 0));
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_d2h[k], 0));         // outputs of batch i-2 have left staging set k
+        if (int rc = body(G.stream, nb, ins, outs)) return rc;
+        HIP_TRY(hipEventRecord(G.ev_cmp[k], G.stream));
+        if (i >= 1)
+            if (int rc = copy_out(k ^ 1, prev_col0, prev_nb)) return rc;
+        prev_col0 = col0; prev_nb = nb;
+    }
+    if (int rc = copy_out((i - 1) & 1, prev_col0, prev_nb)) return rc;
+    HIP_TRY(hipStreamSynchronize(G.cp_out));
+    HIP_TRY(hipStreamSynchronize(G.stream));
+    return 0;
+}
+
 // ---- Mersenne Twister MT19937 (Matsumoto & Nishimura 1998; init_genrand / genrand_real1 of mt19937ar) -------
 // The reference's irng = 1 stream: src/mcica_random_numbers.f90:157-169 (scalar seeding), :262-295 (deviate on [0,1]).
 struct MT19937 {
@@ -613,6 +679,11 @@ void rrtmg_lw_hip_finalize(void)
     if (G.d_stat) (void)hipFree(G.d_stat);
     if (G.d_err) (void)hipFree(G.d_err);
     if (G.stream) (void)hipStreamDestroy(G.stream);
+    if (G.cp_in) {
+        (void)hipStreamDestroy(G.cp_in);
+        (void)hipStreamDestroy(G.cp_out);
+        for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_h2d[k]); (void)hipEventDestroy(G.ev_cmp[k]); (void)hipEventDestroy(G.ev_d2h[k]); }
+    }
     if (G.aux) {
         (void)hipStreamDestroy(G.aux);
         (void)hipStreamDestroy(G.sw);
@@ -728,6 +799,7 @@ int rrtmg_lw_hip_run_nomcica(
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = check_common(ncol, nlay)) return rc;
+    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
@@ -735,53 +807,27 @@ int rrtmg_lw_hip_run_nomcica(
     const bool cloud = *icld >= 1;          // inatm copies the cloud arrays only when icld >= 1 (:893-910)
     const int nbmax = std::min(ncol, G.batch);
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
-    const size_t n = (size_t)nbmax, L = (size_t)nlay;
-    // staging layout (doubles): 15 x (n,L), 2 x (n,L+1), tsfc n, emis 16n, tauaer 16 n L, [5 x (n,L) + 16 n L], outputs 6 x (n,L+1) + 2 x (n,L)
-    const size_t in_d = 15 * n * L + 2 * n * (L + 1) + n + 16 * n + 16 * n * L + (cloud ? 5 * n * L + 16 * n * L : 0);
-    const size_t out_d = 6 * n * (L + 1) + 2 * n * L;
-    if (int rc = ensure_stage((in_d + out_d) * 8 + 4096)) return rc;
-    double *p = (double *)G.stage_base;
-    auto take = [&](size_t cnt) { double *q = p; p += cnt; return q; };
-    double *d2[15];
-    for (auto &q : d2) q = take(n * L);
-    double *d_plev = take(n * (L + 1)), *d_tlev = take(n * (L + 1)), *d_tsfc = take(n), *d_emis = take(16 * n);
-    double *d_tauaer = take(16 * n * L);
-    double *d_cld[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *d_taucld = nullptr;
-    if (cloud) { for (auto &q : d_cld) q = take(n * L); d_taucld = take(16 * n * L); }
-    double *d_o1[6];
-    for (auto &q : d_o1) q = take(n * (L + 1));
-    double *d_hr = take(n * L), *d_hrc = take(n * L);
-    hipStream_t s = G.stream;
-    const double *h2[15] = {play, tlay, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, nullptr, nullptr, nullptr};
-    const double *hcld[5] = {cldfr, cicewp, cliqwp, reice, reliq};
-    double *hout1[6] = {uflx, dflx, uflxc, dflxc, duflx_dt, duflxc_dt};
-    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
-        const int nb = std::min(nbmax, ncol - col0);
-        const size_t w = (size_t)nb * 8, sp = (size_t)ncol * 8;
-        for (int k = 0; k < 12; k++)
-            HIP_TRY(hipMemcpy2DAsync(d2[k], w, h2[k] + col0, sp, w, L, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpy2DAsync(d_plev, w, plev + col0, sp, w, L + 1, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpy2DAsync(d_tlev, w, tlev + col0, sp, w, L + 1, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_tsfc, tsfc + col0, w, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpy2DAsync(d_emis, w, emis + col0, sp, w, 16, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpy2DAsync(d_tauaer, w, tauaer + col0, sp, w, L * 16, hipMemcpyHostToDevice, s));
-        if (cloud) {
-            for (int k = 0; k < 5; k++)
-                HIP_TRY(hipMemcpy2DAsync(d_cld[k], w, hcld[k] + col0, sp, w, L, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpy2DAsync(d_taucld, 16 * w, taucld + (size_t)16 * col0, 16 * sp, 16 * w, L, hipMemcpyHostToDevice, s));
-        }
-        GcmIn g{d2[0], d_plev, d2[1], d_tlev, d_tsfc, d2[2], d2[3], d2[4], d2[5], d2[6], d2[7], d2[8], d2[9], d2[10], d2[11],
-                d_emis, d_cld[0], d_taucld, d_cld[1], d_cld[2], d_cld[3], d_cld[4], d_tauaer};
+    const size_t L = (size_t)nlay;
+    std::vector<HostIn> ins = {
+        {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
+        {h2ovmr, 1, L, 0}, {o3vmr, 1, L, 0}, {co2vmr, 1, L, 0}, {ch4vmr, 1, L, 0}, {n2ovmr, 1, L, 0}, {o2vmr, 1, L, 0},
+        {cfc11vmr, 1, L, 0}, {cfc12vmr, 1, L, 0}, {cfc22vmr, 1, L, 0}, {ccl4vmr, 1, L, 0}, {emis, 1, 16, 0}, {tauaer, 1, 16 * L, 0},
+        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, NBND, L, 0}, {cloud ? cicewp : nullptr, 1, L, 0},
+        {cloud ? cliqwp : nullptr, 1, L, 0}, {cloud ? reice : nullptr, 1, L, 0}, {cloud ? reliq : nullptr, 1, L, 0}};
+    for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
+    if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
+    std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
+                                 {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
+    for (size_t k = 0; k < 6; k++) if (!outs[k].h) return fail(RRTMG_LW_HIP_EARG, "null output array");
+    auto body = [&](hipStream_t s, int nb, std::vector<HostIn> &in, std::vector<HostOut> &out_) -> int {
+        GcmIn g{in[0].d, in[1].d, in[2].d, in[3].d, in[4].d, in[5].d, in[6].d, in[7].d, in[8].d, in[9].d, in[10].d,
+                in[11].d, in[12].d, in[13].d, in[14].d, in[15].d, in[17].d, in[18].d, in[19].d, in[20].d, in[21].d, in[22].d, in[16].d};
         ColIn c{};
-        FluxOut out{d_o1[0], d_o1[1], d_hr, d_o1[2], d_o1[3], d_hrc, d_o1[4], d_o1[5], nullptr, nullptr};
-        if (int rc = run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out)) return rc;
-        const int nout = idrv == 1 ? 6 : 4;
-        for (int k = 0; k < nout; k++)
-            HIP_TRY(hipMemcpy2DAsync(hout1[k] + col0, sp, d_o1[k], w, w, L + 1, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpy2DAsync(hr + col0, sp, d_hr, w, w, L, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpy2DAsync(hrc + col0, sp, d_hrc, w, w, L, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
+        FluxOut out{out_[0].d, out_[1].d, out_[2].d, out_[3].d, out_[4].d, out_[5].d, out_[6].d, out_[7].d, nullptr, nullptr};
+        return run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out);
+    };
+    if (int rc = host_pipeline(ncol, nbmax, ins, outs, body)) return rc;
+    hipStream_t s = G.stream;
     return read_physics_error(s);
 }
 
@@ -797,6 +843,7 @@ int rrtmg_lw_hip_run_columns(
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = check_common(ncol, nlayers)) return rc;
+    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
     if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns handles at most one batch (%d columns)", G.batch);
     const int mode = icld == 0 ? 0 : (icld == 1 ? 1 : 2);
@@ -846,6 +893,7 @@ int rrtmg_lw_hip_run_columns_mcica(
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = check_common(ncol, nlayers)) return rc;
+    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
     if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns_mcica handles at most one batch (%d columns)", G.batch);
     const int mode = icld == 0 ? 0 : 3;
@@ -881,6 +929,25 @@ int rrtmg_lw_hip_run_columns_mcica(
     double *ho[10] = {totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, dtotuflux_dt, dtotuclfl_dt};
     for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(ho[k], o[k], n * (L + 1) * 8, hipMemcpyDeviceToHost, s));
     return read_physics_error(s);
+}
+
+// Pin a host array the caller will pass repeatedly (a GCM's profile and flux arrays live for the whole run): the H2D / D2H copies
+// of the host-pointer entries then run as asynchronous DMA at PCIe rate instead of through the runtime's pageable staging.
+int rrtmg_lw_hip_host_register(void *ptr, long long bytes)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
+    if (!ptr || bytes <= 0) return fail(RRTMG_LW_HIP_EARG, "bad host range");
+    HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int rrtmg_lw_hip_host_unregister(void *ptr)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ptr) return fail(RRTMG_LW_HIP_EARG, "null pointer");
+    HIP_TRY(hipHostUnregister(ptr));
+    return 0;
 }
 
 // Streams `bytes` from one device buffer into another with 16 B per lane (k_calibrate): known traffic for PMC calibration.
@@ -941,6 +1008,7 @@ int rrtmg_lw_hip_run_mcica(
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = check_common(ncol, nlay)) return rc;
+    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
@@ -982,6 +1050,7 @@ int rrtmg_lw_hip_get_alpha(int ncol, int nlay, int icld, int idcor, double decor
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = check_common(ncol, nlay)) return rc;
+    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!(icld == 4 || icld == 5)) return 0;                      // alpha is only defined for the exponential overlaps
     const size_t n = (size_t)ncol, L = (size_t)nlay;
     std::vector<HostIn> ins = {{dz, 1, L, 0}, {lat, 1, 1, 0}, {cldfrac, 1, L, 0}};
@@ -1021,6 +1090,7 @@ int rrtmg_lw_hip_mcica_subcol(
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
+    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (icld == 0) return 0;
     const size_t n = (size_t)ncol, L = (size_t)nlay;
     const bool two = icld == 4 || icld == 5;
@@ -1098,6 +1168,7 @@ int rrtmg_lw_hip_run_mcica_subcol(
     std::lock_guard<std::mutex> lk(g_mu);
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
+    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int icld_gen = *icld;
     if (*icld > 3) *icld = 2;

@@ -180,3 +180,25 @@ def test_reinitialisation(hip, oracle):
     hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
     assert np.array_equal(a["uflx"], b["uflx"])
     np.testing.assert_allclose(b["hr"] * 1003.5, a["hr"] * 1004.0, rtol=1e-12, atol=1e-12)
+
+
+def test_pinned_host_arrays_and_pipelined_batches(hip, oracle):
+    """Host-pointer entry with arrays pinned through rrtmg_lw_hip_host_register and several column batches in flight
+    (H2D | kernels | D2H pipeline): same results as with pageable arrays, and as the oracle."""
+    d = make_gcm_inputs(1100, 51, "cloudy", col0=3)
+    hip.set_batch(256)
+    try:
+        plain = hip.rrtmg_lw_from_dict(d)
+        out = hip._out_arrays(1100, 51, d["idrv"])
+        pinned = [v for v in list(d.values()) + list(out.values()) if isinstance(v, np.ndarray) and v.flags.f_contiguous and v.dtype == np.float64]
+        for v in pinned:
+            hip.host_register(v)
+        got = hip.rrtmg_lw_from_dict(d, out=out)
+        for v in pinned:
+            hip.host_unregister(v)
+    finally:
+        hip.set_batch(32768)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(got[k], plain[k]), k
+    ref = oracle.rrtmg_lw(1100, 51, d["icld"], d["idrv"], d)
+    _compare(got, ref, d["idrv"], "pinned host arrays, 5 batches")
