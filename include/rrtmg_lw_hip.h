@@ -196,7 +196,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     double *duflx_dt, double *duflxc_dt, void *stream);
 
 /* Tuning / introspection ------------------------------------------------------------------------- */
-/* Columns processed per internal batch (bounds the device workspace); default 32768. */
+/* Columns processed per internal batch (bounds the device workspace); default 65536 (about 0.65 MB of device workspace per column at 72 layers). */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
 /* Device-pointer entries run k_sweep/k_flux of column batch i on a second stream while k_layer of batch i+1 runs on the
  * caller's stream (two scratch sets).  on = 0 serialises them again (halves the scratch workspace actually touched). */
