@@ -202,3 +202,37 @@ def test_pinned_host_arrays_and_pipelined_batches(hip, oracle):
         assert np.array_equal(got[k], plain[k]), k
     ref = oracle.rrtmg_lw(1100, 51, d["icld"], d["idrv"], d)
     _compare(got, ref, d["idrv"], "pinned host arrays, 5 batches")
+
+
+def _special_cloud_inputs(ncol, nlay, kind):
+    """Cloud configurations the random synthetic set does not reach: prescribed cloud optical depths (inflag 0),
+    overcast layers and equal fractions in adjacent layers (the `==` branches of rtrnmr's overlap factors)."""
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=55)
+    rng = np.random.default_rng(7)
+    cf = np.array(d["cldfr"])
+    if kind == "inflag0":
+        d["inflglw"], d["iceflglw"], d["liqflglw"] = 0, 0, 0
+        tau = rng.uniform(0.05, 8.0, (16, ncol, nlay)) * (cf > 0)[None, :, :]
+        d["taucld"] = np.asfortranarray(tau)
+    elif kind == "overcast":
+        cloudy = cf > 0
+        cf[cloudy & (rng.random(cf.shape) < 0.4)] = 1.0
+        for l in range(1, nlay):                      # equal fractions in neighbouring cloudy layers
+            same = cloudy[:, l] & cloudy[:, l - 1] & (rng.random(ncol) < 0.3)
+            cf[same, l] = cf[same, l - 1]
+        d["cldfr"] = np.asfortranarray(cf)
+    elif kind == "thin":
+        d["cldfr"] = np.asfortranarray(np.where(cf > 0, np.where(rng.random(cf.shape) < 0.5, 5e-7, 2e-6), 0.0))   # around rtrn's 1e-6 threshold
+    return d
+
+
+@pytest.mark.parametrize("kind", ["inflag0", "overcast", "thin"])
+@pytest.mark.parametrize("icld", [1, 2])
+def test_special_cloud_configurations(hip, oracle, kind, icld):
+    ncol, nlay = 300, 60
+    d = _special_cloud_inputs(ncol, nlay, kind)
+    got = hip.rrtmg_lw_from_dict(d, icld=icld)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+    _compare(got, ref, d["idrv"], f"{kind} icld={icld}")
+    if kind != "thin":
+        assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0

@@ -146,3 +146,24 @@ def test_live_reference_if_built(oracle):
         b = ref.rrtmg_lw(12, nlay, icld, d["idrv"], d)
         for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt"):
             assert np.abs(a[k] - b[k]).max() <= TOL, (cfg, k)
+
+
+@pytest.mark.parametrize("kind", ["inflag0", "overcast", "thin"])
+def test_live_reference_special_clouds(oracle, kind):
+    """The oracle against the reference's Fortran on the cloud configurations of tests/test_hip_parity.py::
+    test_special_cloud_configurations (prescribed optical depths, overcast / equal neighbouring fractions, fractions
+    around rtrn's 1e-6 threshold)."""
+    from oracle.bindings import Reference
+    if not Reference.available("nomcica"):
+        pytest.skip("oracle/_ref not built (needs /root/reference and flang)")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("thp", os.path.join(os.path.dirname(__file__), "test_hip_parity.py"))
+    thp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(thp)
+    ref = Reference("nomcica")
+    d = thp._special_cloud_inputs(40, 60, kind)
+    for icld in (1, 2):
+        a = oracle.rrtmg_lw(40, 60, icld, d["idrv"], d)
+        b = ref.rrtmg_lw(40, 60, icld, d["idrv"], d)
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+            assert np.abs(a[k] - b[k]).max() <= TOL, (kind, icld, k)
