@@ -95,6 +95,16 @@ const char *physics_message(int code)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// columns per batch: the fewest batches that respect G.batch, of (nearly) equal size - a short last batch would leave the
+// pipelines (prep / layer / sweep of neighbouring batches) unbalanced, e.g. 125000 columns -> 2 x 62720 rather than 65536 + 59464
+int balanced_batch(int ncol, int cap)
+{
+    if (ncol <= cap) return ncol;
+    const int nbatch = (ncol + cap - 1) / cap;
+    const int nb = (int)align_up((size_t)(ncol + nbatch - 1) / nbatch, 256);
+    return std::min(nb, cap);
+}
+
 hipEvent_t get_event()
 {
     if (!G.evpool.empty()) { hipEvent_t e = G.evpool.back(); G.evpool.pop_back(); return e; }
@@ -345,7 +355,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
                   const FluxOut &out, const McIn *mc, KissGen gen = KissGen{false, 0, 0, nullptr})
 {
     if (int rc = ensure_pipeline()) return rc;
-    const int nbmax = std::min(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, G.batch);
     ColIn c{};
     // sub-column arrays mode keeps per-g-point cloud arrays (odg/cfef) in one set only: no layer/sweep overlap there
     const bool split = G.split_sweep && G.ws_two_scr && !(mode == 3 && mc);
@@ -786,7 +796,7 @@ int rrtmg_lw_hip_run_nomcica_device(
     if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.nomcica.f90:456
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);      // :546-560 (icld=0 -> rtrnmr clear branch)
-    const int nbmax = std::min(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, G.batch);
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
@@ -813,7 +823,7 @@ int rrtmg_lw_hip_run_nomcica(
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);
     const bool cloud = *icld >= 1;          // inatm copies the cloud arrays only when icld >= 1 (:893-910)
-    const int nbmax = std::min(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, G.batch);
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
     const size_t L = (size_t)nlay;
     std::vector<HostIn> ins = {
@@ -1000,7 +1010,7 @@ int rrtmg_lw_hip_run_mcica_device(
     if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.f90:469
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : 3;                         // inatm leaves the cloud arrays zero when icld = 0 (:899-911)
-    const int nbmax = std::min(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, G.batch);
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0, mode == 3)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tauaer};
@@ -1153,7 +1163,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     if (*icld > 3) *icld = 2;                                     // what rrtmg_lw does to the generator's icld (src/rrtmg_lw_rad.f90:469)
     const int mode = icld_gen == 0 ? 0 : 3;
     hipStream_t s = (hipStream_t)stream;
-    const int nbmax = std::min(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, G.batch);
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false)) return rc;      // mask path: no per-g-point cloud arrays
     KissGen gen{false, icld_gen, permuteseed, alpha};
     if (mode == 3) {
@@ -1182,7 +1192,7 @@ int rrtmg_lw_hip_run_mcica_subcol(
     if (*icld > 3) *icld = 2;
     const int mode = icld_gen == 0 ? 0 : 3;
     const bool cloud = mode == 3, two = icld_gen == 4 || icld_gen == 5;
-    const int nbmax = std::min(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, G.batch);
     if (int rc = ensure_workspace(nlay, nbmax, cloud, false)) return rc;
     const size_t L = (size_t)nlay, n = (size_t)ncol;
     hipStream_t s = G.stream;
