@@ -10,7 +10,7 @@ python3 bench.py --steps 5 --warmup 2 > $O/bench_1e6.json 2> $O/bench_1e6.err
 python3 bench.py --steps 3 --warmup 1 --mcica 5 --no-cpu-baseline > $O/bench_1e6_mcica5.json 2> $O/bench_1e6_mcica5.err
 python3 bench.py --steps 3 --warmup 1 --config aer_idrv --nlay 137 --ncol 500000 --no-cpu-baseline > $O/bench_5e5_aer137.json 2> $O/bench_aer137.err
 python3 bench.py --steps 5 --warmup 2 --config clear --ncol 10000 --no-cpu-baseline > $O/bench_1e4_clear.json 2> $O/bench_1e4_clear.err
-rocprofv3 --kernel-trace --stats -d $O/stats -f csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -f csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --host-cols 0 > $O/stats.log 2>&1
 P=$O/pmc
 mkdir -p $P
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/fetch -f csv -- python3 tools/pmc_run.py > $P/fetch.log 2>&1
