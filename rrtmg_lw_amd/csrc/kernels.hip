@@ -1381,6 +1381,18 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
 #pragma unroll
         for (int w = 0; w < 5; w++) mw[w] = W.mask[((size_t)w * nlay + (lay - 1)) * W.mask_stride + W.mask_col0 + gc];
     }
+    if constexpr (FROMMASK) {
+        if ((mw[0] | mw[1] | mw[2] | mw[3] | (mw[4] & 0xfffu)) == 0u) {       // no cloudy sub-column in this layer (140 = 4 x 32 + 12 bits)
+            for (int b = 0; b < NBND; b++) {
+                const size_t o = ((size_t)b * nlay + (lay - 1)) * ncb + col;
+                W.odcld[o] = 0.0;
+                W.efcl[o] = 0.0;
+            }
+            W.cflag[(size_t)lay * ncb + col] = 0;
+            if (lay == 1) W.cflag[(size_t)(nlay + 1) * ncb + col] = 0;
+            return;
+        }
+    }
     // particle-size interpolation positions (band independent): cldprmc :208-262
     int ice_err = 0, liq_err = 0, index_i = 1, index_l = 1;
     double fint_i = 0.0, fint_l = 0.0;
