@@ -154,6 +154,36 @@ def rrtmg_lw_device(d, out, icld=None, idrv=None, stream=None):
     return icld_c.value
 
 
+def mcica_subcol_device(d, sub, icld, permuteseed, irng, alpha=None, stream=None):
+    """Device-resident mcica_subcol_lw: `d` as for rrtmg_lw_device (play, cldfr, cicewp, cliqwp, reice, reliq, taucld), `sub` a dict of
+    preallocated torch tensors cldfmcl, ciwpmcl, clwpmcl, taucmcl (g fastest: shape (nlay, ncol, 140) contiguous) and reicmcl, relqmcl."""
+    irng_c = C.c_int(int(irng))
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    args = [C.c_int(d["ncol"]), C.c_int(d["nlay"]), C.c_int(int(icld)), C.c_int(int(permuteseed)), C.byref(irng_c)]
+    args += [ptr(d[k]) for k in ("play", "cldfr", "cicewp", "cliqwp", "reice", "reliq", "taucld")]
+    args += [ptr(alpha) if alpha is not None else C.c_void_p(0)]
+    args += [ptr(sub[k]) for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")]
+    args.append(C.c_void_p(stream or 0))
+    _check(lib().rrtmg_lw_hip_mcica_subcol_device(*args))
+    return irng_c.value
+
+
+def rrtmg_lw_mcica_device(d, sub, out, icld=None, idrv=None, stream=None):
+    """Device-resident McICA rrtmg_lw with explicit sub-column arrays (the reference's argument list, src/rrtmg_lw_rad.f90:99-108)."""
+    icld = d["icld"] if icld is None else icld
+    idrv = d["idrv"] if idrv is None else idrv
+    icld_c = C.c_int(int(icld))
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    args = [C.c_int(d["ncol"]), C.c_int(d["nlay"]), C.byref(icld_c), C.c_int(int(idrv))]
+    args += [ptr(d[k]) for k in _GCM_ORDER]
+    args += [C.c_int(int(d["inflglw"])), C.c_int(int(d["iceflglw"])), C.c_int(int(d["liqflglw"]))]
+    args += [ptr(sub[k]) for k in ("cldfmcl", "taucmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl")] + [ptr(d["tauaer"])]
+    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")]
+    args.append(C.c_void_p(stream or 0))
+    _check(lib().rrtmg_lw_hip_run_mcica_device(*args))
+    return icld_c.value
+
+
 def check(stream=None):
     _check(lib().rrtmg_lw_hip_check(C.c_void_p(stream or 0)))
 
