@@ -946,6 +946,34 @@ struct LayerArgs {
 
 struct alignas(16) scr4 { scr_t v[4]; };
 
+// The per-cell scratch is written once by k_layer and read once (twice for atrans) by k_sweep, gigabytes later: streaming
+// (non-temporal) accesses keep it from evicting the absorption tables and LUTs from L2.
+#ifndef RRLW_SCR_DOUBLE
+typedef float scr_vec __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &v)
+{
+#ifdef RRLW_NO_NT
+    reinterpret_cast<scr4 *>(base)[cell] = v;
+#else
+    scr_vec x = {v.v[0], v.v[1], v.v[2], v.v[3]};
+    __builtin_nontemporal_store(x, reinterpret_cast<scr_vec *>(base) + cell);
+#endif
+}
+__device__ __forceinline__ scr4 scr_load(const scr4 *p)
+{
+#ifdef RRLW_NO_NT
+    return *p;
+#else
+    const scr_vec x = __builtin_nontemporal_load(reinterpret_cast<const scr_vec *>(p));
+    scr4 v; v.v[0] = x.x; v.v[1] = x.y; v.v[2] = x.z; v.v[3] = x.w;
+    return v;
+#endif
+}
+#else
+__device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &v) { reinterpret_cast<scr4 *>(base)[cell] = v; }
+__device__ __forceinline__ scr4 scr_load(const scr4 *p) { return *p; }
+#endif
+
 // transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
 __device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * fdiv(od, bpade + od) + 0.5); }
 
@@ -1012,9 +1040,9 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
                 obbu.v[k] = (scr_t)(frac[j] * (blay + tfn * dplankup));
             }
             const size_t so = so0 + q * qstride;
-            reinterpret_cast<scr4 *>(W.scr[S_ATR])[so] = oatr;
-            reinterpret_cast<scr4 *>(W.scr[S_BBD])[so] = obbd;
-            reinterpret_cast<scr4 *>(W.scr[S_BBU])[so] = obbu;
+            scr_store(W.scr[S_ATR], so, oatr);
+            scr_store(W.scr[S_BBD], so, obbd);
+            scr_store(W.scr[S_BBU], so, obbu);
         }
     } else {
         // cloudy layer, the three sub-branches of rtrn :372-435 in predicated form:
@@ -1090,12 +1118,12 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
                         obbut.v[kk] = (scr_t)(frac[j] * (blay + tftot * dplankup));
                     }
                     const size_t so = so0 + (q0 + q) * qstride;
-                    reinterpret_cast<scr4 *>(W.scr[S_ATR])[so] = oatr;
-                    reinterpret_cast<scr4 *>(W.scr[S_BBD])[so] = obbd;
-                    reinterpret_cast<scr4 *>(W.scr[S_BBU])[so] = obbu;
-                    reinterpret_cast<scr4 *>(W.scr[S_ATOT])[so] = oatot;
-                    reinterpret_cast<scr4 *>(W.scr[S_BBDTOT])[so] = obbdt;
-                    reinterpret_cast<scr4 *>(W.scr[S_BBUTOT])[so] = obbut;
+                    scr_store(W.scr[S_ATR], so, oatr);
+                    scr_store(W.scr[S_BBD], so, obbd);
+                    scr_store(W.scr[S_BBU], so, obbu);
+                    scr_store(W.scr[S_ATOT], so, oatot);
+                    scr_store(W.scr[S_BBDTOT], so, obbdt);
+                    scr_store(W.scr[S_BBUTOT], so, obbut);
                 }
             }
         }
@@ -1853,8 +1881,8 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
             pF[i] = 0;
             if (active && lev >= 1) {
                 const size_t so = (size_t)(lev - 1) * ncb;
-                pA[i] = sA[so];
-                pB[i] = sBd[so];
+                pA[i] = scr_load(sA + so);
+                pB[i] = scr_load(sBd + so);
                 if constexpr (MODE != 0) pF[i] = W.cflag[(size_t)lev * ncb + col];
             }
         }
@@ -1900,7 +1928,7 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
             } else {
                 if constexpr (MODE != 0) {
                     iclddn = 1;
-                    const scr4 vatot = sT[so], vbbdt = sTd[so];
+                    const scr4 vatot = scr_load(sT + so), vbbdt = scr_load(sTd + so);
                     double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
                     if constexpr (MODE == 2) {
                         const size_t mo = (size_t)(lev - 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
@@ -1990,8 +2018,8 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
             pF[i] = 0;
             if (active && lev >= 1 && lev <= nlay) {
                 const size_t so = (size_t)(lev - 1) * ncb;
-                pA[i] = sA[so];
-                pB[i] = sBu[so];
+                pA[i] = scr_load(sA + so);
+                pB[i] = scr_load(sBu + so);
                 if constexpr (MODE != 0) pF[i] = W.cflag[(size_t)lev * ncb + col];
             }
         }
@@ -2044,7 +2072,7 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
                 }
             } else {
                 if constexpr (MODE != 0) {
-                    const scr4 vatot = sT[so], vbbut = sTu[so];
+                    const scr4 vatot = scr_load(sT + so), vbbut = scr_load(sTu + so);
                     double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
                     if constexpr (MODE == 2) {
                         const size_t mo = (size_t)(lev + 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
