@@ -1131,7 +1131,9 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 }
 
 #ifndef RRLW_LAYER_WAVES
-#define RRLW_LAYER_WAVES 1        // waves per SIMD k_layer is compiled for; measured: 1 (no spills, deep ILP) beats 2 (25.9 vs 29.0 ms / 262144 columns)
+#define RRLW_LAYER_WAVES 2        // waves per SIMD k_layer is compiled for: with 8-load chunks it needs 200-230 VGPRs, no spills.  VALU operands
+                                  // must be architectural VGPRs (<= 256; AGPRs are only spill space), so a 512-register budget buys nothing;
+                                  // 3 waves (<= 168 VGPRs) spills 10-40 dwords and is slower (25.1 vs 21.3 ms / 262144 columns)
 #endif
 
 // all quads of band B for one (layer, column)
