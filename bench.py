@@ -68,11 +68,12 @@ def main():
         args.gpus = world
 
     # ---- CPU baseline first: worker processes are spawned, which must happen before this process touches the GPU
-    cpu = None
+    cpu, cpu_sample = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import measure
-        cpu = measure(nlay=args.nlay, config=args.config, cols_per_core=args.cpu_cols_per_core)
+        cpu = measure(nlay=args.nlay, config=args.config, cols_per_core=args.cpu_cols_per_core, sample_cols=0 if args.mcica else 256)
         cpu.pop("wall_s", None)
+        cpu_sample = cpu.pop("sample_outputs", None)
 
     import torch
     import torch.distributed as dist
@@ -239,6 +240,16 @@ def main():
         except Exception as ex:          # registration is optional
             e2e["pinned"] = dict(error=str(ex)[:120])
         del dh
+
+    if rank == 0 and cpu is not None and cpu_sample is not None:
+        # parity of the timed GPU outputs with the CPU baseline's own results on the first 256 columns of the workload
+        import numpy as np
+        n = cpu_sample["uflx"].shape[0]
+        o = outs[(step_no[0] - 1) & 1]
+        g = {k: o[k][:, :n].T.cpu().numpy() for k in cpu_sample}
+        cpu["gpu_vs_this_baseline"] = dict(
+            columns=n, max_abs_dflux_W_m2=float(max(np.abs(g[k] - cpu_sample[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))),
+            max_abs_dhr_K_day=float(max(np.abs(g[k] - cpu_sample[k]).max() for k in ("hr", "hrc"))))
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps

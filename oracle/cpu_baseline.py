@@ -32,6 +32,18 @@ def _worker(args):
     return time.perf_counter() - t0
 
 
+def _sample_worker(args):
+    ncol, nlay, config, kind = args
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle.bindings import Oracle, Reference
+    from rrtmg_lw_amd.synth import make_gcm_inputs
+    eng = Reference("nomcica") if kind == "reference" else Oracle()
+    d = make_gcm_inputs(ncol, nlay, config, col0=0)
+    o = eng.rrtmg_lw(ncol, nlay, d["icld"], d["idrv"], d)
+    return {k: o[k] for k in ("uflx", "dflx", "uflxc", "dflxc", "hr", "hrc")}
+
+
 def usable_cores():
     """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256
     hardware threads but a cpu.max of 16 CPUs; oversubscribing the quota only adds throttling)."""
@@ -45,7 +57,7 @@ def usable_cores():
     return n
 
 
-def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None):
+def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None, sample_cols=0):
     from oracle.bindings import Reference
     kind = "reference" if Reference.available("nomcica") else "port"
     if cores is None:
@@ -54,13 +66,15 @@ def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None):
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
         times = list(ex.map(_worker, jobs))
-    wall = time.perf_counter() - t0
+        wall = time.perf_counter() - t0
+        # the baseline's own results for the first `sample_cols` columns of the workload: bench.py compares the GPU's with them
+        sample = ex.submit(_sample_worker, (sample_cols, nlay, config, kind)).result() if sample_cols > 0 else None
     total = cols_per_core * cores
     tmax = max(times)
     return dict(value=total / tmax, unit="columns/s", cores=cores, kind=kind,
                 sample=f"{total} synthetic {nlay}-layer '{config}' columns ({cols_per_core} per process, one process per core, "
                        f"slowest process {tmax:.2f} s, {sum(times):.1f} core-seconds; single-core rate {cols_per_core / (sum(times) / cores):.0f} columns/s)",
-                wall_s=wall)
+                wall_s=wall, sample_outputs=sample)
 
 
 if __name__ == "__main__":
