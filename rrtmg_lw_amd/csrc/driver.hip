@@ -38,6 +38,8 @@ struct State {
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; double *rad0; } scrset[2] = {};
     hipStream_t aux = nullptr, sw = nullptr;
+    hipEvent_t ev_last = nullptr;           // end of the previous device-entry call (calls on different streams share the workspace)
+    bool ev_last_valid = false;
     hipEvent_t ev_in = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_layer[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     // McICA sub-column masks of all columns of the current call
     unsigned *mask = nullptr;
@@ -337,6 +339,7 @@ int ensure_pipeline()
     HIP_TRY(hipStreamCreateWithFlags(&G.aux, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&G.sw, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&G.ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&G.ev_last, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
         HIP_TRY(hipEventCreateWithFlags(&G.ev_ready[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&G.ev_layer[k], hipEventDisableTiming));
@@ -359,6 +362,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
     ColIn c{};
     // sub-column arrays mode keeps per-g-point cloud arrays (odg/cfef) in one set only: no layer/sweep overlap there
     const bool split = G.split_sweep && G.ws_two_scr && !(mode == 3 && mc);
+    if (G.ev_last_valid) HIP_TRY(hipStreamWaitEvent(s, G.ev_last, 0));      // an earlier call, possibly on another stream, still owns the workspace
     HIP_TRY(hipEventRecord(G.ev_in, s));                 // inputs are ready when the caller's stream gets here
     HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_in, 0));
     int i = 0;
@@ -388,6 +392,8 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
     if (split) {                                  // the caller's stream sees the results of every batch
         for (int k = 0; k < std::min(i, 2); k++) HIP_TRY(hipStreamWaitEvent(s, G.ev_done[k], 0));
     }
+    HIP_TRY(hipEventRecord(G.ev_last, s));
+    G.ev_last_valid = true;
     return 0;
 }
 
@@ -705,6 +711,7 @@ void rrtmg_lw_hip_finalize(void)
         (void)hipStreamDestroy(G.aux);
         (void)hipStreamDestroy(G.sw);
         (void)hipEventDestroy(G.ev_in);
+        (void)hipEventDestroy(G.ev_last);
         for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_ready[k]); (void)hipEventDestroy(G.ev_layer[k]); (void)hipEventDestroy(G.ev_done[k]); }
     }
     G = State();

@@ -236,3 +236,33 @@ def test_special_cloud_configurations(hip, oracle, kind, icld):
     _compare(got, ref, d["idrv"], f"{kind} icld={icld}")
     if kind != "thin":
         assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
+
+
+def test_device_entry_from_two_streams(hip, oracle):
+    """Two callers enqueue device-resident work on different streams without synchronising in between: the driver orders the
+    second call after the first (they share the workspace)."""
+    import torch
+    from rrtmg_lw_amd.shard import output_rows, output_views
+    dev = torch.device("cuda", 0)
+    ncol, nlay = 3000, 72
+    da = make_gcm_inputs(ncol, nlay, "cloudy", col0=0, backend="torch", device=dev)
+    db = make_gcm_inputs(ncol, nlay, "cloudy", col0=50_000, backend="torch", device=dev)
+    oa = output_views(torch.zeros((output_rows(nlay), ncol), dtype=torch.float64, device=dev), nlay)
+    ob = output_views(torch.zeros((output_rows(nlay), ncol), dtype=torch.float64, device=dev), nlay)
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    hip.set_batch(512)
+    try:
+        for _ in range(3):
+            hip.rrtmg_lw_device(da, oa, stream=sa.cuda_stream)
+            hip.rrtmg_lw_device(db, ob, stream=sb.cuda_stream)
+        hip.check(sa.cuda_stream)
+        hip.check(sb.cuda_stream)
+    finally:
+        hip.set_batch(65536)
+    for d0, o in ((0, oa), (50_000, ob)):
+        dn = make_gcm_inputs(200, nlay, "cloudy", col0=d0)
+        ref = oracle.rrtmg_lw(200, nlay, dn["icld"], dn["idrv"], dn)
+        got = {k: o[k][:, :200].T.cpu().numpy() for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")}
+        got["icld"] = ref["icld"]
+        _compare(got, ref, 0, f"two streams, col0={d0}")
