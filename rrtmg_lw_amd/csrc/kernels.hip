@@ -1142,17 +1142,22 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 // one exposed HBM latency per band, which dominated k_layer at one wave per SIMD)
 struct BandIn { double blay, dplankup, dplankdn, secdiff, taua, odcld; };
 
-template <int B, int CLOUD>
-__device__ __forceinline__ BandIn band_inputs(const DevTables &T, const Workspace &W, const LayerArgs &a, int lay, int col, size_t gc,
-                                              int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
+// Prefetching the per-band inputs in the prologue pays only while a launch covers few bands (6+ groups); with all 16 bands in
+// one launch the live registers cost more than the exposed latency (measured per 1e6 columns: 6 groups + prefetch 145.5 ms,
+// 3 groups + partial prefetch 141.0 ms, 1 group without prefetch 141.8 ms and 156 vs 160-162 ms for McICA).
+#ifndef RRLW_PREFETCH_PLANCK
+#define RRLW_PREFETCH_PLANCK 0     // 1: the Planck terms of every band of the group are formed in the prologue too (more live registers)
+#endif
+#ifndef RRLW_PREFETCH_BANDIN
+#define RRLW_PREFETCH_BANDIN 0     // 1: secdiff / tauaer / odcld of every band of the group are fetched in the prologue
+#endif
+
+// Planck functions of the layer and of its two interfaces: setcoef :203-269
+template <int B>
+__device__ __forceinline__ void band_planck(const DevTables &T, const LayerArgs &a, int lay, int indlay, double tlayfrac, int indhi,
+                                            double thifrac, int indlo, double tlofrac, BandIn &in)
 {
-    const size_t ncb = W.ncolb;
-    const int nlay = W.nlay, nct = a.nct;
     const double *S = T.stat;
-    BandIn in;
-    in.odcld = 0.0;
-    if constexpr (CLOUD == 1 || CLOUD == 3) in.odcld = W.odcld[((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col];   // zero for clear layers (k_cloud / k_cloudmc)
-    // Planck functions of the layer and of its two interfaces: setcoef :203-269
     const bool alt16 = (B == 16 && a.istart == 16);
     const double *tp = alt16 ? S + T.sl.totplk16 : S + T.sl.totplnk + 181 * (B - 1);
     const double blay = tp[indlay - 1] + tlayfrac * (tp[indlay] - tp[indlay - 1]);
@@ -1167,6 +1172,20 @@ __device__ __forceinline__ BandIn band_inputs(const DevTables &T, const Workspac
     in.blay = blay;
     in.dplankup = plev_hi - blay;
     in.dplankdn = plev_lo - blay;
+}
+
+template <int B, int CLOUD>
+__device__ __forceinline__ BandIn band_inputs(const DevTables &T, const Workspace &W, const LayerArgs &a, int lay, int col, size_t gc,
+                                              int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
+{
+    if (!RRLW_PREFETCH_BANDIN) return BandIn{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const size_t ncb = W.ncolb;
+    const int nlay = W.nlay, nct = a.nct;
+    BandIn in;
+    in.blay = in.dplankup = in.dplankdn = 0.0;
+    in.odcld = 0.0;
+    if constexpr (CLOUD == 1 || CLOUD == 3) in.odcld = W.odcld[((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col];   // zero for clear layers (k_cloud / k_cloudmc)
+    if (RRLW_PREFETCH_PLANCK) band_planck<B>(T, a, lay, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, in);
     in.secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
     in.taua = a.tauaer[gc + (size_t)nct * ((lay - 1) + (size_t)nlay * (B - 1))];
     return in;
@@ -1174,15 +1193,29 @@ __device__ __forceinline__ BandIn band_inputs(const DevTables &T, const Workspac
 
 __device__ __forceinline__ void pin(BandIn &in)
 {
+#if !RRLW_PREFETCH_BANDIN
+    (void)in;
+#elif RRLW_PREFETCH_PLANCK
     asm volatile("" : "+v"(in.blay), "+v"(in.dplankup), "+v"(in.dplankdn), "+v"(in.secdiff), "+v"(in.taua), "+v"(in.odcld));
+#else
+    asm volatile("" : "+v"(in.secdiff), "+v"(in.taua), "+v"(in.odcld));
+#endif
 }
 
 // all cells of band B for one (layer, column)
 template <int B, int CLOUD>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
-                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const BandIn &in,
-                                           const unsigned (&mw)[5])
+                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const BandIn &in_,
+                                           const unsigned (&mw)[5], int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
 {
+    BandIn in = in_;
+    if (!RRLW_PREFETCH_BANDIN) {
+        const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
+        if constexpr (CLOUD == 1 || CLOUD == 3) in.odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col];
+        in.secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
+        in.taua = a.tauaer[gcx + (size_t)a.nct * ((lay - 1) + (size_t)W.nlay * (B - 1))];
+    }
+    if (!RRLW_PREFETCH_PLANCK || !RRLW_PREFETCH_BANDIN) band_planck<B>(T, a, lay, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, in);
     unsigned gbits = 0u;
     if constexpr (CLOUD == 3) {
         constexpr int g0 = band_g0(B), ng = BT<B>::ng, w0 = g0 >> 5;
@@ -1211,9 +1244,10 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
 
 
 // band groups: one k_layer launch covers the bands of one group; its threads do the inatm/setcoef prologue once.
-// Fewer groups = less repeated prologue work, more groups = shorter kernels (RRLW_LAYER_GROUPS: 6, 3, 2 or 1).
+// Fewer groups = less repeated prologue work and fewer re-reads of the profile inputs, more groups = shorter kernels with
+// fewer live registers (RRLW_LAYER_GROUPS: 9, 6, 3, 2 or 1).  Default: one launch for all 16 bands.
 #ifndef RRLW_LAYER_GROUPS
-#define RRLW_LAYER_GROUPS 6
+#define RRLW_LAYER_GROUPS 1
 #endif
 constexpr int NLGROUP = RRLW_LAYER_GROUPS;
 
@@ -1240,7 +1274,7 @@ __device__ __forceinline__ void group_run(std::integer_sequence<int, K...>, cons
 {
     BandIn in[GB::n] = {band_inputs<GB::b[K], CLOUD>(T, W, a, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac)...};
     (pin(in[K]), ...);
-    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, in[K], mw) : (void)0), ...);
+    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, in[K], mw, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac) : (void)0), ...);
 }
 
 template <bool GCM, int CLOUD, int GROUP>
