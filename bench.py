@@ -48,7 +48,8 @@ def main():
                     help="McICA flavour (BASELINE configs[3]): sub-column generator with overlap ICLD (5 = exponential-random) "
                          "+ cldprmc + rtrnmc through the fused device entry; 0 = non-McICA rtrn/rtrnmr")
     ap.add_argument("--batch", type=int, default=0, help="columns per internal batch (0 = library default)")
-    ap.add_argument("--no-overlap", action="store_true", help="serialise k_layer and k_sweep of consecutive batches (tuning; -5 %)")
+    ap.add_argument("--no-overlap", action="store_true", help="serialise k_layer and k_sweep of consecutive batches (the library default)")
+    ap.add_argument("--overlap", action="store_true", help="run k_sweep of batch i beside k_layer of batch i+1 (tuning; second scratch set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols-per-core", type=int, default=6000)
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N > 1)")
@@ -94,6 +95,8 @@ def main():
         api.set_batch(args.batch)
     if args.no_overlap:
         api.set_overlap(False)
+    if args.overlap:
+        api.set_overlap(True)
 
     # contiguous column block of this rank
     from rrtmg_lw_amd.shard import column_block, output_rows, output_views

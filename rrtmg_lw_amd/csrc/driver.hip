@@ -36,7 +36,7 @@ struct State {
     struct PrepSet { double *percol; int *laytrop, *ncbands; double *taucloud, *odcld, *efcl, *mrfac; int *cflag; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by k_sweep exists twice as well: k_sweep/k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
-    struct ScrSet { scr_t *scr[NSCR]; double *rad0; } scrset[2] = {};
+    struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
     hipStream_t aux = nullptr, sw = nullptr;
     hipEvent_t ev_last = nullptr;           // end of the previous device-entry call (calls on different streams share the workspace)
     bool ev_last_valid = false;
@@ -45,8 +45,10 @@ struct State {
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
     int batch = 65536;      // columns per internal batch: ~0.65 MB of workspace per column at 72 layers (42 GB); measured 32768: 153 ms, 65536: 149 ms, 262144: 145 ms per 1e6 columns
-    bool split_sweep = true;     // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries): measured +5.6 %
+    bool split_sweep = false;    // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: k_sweep
+                                 // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -3 %)
                                  // at 65536-column batches (147.3 vs 155.6 ms per 1e6 columns)
+    bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device
     bool ws_two_scr = false;     // the workspace holds the second scratch set that needs
     // host-entry staging
     void *stage_base = nullptr;
@@ -129,6 +131,47 @@ hipEvent_t get_event()
         }                                                                                        \
     } while (0)
 
+// the same with dynamic LDS
+#define LAUNCH_LDS(NAME, KERNEL, GRID, BLOCKDIM, LDS, STREAM, ...)                               \
+    do {                                                                                         \
+        if (G.profile) {                                                                         \
+            State::ProfRec r_{NAME, get_event(), get_event()};                                   \
+            (void)hipEventRecord(r_.a, STREAM);                                                  \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, LDS, STREAM, __VA_ARGS__);                \
+            (void)hipEventRecord(r_.b, STREAM);                                                  \
+            G.prof.push_back(r_);                                                                \
+        } else {                                                                                 \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, LDS, STREAM, __VA_ARGS__);                \
+        }                                                                                        \
+    } while (0)
+
+// k_sweep stages the transmittance table in LDS: more than the 64 KB a kernel may use without asking
+template <int M, int Q>
+int sweep_attr_one()
+{
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M)));
+    return 0;
+}
+template <int M>
+int sweep_attr_mode()
+{
+    if (int rc = sweep_attr_one<M, 1>()) return rc;
+    if (int rc = sweep_attr_one<M, 2>()) return rc;
+    if (int rc = sweep_attr_one<M, 3>()) return rc;
+    return sweep_attr_one<M, 4>();
+}
+int ensure_sweep_attrs()
+{
+    if (G.sweep_attrs) return 0;
+    if (int rc = sweep_attr_mode<0>()) return rc;
+    if (int rc = sweep_attr_mode<1>()) return rc;
+    if (int rc = sweep_attr_mode<2>()) return rc;
+    if (int rc = sweep_attr_mode<3>()) return rc;
+    if (int rc = sweep_attr_mode<4>()) return rc;
+    G.sweep_attrs = true;
+    return 0;
+}
+
 // (re)allocate the per-batch workspace
 int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
 {
@@ -151,15 +194,9 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     for (int k = 0; k < (two_scr ? 2 : 1); k++) {
         State::ScrSet &ss = G.scrset[k];
         ss = State::ScrSet{};
-        items.push_back({(void **)&ss.scr[S_ATR], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-        items.push_back({(void **)&ss.scr[S_BBD], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-        items.push_back({(void **)&ss.scr[S_BBU], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-        items.push_back({(void **)&ss.rad0, (size_t)2 * NQUAD * 4 * n * 8});
-        if (cloud) {
-            items.push_back({(void **)&ss.scr[S_ATOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-            items.push_back({(void **)&ss.scr[S_BBDTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-            items.push_back({(void **)&ss.scr[S_BBUTOT], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
-        }
+        items.push_back({(void **)&ss.scr[S_CODE], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        items.push_back({(void **)&ss.fw, (size_t)NFW * L * n * sizeof(unsigned)});
+        if (cloud) items.push_back({(void **)&ss.scr[S_CODET], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
     }
     for (auto &ps : G.prep) {
         ps = State::PrepSet{};
@@ -189,7 +226,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     W.nlay = nlay;
     W.err = G.d_err;
     for (int a = 0; a < NSCR; a++) W.scr[a] = G.scrset[0].scr[a];
-    W.rad0 = G.scrset[0].rad0;
+    W.fw = G.scrset[0].fw;
     {   // G.W itself carries prep set 0 and scratch set 0
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
@@ -224,7 +261,7 @@ Workspace ws_for(int k)
     w.taucloud = ps.taucloud; w.odcld = ps.odcld; w.efcl = ps.efcl; w.mrfac = ps.mrfac;
     const State::ScrSet &ss = G.scrset[G.ws_two_scr ? k : 0];
     for (int a = 0; a < NSCR; a++) w.scr[a] = ss.scr[a];
-    w.rad0 = ss.rad0;
+    w.fw = ss.fw;
     return w;
 }
 
@@ -293,10 +330,13 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 {
     const dim3 block(BLOCK);
     const unsigned gx = (nb + BLOCK - 1) / BLOCK;
+    if (int rc = ensure_sweep_attrs()) return rc;
     SweepArgs sa;
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
     sa.emis = GCM ? g.emis : c.semiss;
     sa.cldfrac = GCM ? g.cldfr : c.cldfrac;
+    sa.tlay = GCM ? g.tlay : c.tavel;
+    sa.tlev = GCM ? g.tlev : c.tz;
     // one sweep launch per class of bands with the same number of quads (workgroup = 64 columns x that many waves)
     for (int nq = 4; nq >= 1; nq--) {
         unsigned long long list = 0ull;
@@ -305,8 +345,12 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             if (band_nquad(B) == nq && B >= istart && B <= iend) list |= (unsigned long long)(B - 1) << (4 * nb_bands++);
         if (nb_bands == 0) continue;
         sa.bands = list;
-        const dim3 sgrid((nb + 63) / 64, nb_bands), sblock(64, nq);
-#define SWEEP(M, Q) LAUNCH("k_sweep<" #M "," #Q ">", (k_sweep<M, Q>), sgrid, sblock, s, G.D, Wk, sa)
+#define SWEEP(M, Q)                                                                                                  \
+    do {                                                                                                             \
+        const int ns = sweep_ns(Q, M);                                                                               \
+        const dim3 sgrid((nb + 64 * ns - 1) / (64 * ns), nb_bands), sblock(64, Q, ns);                               \
+        LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q>), sgrid, sblock, sweep_lds_bytes(Q, M), s, G.D, Wk, sa);  \
+    } while (0)
 #define SWEEP_MODE(Q)                                                          \
         if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q);
         if (nq == 4) { SWEEP_MODE(4) } else if (nq == 3) { SWEEP_MODE(3) } else if (nq == 2) { SWEEP_MODE(2) } else { SWEEP_MODE(1) }
@@ -658,6 +702,7 @@ int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, do
     std::string err;
     if (!build_tables(static_tables_path, kdata_path, cpdair, G.H, err)) return fail(RRTMG_LW_HIP_EDATA, "%s", err.c_str());
     HIP_TRY(hipSetDevice(device));
+    G.sweep_attrs = false;
     if (G.d_ktab) { (void)hipFree(G.d_ktab); G.d_ktab = nullptr; }
     if (G.d_stat) { (void)hipFree(G.d_stat); G.d_stat = nullptr; }
     HIP_TRY(hipMalloc((void **)&G.d_ktab, G.H.ktab.size() * 8));

@@ -55,17 +55,14 @@ enum PerCol { PC_PLANKBND = 0, PC_DPLANKBND = 16, PC_SECDIFF = 32, NPERCOL = 48 
 // rtrnmr overlap factors, each [(nlay+2)][ncolb], level index 0..nlay+1
 enum MrFac { MR_FACCLD1, MR_FACCLD2, MR_FACCLR1, MR_FACCLR2, MR_FACCMB1, MR_FACCMB2,
              MR_FACCLD1D, MR_FACCLD2D, MR_FACCLR1D, MR_FACCLR2D, MR_FACCMB1D, MR_FACCMB2D, NMRFAC };
-// per-cell terms handed from k_layer to k_sweep, each [NQUAD][nlay][ncolb][4]
-enum Scr { S_ATR, S_BBD, S_BBU, S_ATOT, S_BBDTOT, S_BBUTOT, NSCR };
+// per-cell transmittance codes handed from k_layer to k_sweep, each [NQUAD][nlay][ncolb][4] (see cell_code):
+// gas optical depth of every cell, total (gas + cloud) optical depth of the cells of cloudy layers
+enum Scr { S_CODE, S_CODET, NSCR };
 // per-band partial fluxes, each [band][level][column] of {total-sky, clear-sky}: downward, upward, d(upward)/dT
 struct alignas(16) Part2 { double a, b; };
 
-// storage type of the per-cell terms handed from k_layer to k_sweep (all arithmetic stays float64)
-#ifdef RRLW_SCR_DOUBLE
-typedef double scr_t;
-#else
-typedef float scr_t;     // measured on MI355X: max |dflux| vs the oracle 6.66e-6 W m-2 (6.55e-6 with double), |dhr| unchanged
-#endif
+// storage type of the per-cell codes handed from k_layer to k_sweep (all arithmetic stays float64)
+typedef float scr_t;
 
 struct Workspace {
     int ncolb;          // column stride (batch capacity)
@@ -79,7 +76,7 @@ struct Workspace {
     double *mrfac;      // [NMRFAC][nlay+2][ncolb]
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcld, bit2 istcldd; cflag[0] bit3 = column has cloud
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
-    double *rad0;       // [2][4*NQUAD][ncolb]  fracs(1,g)*plankbnd, fracs(1,g)*dplankbnd_dt
+    unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
     Part2 *pdn, *pup;   // [16 bands][nlay+1][ncolb]
     Part2 *dpart;       // [16 bands][nlay+1][ncolb]  (idrv = 1)
     int *err;           // [1] first physics error code
@@ -685,9 +682,24 @@ template <int N>
 struct Rows {
     unsigned off[N > 0 ? N : 1];   // element offsets into the packed k-table buffer (row start, g = 0)
     double w[N > 0 ? N : 1];
-    unsigned foff;                 // Planck-fraction row
-    double fpl;                    // interpolation weight to the next fraction row (binary-key regions)
+    unsigned fw;                   // binary-key regions: Planck fractions are interpolated between rows js-1 and js of fracrefa/b with
+                                   // weight fs (taumol :556-561, :692-693); packed (js << 28) | fs in 28-bit fixed point for k_sweep
 };
+
+// binary-key bands get a slot in Workspace::fw (every band whose upper region is binary-key has a binary-key lower region too)
+template <int B> constexpr unsigned lo_binary_mask() { return (BT<B>::lo.key == K_BINARY ? 1u << (B - 1) : 0u) | lo_binary_mask<B - 1>(); }
+template <> constexpr unsigned lo_binary_mask<0>() { return 0u; }
+template <int B> constexpr unsigned up_binary_mask() { return (BT<B>::up.key == K_BINARY ? 1u << (B - 1) : 0u) | up_binary_mask<B - 1>(); }
+template <> constexpr unsigned up_binary_mask<0>() { return 0u; }
+template <int B> constexpr unsigned up_zero_mask() { return (BT<B>::up.key == K_ZERO ? 1u << (B - 1) : 0u) | up_zero_mask<B - 1>(); }
+template <> constexpr unsigned up_zero_mask<0>() { return 0u; }
+template <int B> constexpr unsigned up_from_a_mask() { return (BT<B>::up.frac_from_a ? 1u << (B - 1) : 0u) | up_from_a_mask<B - 1>(); }
+template <> constexpr unsigned up_from_a_mask<0>() { return 0u; }
+constexpr unsigned LO_BINARY = lo_binary_mask<16>(), UP_BINARY = up_binary_mask<16>(), UP_ZERO = up_zero_mask<16>(), UP_FROM_A = up_from_a_mask<16>();
+static_assert((UP_BINARY & ~LO_BINARY) == 0u, "fw slots are assigned by the lower region");
+__host__ __device__ constexpr int popcnt_c(unsigned v) { int n = 0; for (; v; v &= v - 1) n++; return n; }
+constexpr int NFW = popcnt_c(LO_BINARY);                                          // 9
+__host__ __device__ constexpr int fw_slot(int B) { return popcnt_c(LO_BINARY & ((1u << (B - 1)) - 1u)); }
 
 // one minor gas: rows IBASE.. of the list
 template <int B, bool LOWER, int N, int IM>
@@ -736,8 +748,7 @@ __device__ __forceinline__ void rows_prep(const DevTables &T, const LayerCoef &C
     const BandLayout &L = T.band[B - 1];
     const int jp = C.jp, jt = C.jt, jt1 = C.jt1;
     const double *rat_tab = T.stat + T.sl.rat;
-    rw.foff = (unsigned)((LOWER || R.frac_from_a) ? L.fracrefa : L.fracrefb);
-    rw.fpl = 0.0;
+    rw.fw = 0u;
     if constexpr (R.key == K_ZERO) return;
 
     double corradj = 1.;
@@ -799,8 +810,9 @@ __device__ __forceinline__ void rows_prep(const DevTables &T, const LayerCoef &C
         }
         // Planck fractions interpolated in the mixture: taumol :556-561, :692-693
         const Spec sp = spec_calc(cola, T.refrat[B - 1][R.planck_slot], colb, mult, T.oneminus);
-        rw.foff += (unsigned)(sp.js - 1) * ng;
-        rw.fpl = sp.fs;
+        unsigned q = (unsigned)(sp.fs * 268435456.0 + 0.5);
+        if (q > 268435455u) q = 268435455u;
+        rw.fw = ((unsigned)sp.js << 28) | q;
     }
     constexpr int IS = region_major_rows(R, LOWER);
     if constexpr (R.self_) {                                // taumol :350-351
@@ -858,8 +870,7 @@ struct BandLoads {
     static constexpr int ng = BT<B>::ng;
     static constexpr int HP = ng / 2;                                    // 16-byte loads per table row
     static constexpr int NK = N * HP;                                    // absorption-coefficient loads
-    static constexpr int NF = R.key == K_BINARY ? 2 * HP : HP;           // Planck-fraction loads
-    static constexpr int NL = NK + NF;
+    static constexpr int NL = NK;
     static constexpr int CH = RRLW_LOAD_CHUNK;
     static constexpr int NCH = (NL + CH - 1) / CH;
 
@@ -871,13 +882,11 @@ struct BandLoads {
             constexpr int dummy = 0; (void)dummy;
             const int idx = C * CH + k;
             if (idx < NK) b[k] = ld2(kt, rw.off[idx / HP] + 2u * (unsigned)(idx % HP));
-            else if (idx < NK + HP) b[k] = ld2(kt, rw.foff + 2u * (unsigned)(idx - NK));
-            else if (idx < NL) b[k] = ld2(kt, rw.foff + (unsigned)ng + 2u * (unsigned)(idx - NK - HP));
         }
     }
 
     template <int C>
-    static __device__ __forceinline__ void consume(const Rows<N> &rw, const double2 (&b)[CH], double *tau, double *frac)
+    static __device__ __forceinline__ void consume(const Rows<N> &rw, const double2 (&b)[CH], double *tau)
     {
 #pragma unroll
         for (int k = 0; k < CH; k++) {
@@ -886,43 +895,35 @@ struct BandLoads {
                 const int i = idx / HP, p = idx % HP;
                 tau[2 * p] = tau[2 * p] + rw.w[i] * b[k].x;
                 tau[2 * p + 1] = tau[2 * p + 1] + rw.w[i] * b[k].y;
-            } else if (idx < NK + HP) {
-                const int p = idx - NK;
-                frac[2 * p] = b[k].x; frac[2 * p + 1] = b[k].y;
-            } else if (idx < NL) {
-                const int p = idx - NK - HP;
-                frac[2 * p] = frac[2 * p] + rw.fpl * (b[k].x - frac[2 * p]);
-                frac[2 * p + 1] = frac[2 * p + 1] + rw.fpl * (b[k].y - frac[2 * p + 1]);
             }
         }
     }
 
     template <int C>
     static __device__ __forceinline__ void step(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double2 (&cur)[CH], double2 (&nxt)[CH],
-                                                double *tau, double *frac)
+                                                double *tau)
     {
         if constexpr (C < NCH) {
             if constexpr (C + 1 < NCH) issue<C + 1>(kt, rw, nxt);
             __builtin_amdgcn_sched_barrier(0);
-            consume<C>(rw, cur, tau, frac);
+            consume<C>(rw, cur, tau);
             __builtin_amdgcn_sched_barrier(0);
-            step<C + 1>(kt, rw, nxt, cur, tau, frac);
+            step<C + 1>(kt, rw, nxt, cur, tau);
         }
     }
 };
 
 template <int B, bool LOWER, int N>
-__device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double (&tau)[4 * band_nquad(B)],
-                                               double (&frac)[4 * band_nquad(B)])
+__device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double (&tau)[4 * band_nquad(B)])
 {
     using BL = BandLoads<B, LOWER, N>;
     constexpr int NP = 4 * band_nquad(B);
 #pragma unroll
-    for (int j = 0; j < NP; j++) { tau[j] = 0.0; frac[j] = 0.0; }
-    if constexpr (BL::R.key != K_ZERO) {
+    for (int j = 0; j < NP; j++) tau[j] = 0.0;
+    if constexpr (BL::NL > 0) {
         double2 b0[BL::CH], b1[BL::CH];
         BL::template issue<0>(kt, rw, b0);
-        BL::template step<0>(kt, rw, b0, b1, tau, frac);
+        BL::template step<0>(kt, rw, b0, b1, tau);
 #pragma unroll
         for (int j = 0; j < BL::ng; j++) {
             if constexpr (BL::R.mult == 4) tau[j] = tau[j] * kMult4[j];
@@ -946,9 +947,8 @@ struct LayerArgs {
 
 struct alignas(16) scr4 { scr_t v[4]; };
 
-// The per-cell scratch is written once by k_layer and read once (twice for atrans) by k_sweep, gigabytes later: streaming
-// (non-temporal) accesses keep it from evicting the absorption tables and LUTs from L2.
-#ifndef RRLW_SCR_DOUBLE
+// The per-cell codes are written once by k_layer and read twice (down and up sweep) by k_sweep, gigabytes later: streaming
+// (non-temporal) accesses keep them from evicting the absorption tables and LUTs from L2.
 typedef float scr_vec __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &v)
 {
@@ -969,30 +969,35 @@ __device__ __forceinline__ scr4 scr_load(const scr4 *p)
     return v;
 #endif
 }
-#else
-__device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &v) { reinterpret_cast<scr4 *>(base)[cell] = v; }
-__device__ __forceinline__ scr4 scr_load(const scr4 *p) { return *p; }
-#endif
 
 // transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
 __device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * fdiv(od, bpade + od) + 0.5); }
+
+// What k_layer hands to k_sweep for one cell is the DECISION the reference takes on its optical depth (rtrn :372-451), in 4 bytes:
+//   code >= 0 : the optical depth itself (<= 0.06, or odtot < 0.06) - the series branch: atrans = od - od^2/2, tfac = od/6
+//   code <  0 : -(index into the 1e-4-quantised transmittance / tfn tables), formed here in float64 exactly as the reference forms it
+// k_sweep turns the code back into (transmittance, tfn factor) and forms the Planck source terms in float64 itself.  Compared with
+// storing {atrans, bbd, bbu} as three floats this is a third of the bytes, and the table index never depends on a rounded value.
+__device__ __forceinline__ scr_t cell_code(double od, bool series, double bpade)
+{
+    return series ? (scr_t)od : -(scr_t)lut_index(od, bpade);
+}
 
 // all cells (g-points) of band B of one (layer, column).
 // CLOUD: 0 clear-sky set, 1 one cloud optical depth per band (rtrn / rtrnmr), 2 one per g-point from W.odg (rtrnmc, sub-column
 // arrays), 3 the band's value where the sub-column mask has a bit (rtrnmc, generator mask; gbits = the band's ng mask bits)
 template <int B, int CLOUD, bool LOWER, int N>
 __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, int lay, int col,
-                                           double blay, double dplankup, double dplankdn, double secdiff, double taua,
-                                           int cloudy, double odcld, double pb, double dpb, bool idrv, unsigned gbits)
+                                           double secdiff, double taua, int cloudy, double odcld, unsigned gbits)
 {
+    constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
     constexpr int ng = BT<B>::ng;
     constexpr int NQ = band_nquad(B), NP = 4 * NQ, QS = band_qstart(B);
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
-    double od[NP], frac[NP];
-    rows_eval_band<B, LOWER, N>(kt, rw, od, frac);
+    double od[NP];
+    rows_eval_band<B, LOWER, N>(kt, rw, od);
     const double *S = T.stat;
-    const double2 *__restrict__ lut2 = reinterpret_cast<const double2 *>(S + T.sl.lut);
     const double *__restrict__ tau_tbl = S + T.sl.tau_tbl;
     const double bpade = T.bpade;
     // (kept in the basic block of the table loads: an instruction-sinking pass would otherwise move the whole FMA chains
@@ -1004,59 +1009,28 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
         od[j] = o;
     }
 #pragma unroll
-    for (int j = 0; j < NP; j++) {        // pin: the values exist here (LLVM's Sink pass may not move their FMA chains past this point)
-        asm volatile("" : "+v"(od[j]));
-        asm volatile("" : "+v"(frac[j]));
-    }
-    if (lay == 1) {               // surface emission seeds: rtrn :476-479 (padding g-points carry zeros)
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-            W.rad0[(size_t)(QS * 4 + j) * ncb + col] = frac[j] * pb;
-            if (idrv) W.rad0[(size_t)(4 * NQUAD + QS * 4 + j) * ncb + col] = frac[j] * dpb;
-        }
-    }
+    for (int j = 0; j < NP; j++) asm volatile("" : "+v"(od[j]));   // pin: the values exist here (LLVM's Sink pass may not move their FMA chains past this point)
+    if constexpr (R.key == K_BINARY) W.fw[((size_t)fw_slot(B) * nlay + (lay - 1)) * ncb + col] = rw.fw;
     const size_t so0 = ((size_t)QS * nlay + (lay - 1)) * ncb + col;     // scratch cell of the band's first quad
     const size_t qstride = (size_t)nlay * ncb;
-    if (!(CLOUD && cloudy)) {
-        // clear layer: rtrn :439-451.  All table look-ups of the band are issued before the first is used.
-        double2 e[NP];
+    // gas: series for od <= 0.06, else the table (rtrn :372-451; in a cloudy layer the branch taken for the gas terms depends on od alone)
 #pragma unroll
-        for (int j = 0; j < NP; j++) {
-            int it = 0;
-            if (j < ng && od[j] > 0.06) it = lut_index(od[j], bpade);
-            e[j] = lut2[it];
-        }
+    for (int q = 0; q < NQ; q++) {
+        scr4 c;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            scr4 oatr, obbd, obbu;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int j = 4 * q + k;
-                double atr, tfn;
-                if (od[j] <= 0.06) { atr = od[j] - 0.5 * od[j] * od[j]; tfn = 0.166667 * od[j]; }
-                else { atr = 1. - e[j].x; tfn = e[j].y; }
-                oatr.v[k] = (scr_t)atr;
-                obbd.v[k] = (scr_t)(frac[j] * (blay + tfn * dplankdn));
-                obbu.v[k] = (scr_t)(frac[j] * (blay + tfn * dplankup));
-            }
-            const size_t so = so0 + q * qstride;
-            scr_store(W.scr[S_ATR], so, oatr);
-            scr_store(W.scr[S_BBD], so, obbd);
-            scr_store(W.scr[S_BBU], so, obbu);
-        }
-    } else {
-        // cloudy layer, the three sub-branches of rtrn :372-435 in predicated form:
-        //   p1: odtot < 0.06              gas and total both from the series
-        //   p2: else if odepth <= 0.06    gas from the series, total from the table
-        //   p3: else                      gas from the table at itgas, odepth := tau_tbl(itgas), total from the table
-        // processed RRLW_CLOUD_QUADS quads at a time (two dependent table look-ups per cell are in flight for all of them)
+        for (int k = 0; k < 4; k++) c.v[k] = cell_code(od[4 * q + k], od[4 * q + k] <= 0.06, bpade);
+        scr_store(W.scr[S_CODE], so0 + q * qstride, c);
+    }
+    if (CLOUD && cloudy) {
+        // cloudy layer, the three sub-branches of rtrn :372-435:
+        //   p1: odtot < 0.06              total from the series
+        //   p2: else if odepth <= 0.06    total = odepth + odcld from the table
+        //   p3: else                      odepth := tau_tbl(itgas), total from the table
         constexpr int QC = RRLW_CLOUD_QUADS < NQ ? RRLW_CLOUD_QUADS : NQ;
 #pragma unroll
         for (int q0 = 0; q0 < NQ; q0 += QC) {
             constexpr int GC = 4 * QC;
-            double odc[GC];
-            double2 e[GC], e2[GC];
-            double tg[GC], odtot[GC];
+            double odc[GC], tg[GC];
 #pragma unroll
             for (int k = 0; k < GC; k++) odc[k] = odcld;
             if constexpr (CLOUD == 3) {
@@ -1080,50 +1054,22 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
                     int ig = 0;
                     const bool p3 = !(od[j] + odc[k] < 0.06) && !(od[j] <= 0.06);
                     if (j < ng && p3) ig = lut_index(od[j], bpade);
-                    e[k] = lut2[ig];
                     tg[k] = tau_tbl[ig];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < GC; k++) {
-                const int j = 4 * q0 + k;
-                if (j < NP) {
-                    const bool p1 = od[j] + odc[k] < 0.06;
-                    const bool p3 = !p1 && !(od[j] <= 0.06);
-                    odtot[k] = (p3 ? tg[k] : od[j]) + odc[k];
-                    int it = 0;
-                    if (j < ng && !p1) it = lut_index(odtot[k], bpade);
-                    e2[k] = lut2[it];
                 }
             }
 #pragma unroll
             for (int q = 0; q < QC; q++) {
                 if (q0 + q < NQ) {
-                    scr4 oatr, obbd, obbu, oatot, obbdt, obbut;
+                    scr4 c;
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
                         const int k = 4 * q + kk, j = 4 * (q0 + q) + kk;
                         const bool p1 = od[j] + odc[k] < 0.06;
                         const bool p3 = !p1 && !(od[j] <= 0.06);
-                        double atr, tfgas, atot, tftot;
-                        if (p3) { atr = 1. - e[k].x; tfgas = e[k].y; }
-                        else { atr = od[j] - 0.5 * od[j] * od[j]; tfgas = 0.166667 * od[j]; }
-                        if (p1) { atot = odtot[k] - 0.5 * odtot[k] * odtot[k]; tftot = 0.166667 * odtot[k]; }
-                        else { atot = 1. - e2[k].x; tftot = e2[k].y; }
-                        oatr.v[kk] = (scr_t)atr;
-                        obbd.v[kk] = (scr_t)(frac[j] * (blay + tfgas * dplankdn));
-                        obbu.v[kk] = (scr_t)(frac[j] * (blay + tfgas * dplankup));
-                        oatot.v[kk] = (scr_t)atot;
-                        obbdt.v[kk] = (scr_t)(frac[j] * (blay + tftot * dplankdn));
-                        obbut.v[kk] = (scr_t)(frac[j] * (blay + tftot * dplankup));
+                        const double odtot = (p3 ? tg[k] : od[j]) + odc[k];
+                        c.v[kk] = j < ng ? cell_code(odtot, p1, bpade) : (scr_t)0;
                     }
-                    const size_t so = so0 + (q0 + q) * qstride;
-                    scr_store(W.scr[S_ATR], so, oatr);
-                    scr_store(W.scr[S_BBD], so, obbd);
-                    scr_store(W.scr[S_BBU], so, obbu);
-                    scr_store(W.scr[S_ATOT], so, oatot);
-                    scr_store(W.scr[S_BBDTOT], so, obbdt);
-                    scr_store(W.scr[S_BBUTOT], so, obbut);
+                    scr_store(W.scr[S_CODET], so0 + (q0 + q) * qstride, c);
                 }
             }
         }
@@ -1131,114 +1077,36 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 }
 
 #ifndef RRLW_LAYER_WAVES
-#define RRLW_LAYER_WAVES 2        // waves per SIMD k_layer is compiled for: with 8-load chunks it needs 200-230 VGPRs, no spills.  VALU operands
-                                  // must be architectural VGPRs (<= 256; AGPRs are only spill space), so a 512-register budget buys nothing;
-                                  // 3 waves (<= 168 VGPRs) spills 10-40 dwords and is slower (25.1 vs 21.3 ms / 262144 columns)
+#define RRLW_LAYER_WAVES 2        // waves per SIMD k_layer is compiled for.  VALU operands must be architectural VGPRs (<= 256; AGPRs are only
+                                  // spill space), so a 512-register budget buys nothing
 #endif
-
-// all quads of band B for one (layer, column)
-// per-band inputs of one (layer, column) that come from global memory: fetched for ALL bands of the launch group in the
-// kernel prologue, in one memory round trip together with the profile inputs (measured: fetching them band by band costs
-// one exposed HBM latency per band, which dominated k_layer at one wave per SIMD)
-struct BandIn { double blay, dplankup, dplankdn, secdiff, taua, odcld; };
-
-// Prefetching the per-band inputs in the prologue pays only while a launch covers few bands (6+ groups); with all 16 bands in
-// one launch the live registers cost more than the exposed latency (measured per 1e6 columns: 6 groups + prefetch 145.5 ms,
-// 3 groups + partial prefetch 141.0 ms, 1 group without prefetch 141.8 ms and 156 vs 160-162 ms for McICA).
-#ifndef RRLW_PREFETCH_PLANCK
-#define RRLW_PREFETCH_PLANCK 0     // 1: the Planck terms of every band of the group are formed in the prologue too (more live registers)
-#endif
-#ifndef RRLW_PREFETCH_BANDIN
-#define RRLW_PREFETCH_BANDIN 0     // 1: secdiff / tauaer / odcld of every band of the group are fetched in the prologue
-#endif
-
-// Planck functions of the layer and of its two interfaces: setcoef :203-269
-template <int B>
-__device__ __forceinline__ void band_planck(const DevTables &T, const LayerArgs &a, int lay, int indlay, double tlayfrac, int indhi,
-                                            double thifrac, int indlo, double tlofrac, BandIn &in)
-{
-    const double *S = T.stat;
-    const bool alt16 = (B == 16 && a.istart == 16);
-    const double *tp = alt16 ? S + T.sl.totplk16 : S + T.sl.totplnk + 181 * (B - 1);
-    const double blay = tp[indlay - 1] + tlayfrac * (tp[indlay] - tp[indlay - 1]);
-    const double plev_hi = tp[indhi - 1] + thifrac * (tp[indhi] - tp[indhi - 1]);
-    double plev_lo;
-    if (alt16 && lay == 1) {       // :244-246: level 0 mixes the two tables when band 16 runs alone
-        const double *tq = S + T.sl.totplnk + 181 * 15;
-        plev_lo = tp[indlo - 1] + tlofrac * (tq[indlo] - tq[indlo - 1]);
-    } else {
-        plev_lo = tp[indlo - 1] + tlofrac * (tp[indlo] - tp[indlo - 1]);
-    }
-    in.blay = blay;
-    in.dplankup = plev_hi - blay;
-    in.dplankdn = plev_lo - blay;
-}
-
-template <int B, int CLOUD>
-__device__ __forceinline__ BandIn band_inputs(const DevTables &T, const Workspace &W, const LayerArgs &a, int lay, int col, size_t gc,
-                                              int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
-{
-    if (!RRLW_PREFETCH_BANDIN) return BandIn{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const size_t ncb = W.ncolb;
-    const int nlay = W.nlay, nct = a.nct;
-    BandIn in;
-    in.blay = in.dplankup = in.dplankdn = 0.0;
-    in.odcld = 0.0;
-    if constexpr (CLOUD == 1 || CLOUD == 3) in.odcld = W.odcld[((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col];   // zero for clear layers (k_cloud / k_cloudmc)
-    if (RRLW_PREFETCH_PLANCK) band_planck<B>(T, a, lay, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, in);
-    in.secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
-    in.taua = a.tauaer[gc + (size_t)nct * ((lay - 1) + (size_t)nlay * (B - 1))];
-    return in;
-}
-
-__device__ __forceinline__ void pin(BandIn &in)
-{
-#if !RRLW_PREFETCH_BANDIN
-    (void)in;
-#elif RRLW_PREFETCH_PLANCK
-    asm volatile("" : "+v"(in.blay), "+v"(in.dplankup), "+v"(in.dplankdn), "+v"(in.secdiff), "+v"(in.taua), "+v"(in.odcld));
-#else
-    asm volatile("" : "+v"(in.secdiff), "+v"(in.taua), "+v"(in.odcld));
-#endif
-}
 
 // all cells of band B for one (layer, column)
 template <int B, int CLOUD>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
-                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const BandIn &in_,
-                                           const unsigned (&mw)[5], int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac)
+                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const unsigned (&mw)[5])
 {
-    BandIn in = in_;
-    if (!RRLW_PREFETCH_BANDIN) {
-        const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
-        if constexpr (CLOUD == 1 || CLOUD == 3) in.odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col];
-        in.secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
-        in.taua = a.tauaer[gcx + (size_t)a.nct * ((lay - 1) + (size_t)W.nlay * (B - 1))];
-    }
-    if (!RRLW_PREFETCH_PLANCK || !RRLW_PREFETCH_BANDIN) band_planck<B>(T, a, lay, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, in);
+    const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
+    double odcld = 0.0;
+    if constexpr (CLOUD == 1 || CLOUD == 3) odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col];   // zero for clear layers (k_cloud / k_cloudmc)
+    const double secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
+    const double taua = a.tauaer[gcx + (size_t)a.nct * ((lay - 1) + (size_t)W.nlay * (B - 1))];
     unsigned gbits = 0u;
     if constexpr (CLOUD == 3) {
         constexpr int g0 = band_g0(B), ng = BT<B>::ng, w0 = g0 >> 5;
         const unsigned long long lo = mw[w0], hi = w0 < 4 ? mw[w0 + 1 < 5 ? w0 + 1 : 4] : 0u;
         gbits = (unsigned)(((lo | (hi << 32)) >> (g0 & 31)) & ((1ull << ng) - 1ull));
     }
-    const size_t ncb = W.ncolb;
-    double pb = 0.0, dpb = 0.0;
-    if (lay == 1) {
-        pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + col];
-        dpb = W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + col];
-    }
-    const bool idrv = a.idrv == 1;
     if (lower) {
         constexpr int N = region_nrows(BT<B>::lo, true);
         Rows<N> rw;
         rows_prep<B, true, N>(T, C, rw);
-        band_cells<B, CLOUD, true, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv, gbits);
+        band_cells<B, CLOUD, true, N>(T, W, kt, rw, lay, col, secdiff, taua, cloudy, odcld, gbits);
     } else {
         constexpr int N = region_nrows(BT<B>::up, false);
         Rows<N> rw;
         rows_prep<B, false, N>(T, C, rw);
-        band_cells<B, CLOUD, false, N>(T, W, kt, rw, lay, col, in.blay, in.dplankup, in.dplankdn, in.secdiff, in.taua, cloudy, in.odcld, pb, dpb, idrv, gbits);
+        band_cells<B, CLOUD, false, N>(T, W, kt, rw, lay, col, secdiff, taua, cloudy, odcld, gbits);
     }
 }
 
@@ -1268,13 +1136,10 @@ GROUP_BANDS(9, 6, 1, 10) GROUP_BANDS(9, 7, 2, 11) GROUP_BANDS(9, 8, 6, 12)
 
 template <class GB, int CLOUD, int... K>
 __device__ __forceinline__ void group_run(std::integer_sequence<int, K...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
-                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, size_t gc, int cloudy,
-                                          int indlay, double tlayfrac, int indhi, double thifrac, int indlo, double tlofrac,
+                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy,
                                           const unsigned (&mw)[5])
 {
-    BandIn in[GB::n] = {band_inputs<GB::b[K], CLOUD>(T, W, a, lay, col, gc, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac)...};
-    (pin(in[K]), ...);
-    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, in[K], mw, indlay, tlayfrac, indhi, thifrac, indlo, tlofrac) : (void)0), ...);
+    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, mw) : (void)0), ...);
 }
 
 template <bool GCM, int CLOUD, int GROUP>
@@ -1291,14 +1156,12 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
     const double amd = 28.9660, amw = 18.0160, avogad = 6.02214199e+23, grav = 9.8066;
     const double stpfac = 296. / 1013.;
 
-    double pavel, tavel, tz_lo, tz_hi, coldry, wbrodl, w1, w2, w3, w4, w5, w6, w7;
+    double pavel, tavel, coldry, wbrodl, w1, w2, w3, w4, w5, w6, w7;
     LayerCoef C;
     if (GCM) {
         pavel = g.play[gi];
         tavel = g.tlay[gi];
         const double pz_lo = g.plev[gi], pz_hi = g.plev[gc + (size_t)nct * lay];
-        tz_lo = g.tlev[gi];
-        tz_hi = g.tlev[gc + (size_t)nct * lay];
         w1 = g.h2ovmr[gi]; w2 = g.co2vmr[gi]; w3 = g.o3vmr[gi]; w4 = g.n2ovmr[gi];
         w5 = 0.0; w6 = g.ch4vmr[gi]; w7 = g.o2vmr[gi];
         const double amm = (1. - w1) * amd + w1 * amw;
@@ -1316,8 +1179,6 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
     } else {
         pavel = c.pavel[gi];
         tavel = c.tavel[gi];
-        tz_lo = c.tz[gi];
-        tz_hi = c.tz[gc + (size_t)nct * lay];
         coldry = c.coldry[gi];
         wbrodl = c.wbrodl[gi];
         const size_t wi = gc + (size_t)nct * 7 * (lay - 1);       // wkl (ncol,7,nlayers)
@@ -1329,14 +1190,7 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
         C.f[F_WX3] = c.wx[xi + (size_t)nct * 2]; C.f[F_WX4] = c.wx[xi + (size_t)nct * 3];
     }
 
-    // temperature indices for the Planck tables: setcoef :173-201
-    const int indlay = clampi((int)(tavel - 159.), 1, 180);
-    const double tlayfrac = tavel - 159. - (double)indlay;
-    const int indhi = clampi((int)(tz_hi - 159.), 1, 180);
-    const double thifrac = tz_hi - 159. - (double)indhi;
-    const int indlo = clampi((int)(tz_lo - 159.), 1, 180);
-    const double tlofrac = tz_lo - 159. - (double)indlo;
-
+    // (the Planck functions of setcoef :173-269 are formed by k_sweep, which needs them per band and level)
     // pressure / temperature interpolation: setcoef :276-306
     const double plog = log(pavel);
     const int jp = clampi((int)(36. - 5 * (plog + 0.04)), 1, 58);
@@ -1407,8 +1261,7 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
         }
     }
     using GB = GroupBands<NLGROUP, GROUP>;
-    group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, lower, lay, col, gc, cloudy,
-                         indlay, tlayfrac, indhi, thifrac, indlo, tlofrac, mw);
+    group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, lower, lay, col, cloudy, mw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1796,60 +1649,204 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 // k_sweep : the vertical recurrences.  One thread owns NGC consecutive g-points of one band for one column.
 //   MODE 0 clear column set (icld = 0): rtrn/rtrnmr clear branch   src/rrtmg_lw_rtrn.f90:437-466,:497-540
 //   MODE 1 rtrn   (random overlap)                                 src/rrtmg_lw_rtrn.f90:361-540
-//   MODE 2 rtrnmr (maximum-random overlap)                         src/rrtmg_lw_rtrnmr.f90:531-738
+//   MODE 2 rtrnmr (maximum-random overlap)                         src/rrtmg_lw_rtrnmr.f90:347-738
 //   MODE 3 rtrnmc (McICA: cloud terms per g-point, k_cloudmc)      src/rrtmg_lw_rtrnmc.f90:331-520
 //   MODE 4 rtrnmc with the cloud terms given per band + the generator's sub-column mask
-// Writes the chunk's flux contribution (sum over its g-points x 0.5 x delwave, rtrn :549-562) per level.
+// Per cell it reads k_layer's 4-byte code (cell_code) and forms, in float64: transmittance and tfn factor (series, or the
+// transmittance table staged in LDS; rtrn :372-451), the layer's Planck functions for this band (setcoef :173-269, from
+// tlay / tlev and the band's totplnk row staged in LDS), the Planck fractions (taumol: constant per g-point, or interpolated
+// between two fracref rows staged in LDS with the layer's (js, fs) from k_layer) and from them the source terms bbd / bbu
+// (rtrn :447-449).  For rtrnmr the overlap factors of a cloudy level (rtrnmr :347-506) are formed on the fly from the cloud
+// fractions of the level and its two neighbours, in sweep order, exactly as the reference's two set-up loops form them.
+// Writes the band's flux contribution (sum over its g-points x 0.5 x delwave, rtrn :549-562) per level.
+// Lanes beyond the last column work on a copy of the last column (no divergence); only their stores are masked.
 // ------------------------------------------------------------------------------------------------
-#ifndef RRLW_SWEEP_UNROLL
-#define RRLW_SWEEP_UNROLL 4
-#endif
-
 struct SweepArgs {
     unsigned long long bands;  // the launch's bands (all with the same number of quads), one nibble (band - 1) per blockIdx.y
     int ncol, col0, nct, idrv;
     int istart, iend;          // only bands in [istart, iend] are swept
     const double *emis;        // semiss (nct,16)
     const double *cldfrac;     // (nct,nlay)
+    const double *tlay;        // (nct,nlay)     layer temperatures    (tlay | tavel)
+    const double *tlev;        // (nct,nlay+1)   interface temperatures (tlev | tz)
 };
 
-constexpr int SWEEP_LV = 4;       // levels per reduction round == quad slots per workgroup (blockDim.y)
-
-// Workgroup = 64 columns x the NQ quads of ONE band (blockIdx.y indexes the launch's list of bands with NQ quads).  Each wave sweeps one quad; every SWEEP_LV levels the
-// waves' partial flux sums meet in LDS and are added in quad order, so only one slab per BAND (not per quad) goes to HBM:
-// measured (profiles/round1_pmc_v2_two_phase.md) k_sweep runs at 5.3 TB/s of HBM traffic, a quarter of it these partials.
-#ifndef RRLW_SWEEP_WAVES
-#define RRLW_SWEEP_WAVES 2         // waves per SIMD the sweep is compiled for (HBM-bound: memory-level parallelism comes from occupancy)
+constexpr int SWEEP_LV = 4;       // levels per reduction round
+#ifndef RRLW_SWEEP_PF
+#define RRLW_SWEEP_PF 2           // prefetch distance in levels (= register slots of the rolling prefetch); divides SWEEP_LV.  4 slots make
+                                  // the rtrnmr sweep spill (58-67 dwords) and are slower (81.5 vs 76.9 ms per 1e6 cloudy columns)
 #endif
+#ifndef RRLW_SWEEP_WAVES_CLEAR
+#define RRLW_SWEEP_WAVES_CLEAR 4  // waves per SIMD the clear-sky sweep (MODE 0) is compiled for (128 VGPRs, no spills; 31.8 vs 39.0 ms per 1e6 columns at 2)
+#endif
+#ifndef RRLW_SWEEP_WAVES_CLOUD
+#define RRLW_SWEEP_WAVES_CLOUD 2  // ... and the cloudy sweeps
+#endif
+__host__ __device__ constexpr int sweep_waves(int MODE) { return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : RRLW_SWEEP_WAVES_CLOUD; }
+// column sub-blocks (of 64 columns) per workgroup for bands of NQ quads: one workgroup per CU (the table in LDS), 4 x sweep_waves waves
+// (3 x for NQ = 3)
+__host__ __device__ constexpr int sweep_ns(int NQ, int MODE) { return (NQ >= 3 ? 1 : NQ == 2 ? 2 : 4) * sweep_waves(MODE); }
+// dynamic LDS of k_sweep<., NQ>: transmittance table (float pairs), Planck rows, fraction rows, reduction buffer
+constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8, SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
+__host__ __device__ constexpr int sweep_lds_bytes(int NQ, int MODE)
+{
+    return SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES + (NQ > 1 ? sweep_ns(NQ, MODE) * NQ * SWEEP_LV * 64 * 16 : 0);
+}
+
+// Loads of k_sweep: wave-uniform base pointer in a buffer descriptor (scalar registers), per-lane 32-bit byte offset that does not
+// change from level to level - no 64-bit vector address arithmetic per load.  nt = streaming (non-temporal) access.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
+}
+__device__ __forceinline__ scr4 bload_scr4_nt(const void *base, unsigned voff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, 0, 2);
+    scr4 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double bload_f64(const void *base, unsigned voff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(sweep_rsrc(base), (int)voff, 0, 0);
+    double r;
+    __builtin_memcpy(&r, &v, 8);
+    return r;
+}
+__device__ __forceinline__ unsigned bload_u32(const void *base, unsigned voff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(sweep_rsrc(base), (int)voff, 0, 0);
+}
+
+// table index of a cell's code (0 for the series branch: entry 0 is {1 - exp = 0, tfn = 0})
+__device__ __forceinline__ unsigned code_index(scr_t c) { return (unsigned)max((int)(-c), 0); }
+// the optical depth of a series cell, 0 for a table cell: max(c, 0) on the bit pattern (a negative float is a negative integer)
+__device__ __forceinline__ float code_od(scr_t c) { return __int_as_float(max(__float_as_int(c), 0)); }
+// (1 - transmittance, tfn factor) of a cell from its code and the table entry at code_index: rtrn :439-451.  Branch-free: a table
+// cell adds the series terms of od = 0, a series cell adds the table terms of entry 0 - both exact zeros.
+__device__ __forceinline__ void decode(scr_t c, const float2 &e, double &atr, double &tfn)
+{
+    const double od = (double)code_od(c);
+    atr = (double)e.x + (od - 0.5 * od * od);
+    tfn = (double)e.y + 0.166667 * od;
+}
+// integrated Planck function at temperature t from one band's row of totplnk: setcoef :173-269
+__device__ __forceinline__ double planck_at(const double *tp, const double *tq, double t)
+{
+    const double x = t - 159.;
+    const int ind = clampi((int)x, 1, 180);
+    const double f = x - (double)ind;
+    return tp[ind - 1] + f * (tq[ind] - tq[ind - 1]);
+}
+
+// Maximum-random overlap factors of ONE cloudy level, src/rrtmg_lw_rtrnmr.f90:347-506 (upward loop :347-425, downward loop :427-506;
+// the two loops are mirror images).  cl = cloud fraction of the level, cn = of the next level in sweep direction, cp = of the previous
+// one (read only when that level is cloudy, i.e. !first), last = the level is the last of the sweep.  rat1 / rat2 carry from cloudy
+// level to cloudy level as in the reference.  faccmb1/2, which the reference reads uninitialised when first, are ZERO.
+struct OvlFac { double clr1, cld1, cmb1, cmb2, clr2, cld2, rat1, rat2; };     // rat1 / rat2: the values carried to the next cloudy level
+__device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool first, bool last, double rat1, double rat2)
+{
+    // (everything by value: carried state behind references ends up in scratch memory)
+    double clr1 = 0.0, clr2 = 0.0, cld1 = 0.0, cld2 = 0.0, cmb1 = 0.0, cmb2 = 0.0;
+    if (!last) {
+        if (cn >= cl) {
+            if (first) {
+                if (cl < 1.) clr2 = fdiv(cn - cl, 1. - cl);
+            } else {
+                const double fmx = fmax(cl, cp);
+                if (cn > fmx) { clr1 = rat2; clr2 = fdiv(cn - fmx, 1. - fmx); }
+                else if (cn < fmx) { clr1 = fdiv(cn - cl, cp - cl); }
+                else { clr1 = rat2; }
+            }
+            rat1 = (clr1 > 0. || clr2 > 0.) ? 1. : 0.;
+            rat2 = 0.;
+        } else {
+            if (first) {
+                cld2 = fdiv(cl - cn, cl);
+            } else {
+                const double fmn = fmin(cl, cp);
+                if (cn <= fmn) { cld1 = rat1; cld2 = fdiv(fmn - cn, fmn); }
+                else { cld1 = fdiv(cl - cn, cl - fmn); }
+            }
+            rat2 = (cld1 > 0. || cld2 > 0.) ? 1. : 0.;
+            rat1 = 0.;
+        }
+    }
+    if (!first) {
+        const double cx = last ? 0.0 : cn;          // beyond the last level the reference's neighbour fraction is taken as 0
+        cmb1 = fmax(0., fmin(cx - cl, cp - cl));
+        cmb2 = fmax(0., fmin(cl - cx, cl - cp));
+    }
+    return OvlFac{clr1, cld1, cmb1, cmb2, clr2, cld2, rat1, rat2};
+}
+
+struct SweepLev { scr4 c, ct; double tl, tz, cf, cfn; unsigned w; };     // one level's prefetched inputs
 
 template <int MODE, int NQ>
-__global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T, Workspace W, SweepArgs a)
+__global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) void k_sweep(DevTables T, Workspace W, SweepArgs a)
 {
     constexpr int NGC = 4;
-    constexpr int LV = SWEEP_LV;
-    __shared__ Part2 red[NQ > 1 ? NQ * LV * 64 : 1];            // [slot][level-in-round][column]
-    const int tx = threadIdx.x, slot = threadIdx.y;
-    const int col = blockIdx.x * 64 + tx;
+    constexpr int LV = SWEEP_LV, PF = RRLW_SWEEP_PF;
+    static_assert(LV % PF == 0, "prefetch slots");
+    constexpr int NS = sweep_ns(NQ, MODE);
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *s_lut = reinterpret_cast<float2 *>(smem);                                              // [NTBL + 1] {1 - exp, tfn}
+    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);              // [0] this band's Planck integrals, [1] band 16's (istart = 16 quirk)
+    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);   // Planck fractions: rows 0-8 fracrefa, 9-13 fracrefb, 14-15 zeros
+    const int tx = threadIdx.x, slot = threadIdx.y, sub = threadIdx.z;
+    Part2 *red = reinterpret_cast<Part2 *>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES) + (size_t)sub * NQ * LV * 64;   // [slot][level-in-round][column]
+    const int col = (blockIdx.x * NS + sub) * 64 + tx;
     const int B = (int)((a.bands >> (4 * blockIdx.y)) & 15ull) + 1;     // bands with NQ quads, packed as nibbles (band - 1)
     if (B < a.istart || B > a.iend) return;         // uniform over the workgroup
-    constexpr int nq = NQ;
-    const bool active = col < a.ncol;
-    const bool incol = active;
+    const bool incol = col < a.ncol;
+    const int colc = incol ? col : a.ncol - 1;      // lanes past the end shadow the last column
     const int quad = band_qstart(B) + slot;
-    const size_t gc = (size_t)a.col0 + col;
+    const size_t gc = (size_t)a.col0 + colc;
     const int nlay = W.nlay, nct = a.nct;
     const size_t ncb = W.ncolb;
     const double wtdelw = T.delwave[B - 1];
     const bool idrv = a.idrv == 1;
-    const scr4 *__restrict__ sA = reinterpret_cast<const scr4 *>(W.scr[S_ATR]) + (size_t)quad * nlay * ncb + col;
-    const scr4 *__restrict__ sBd = reinterpret_cast<const scr4 *>(W.scr[S_BBD]) + (size_t)quad * nlay * ncb + col;
-    const scr4 *__restrict__ sBu = reinterpret_cast<const scr4 *>(W.scr[S_BBU]) + (size_t)quad * nlay * ncb + col;
-    const scr4 *__restrict__ sT = reinterpret_cast<const scr4 *>(W.scr[S_ATOT]) + (size_t)quad * nlay * ncb + col;
-    const scr4 *__restrict__ sTd = reinterpret_cast<const scr4 *>(W.scr[S_BBDTOT]) + (size_t)quad * nlay * ncb + col;
-    const scr4 *__restrict__ sTu = reinterpret_cast<const scr4 *>(W.scr[S_BBUTOT]) + (size_t)quad * nlay * ncb + col;
+    const bool alt16 = (B == 16 && a.istart == 16);
+    const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
+    const bool any_bin = lo_bin || up_bin;
+    const int base_up = ((UP_ZERO >> (B - 1)) & 1u) ? 14 : (((UP_FROM_A >> (B - 1)) & 1u) ? 0 : 9);     // first fracs row of the upper atmosphere
+    {   // stage the tables
+        const int tid = (sub * NQ + slot) * 64 + tx, nth = 64 * NQ * NS;
+        const double2 *src = reinterpret_cast<const double2 *>(T.stat + T.sl.lutf);
+        double2 *dst = reinterpret_cast<double2 *>(smem);
+        for (int i = tid; i < SWEEP_LUT_BYTES / 16; i += nth) dst[i] = src[i];
+        const double *tp = alt16 ? T.stat + T.sl.totplk16 : T.stat + T.sl.totplnk + 181 * (B - 1);
+        const double *tq = T.stat + T.sl.totplnk + 181 * 15;
+        for (int i = tid; i < 181; i += nth) { s_pl[0][i] = tp[i]; s_pl[1][i] = tq[i]; }
+        const int ng = T.band[B - 1].ng, fa = T.band[B - 1].fracrefa, fb = T.band[B - 1].fracrefb;
+        const int na = lo_bin ? 9 : 1, nb = up_bin ? 5 : 1;
+        for (int i = tid; i < 16 * 16; i += nth) {
+            const int r = i >> 4, g = i & 15;
+            double v = 0.0;
+            if (g < ng) {
+                if (r < 9) { if (r < na) v = T.ktab[fa + r * ng + g]; }
+                else if (r < 14 && fb >= 0 && r - 9 < nb) v = T.ktab[fb + (r - 9) * ng + g];
+            }
+            s_fr[r][g] = v;
+        }
+        __syncthreads();
+    }
+    // wave-uniform bases (the quad index is uniform over a wave: one wave = 64 columns of one quad) and per-lane byte offsets
+    const int uquad = __builtin_amdgcn_readfirstlane(quad);
+    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)uquad * nlay * ncb;
+    const scr4 *__restrict__ sCt = reinterpret_cast<const scr4 *>(W.scr[S_CODET]) + (size_t)uquad * nlay * ncb;
+    const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
+    const int *__restrict__ sFlag = W.cflag;
+    const double *__restrict__ tlay = a.tlay + a.col0;
+    const double *__restrict__ tlev = a.tlev + a.col0;
+    const double *__restrict__ cldf = a.cldfrac + a.col0;
+    const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
     Part2 *__restrict__ pdn = W.pdn + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
     Part2 *__restrict__ pup = W.pup + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
     Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    const int laytrop = W.laytrop[colc];
+    const double *tp0 = s_pl[0], *tp1 = s_pl[1];
 
     // adds the round's partials of the band's quads in quad order; wave `slot` finishes levels lev0 + dir * (slot, slot + NQ, ..)
     auto reduce_store = [&](const Part2 (&acc)[LV], Part2 *__restrict__ dst, int lev0, int dir) {
@@ -1892,107 +1889,145 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
         return (unsigned)(((lo | (hi << 32)) >> (ig0 & 31)) & ((1u << nvalid) - 1u));
     };
 
+    // Planck fractions of this thread's g-points in layer `lev`: taumol (constant rows, or :556-561 / :692-693 interpolated between
+    // rows js-1 and js with k_layer's (js, fs) word).  Regions with constant fractions interpolate with weight 0.
+    auto fracs = [&](int lev, unsigned fwv, double (&fr)[NGC]) {
+        const bool lower = lev <= laytrop;
+        if (any_bin) {          // uniform
+            const unsigned w = (lower ? lo_bin : up_bin) ? fwv : 0x10000000u;
+            const int r0 = clampi((lower ? 0 : base_up) + (int)(w >> 28) - 1, 0, 14);
+            const double fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
+            const double *row = &s_fr[r0][4 * slot];
+#pragma unroll
+            for (int j = 0; j < NGC; j++) fr[j] = row[j] + fpl * (row[16 + j] - row[j]);
+        } else {
+            const double *row = &s_fr[lower ? 0 : base_up][4 * slot];
+#pragma unroll
+            for (int j = 0; j < NGC; j++) fr[j] = row[j];
+        }
+    };
+    // layer flag (bit 0: the layer holds cloud) - out-of-range levels are clear
+    auto ldflag = [&](int lev) -> int {
+        if constexpr (MODE == 0) return 0;
+        return (lev >= 1 && lev <= nlay) ? (int)(bload_u32(sFlag + (size_t)lev * ncb, off4) & 1u) : 0;
+    };
+    // the loads of level `lev`: zlev = the interface whose temperature the sweep direction needs, nlev = the next level in sweep
+    // direction; cloudy = the level's flag (known a round earlier) selects the extra loads of a cloudy level
+    auto fill = [&](int lev, int zlev, int nlev, int cloudy, SweepLev &q) {
+        q.w = 0u;
+        if (lev >= 1 && lev <= nlay) {                         // uniform
+            const size_t so = (size_t)(lev - 1) * ncb;
+            q.c = bload_scr4_nt(sC + so, off16);
+            q.tl = bload_f64(tlay + (size_t)nct * (lev - 1), off8);
+            q.tz = bload_f64(tlev + (size_t)nct * zlev, off8);
+            if (any_bin) q.w = bload_u32(sFw + so, off4);
+            if constexpr (MODE != 0) {
+                if (cloudy) {
+                    q.ct = bload_scr4_nt(sCt + so, off16);
+                    if constexpr (MODE == 1 || MODE == 2) q.cf = bload_f64(cldf + (size_t)nct * (lev - 1), off8);
+                    if constexpr (MODE == 2) q.cfn = (nlev >= 1 && nlev <= nlay) ? bload_f64(cldf + (size_t)nct * (nlev - 1), off8) : 0.0;
+                }
+            }
+        }
+    };
+
     bool colcloud = false;
-    if constexpr (MODE != 0) { if (incol) colcloud = (W.cflag[col] & 8) != 0; }
+    if constexpr (MODE != 0) colcloud = (bload_u32(sFlag, off4) & 8u) != 0;
 
     double radld[NGC], radclrd[NGC], cldrad[NGC], clrrad[NGC], radmr[NGC];
 #pragma unroll
     for (int j = 0; j < NGC; j++) { radld[j] = 0.0; radclrd[j] = 0.0; cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
-    int iclddn = 0;
+    bool iclddn = false;
     if (slot == 0 && incol) {   // downward flux at the top level is zero
         Part2 z{0.0, 0.0};
         pdn[(size_t)nlay * ncb] = z;
     }
 
     // ------------------------------------------------------------------ downward sweep, SWEEP_LV levels per round
-    // (the unrolled round keeps the independent per-cell loads of several levels in flight while the recurrence runs)
-    // the unconditional loads of a round (gas terms, layer flags) are issued one round ahead, before the reduction's
-    // barriers, so that they are in flight while the previous round's partial sums meet in LDS
-    scr4 pA[LV], pB[LV];
-    int pF[LV];
-    auto prefetch_down = [&](int top) {
+    // Rolling prefetch: the loads of a level are issued SWEEP_LV levels before it is processed (into the slot of the level just
+    // consumed), its cloud flag 2 x SWEEP_LV levels before, so that the conditional loads of a cloudy level are part of the prefetch.
+    SweepLev p[PF];
+    int fl[2][PF];
 #pragma unroll
-        for (int i = 0; i < LV; i++) {
-            const int lev = top - i;
-            pF[i] = 0;
-            if (active && lev >= 1) {
-                const size_t so = (size_t)(lev - 1) * ncb;
-                pA[i] = scr_load(sA + so);
-                pB[i] = scr_load(sBd + so);
-                if constexpr (MODE != 0) pF[i] = W.cflag[(size_t)lev * ncb + col];
-            }
-        }
-    };
-    prefetch_down(nlay);
+    for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(nlay - i); fl[1][i] = ldflag(nlay - PF - i); }
+#pragma unroll
+    for (int i = 0; i < PF; i++) fill(nlay - i, nlay - i - 1, nlay - i - 1, fl[0][i], p[i]);
+    bool prevcld = false;                // the previous level of the sweep was cloudy (istcldd(lev) == 0)
+    double cfprev = 0.0, rat1 = 0.0, rat2 = 0.0;
     for (int top = nlay; top >= 1; top -= LV) {
         Part2 acc[LV];
-        scr4 cA[LV], cB[LV];
-        int cF[LV];
-#pragma unroll
-        for (int i = 0; i < LV; i++) { cA[i] = pA[i]; cB[i] = pB[i]; cF[i] = pF[i]; }
-        prefetch_down(top - LV);
 #pragma unroll
         for (int i = 0; i < LV; i++) {
             const int lev = top - i;
             acc[i] = Part2{0.0, 0.0};
-            if (!(active && lev >= 1)) continue;
-            int cloudy = 0, flags = 0;
-            double cf = 0.0, efcl = 0.0;
-            if constexpr (MODE != 0) {
-                flags = cF[i];
-                cloudy = flags & 1;
-                if (cloudy) {
-                    if constexpr (MODE != 3 && MODE != 4) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
-                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
-                }
+            const int s = i % PF;
+            const SweepLev cur = p[s];
+            const int cloudy = fl[0][s];
+            fl[0][s] = fl[1][s];
+            fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[0][s], p[s]);
+            fl[1][s] = ldflag(lev - 2 * PF);
+            if (lev < 1) continue;          // uniform
+            double fr[NGC], atr[NGC], bbd[NGC];
+            fracs(lev, cur.w, fr);
+            const double blay = planck_at(tp0, tp0, cur.tl);
+            const double dplankdn = planck_at(tp0, (alt16 && lev == 1) ? tp1 : tp0, cur.tz) - blay;
+#pragma unroll
+            for (int j = 0; j < NGC; j++) {
+                double tfn;
+                decode(cur.c.v[j], s_lut[code_index(cur.c.v[j])], atr[j], tfn);
+                bbd[j] = fr[j] * (blay + tfn * dplankdn);
             }
-            const size_t so = (size_t)(lev - 1) * ncb;
-            const scr4 vatr = cA[i], vbbd = cB[i];
             double dsum = 0.0, dsumc = 0.0;
-            if (!cloudy) {
+            if (MODE == 0 || !cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    const double atr = vatr.v[j], bbd = vbbd.v[j];
-                    radld[j] = radld[j] + (bbd - radld[j]) * atr;
+                    radld[j] = radld[j] + (bbd[j] - radld[j]) * atr[j];
                     dsum = dsum + radld[j];
                     if constexpr (MODE != 0) {
-                        if (iclddn) radclrd[j] = radclrd[j] + (bbd - radclrd[j]) * atr;
-                        else radclrd[j] = radld[j];
+                        const double upd = radclrd[j] + (bbd[j] - radclrd[j]) * atr[j];
+                        radclrd[j] = iclddn ? upd : radld[j];
                         dsumc = dsumc + radclrd[j];
                     }
                 }
+                if constexpr (MODE == 2) prevcld = false;
             } else {
                 if constexpr (MODE != 0) {
-                    iclddn = 1;
-                    const scr4 vatot = scr_load(sT + so), vbbdt = scr_load(sTd + so);
-                    double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
+                    iclddn = true;
+                    const double cf = cur.cf;
+                    double efcl = 0.0;
+                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
+                    OvlFac mf{0, 0, 0, 0, 0, 0, 0, 0};
+                    bool first = false;
                     if constexpr (MODE == 2) {
-                        const size_t mo = (size_t)(lev - 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
-                        fclr1 = W.mrfac[MR_FACCLR1D * ms + mo]; fcld1 = W.mrfac[MR_FACCLD1D * ms + mo];
-                        fcmb1 = W.mrfac[MR_FACCMB1D * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2D * ms + mo];
-                        fclr2 = W.mrfac[MR_FACCLR2D * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2D * ms + mo];
+                        first = !prevcld;
+                        mf = mr_step(cf, cur.cfn, cfprev, first, lev == 1, rat1, rat2);
+                        rat1 = mf.rat1; rat2 = mf.rat2;
+                        prevcld = true;
+                        cfprev = cf;
                     }
                     double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
                     if constexpr (MODE == 3) {          // rtrnmc: cloud fraction and effective emissivity per g-point
-                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
+                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + colc) * 8);
                         const float4 c4 = pc[0], e4 = pc[1];
                         cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
                         efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
                     }
                     if constexpr (MODE == 4) {
                         const unsigned bits = quad_bits(lev);
-                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
+                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
 #pragma unroll
                         for (int j = 0; j < NGC; j++) { const bool on = (bits >> j) & 1u; cfj[j] = on ? 1.0 : 0.0; efj[j] = on ? ef : 0.0; }
                     }
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
-                        const double atr = vatr.v[j], bbd = vbbd.v[j], atot = vatot.v[j], bbdtot = vbbdt.v[j];
-                        const double gassrc = bbd * atr;
+                        double atot, tftot;
+                        decode(cur.ct.v[j], s_lut[code_index(cur.ct.v[j])], atot, tftot);
+                        const double bbdtot = fr[j] * (blay + tftot * dplankdn);
+                        const double gassrc = bbd[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
-                            radld[j] = radld[j] - radld[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbdtot * atot - gassrc);
+                            radld[j] = radld[j] - radld[j] * (atr[j] + efj[j] * (1. - atr[j])) + gassrc + cfj[j] * (bbdtot * atot - gassrc);
                         } else {            // rtrnmr :591-615
-                            if (flags & 4) {        // istcldd(lev) == 1
+                            if (first) {        // istcldd(lev) == 1
                                 cldrad[j] = cf * radld[j];
                                 clrrad[j] = radld[j] - cldrad[j];
                                 radmr[j] = 0.0;
@@ -2000,17 +2035,17 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
                             const double ttot = 1. - atot;
                             const double cldsrc = bbdtot * atot;
                             cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                            clrrad[j] = clrrad[j] * (1. - atr) + (1. - cf) * gassrc;
+                            clrrad[j] = clrrad[j] * (1. - atr[j]) + (1. - cf) * gassrc;
                             radld[j] = cldrad[j] + clrrad[j];
-                            const double radmod = radmr[j] * (fclr1 * (1. - atr) + fcld1 * ttot) - fcmb1 * gassrc + fcmb2 * cldsrc;
+                            const double radmod = radmr[j] * (mf.clr1 * (1. - atr[j]) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
                             const double oldcld = cldrad[j] - radmod;
                             const double oldclr = clrrad[j] + radmod;
-                            radmr[j] = -radmod + fclr2 * oldclr - fcld2 * oldcld;
+                            radmr[j] = -radmod + mf.clr2 * oldclr - mf.cld2 * oldcld;
                             cldrad[j] = cldrad[j] + radmr[j];
                             clrrad[j] = clrrad[j] - radmr[j];
                         }
                         dsum = dsum + radld[j];
-                        radclrd[j] = radclrd[j] + (bbd - radclrd[j]) * atr;
+                        radclrd[j] = radclrd[j] + (bbd[j] - radclrd[j]) * atr[j];
                         dsumc = dsumc + radclrd[j];
                     }
                 }
@@ -2023,19 +2058,21 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
     // ------------------------------------------------------------------ surface: rtrn :476-495
     double radlu[NGC], radclru[NGC], drad[NGC], dradc[NGC];
     Part2 surf{0.0, 0.0}, dsurf{0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < NGC; j++) { radlu[j] = 0.0; radclru[j] = 0.0; drad[j] = 0.0; dradc[j] = 0.0; }
-    if (active) {
+    {
         const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
+        const double pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + colc];
+        const double dpb = idrv ? W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + colc] : 0.0;
+        double fr1[NGC];                     // fracs(1,g): the surface emits with the lowest layer's Planck fractions
+        fracs(1, any_bin ? bload_u32(sFw, off4) : 0u, fr1);
         double usum = 0.0, usumc = 0.0, dusum = 0.0;
 #pragma unroll
         for (int j = 0; j < NGC; j++) {
-            const double rad0 = W.rad0[(size_t)(quad * 4 + j) * ncb + col];
+            const double rad0 = fr1[j] * pb;
             radlu[j] = rad0 + reflect * radld[j];
             radclru[j] = rad0 + reflect * radclrd[j];
             usum = usum + radlu[j];
             usumc = usumc + radclru[j];
-            drad[j] = idrv ? W.rad0[(size_t)(4 * NQUAD + quad * 4 + j) * ncb + col] : 0.0;
+            drad[j] = idrv ? fr1[j] * dpb : 0.0;
             dradc[j] = drad[j];
             dusum = dusum + drad[j];
         }
@@ -2047,96 +2084,88 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
 
     // ------------------------------------------------------------------ upward sweep: round r covers levels base .. base+LV-1,
     // level 0 being the surface value computed above
-    auto prefetch_up = [&](int base) {
 #pragma unroll
-        for (int i = 0; i < LV; i++) {
-            const int lev = base + i;
-            pF[i] = 0;
-            if (active && lev >= 1 && lev <= nlay) {
-                const size_t so = (size_t)(lev - 1) * ncb;
-                pA[i] = scr_load(sA + so);
-                pB[i] = scr_load(sBu + so);
-                if constexpr (MODE != 0) pF[i] = W.cflag[(size_t)lev * ncb + col];
-            }
-        }
-    };
-    prefetch_up(0);
+    for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(i); fl[1][i] = ldflag(PF + i); }
+#pragma unroll
+    for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i]);
+    prevcld = false; cfprev = 0.0; rat1 = 0.0; rat2 = 0.0;
     for (int base = 0; base <= nlay; base += LV) {
         Part2 acc[LV], accd[LV];
-        scr4 cA[LV], cB[LV];
-        int cF[LV];
-#pragma unroll
-        for (int i = 0; i < LV; i++) { cA[i] = pA[i]; cB[i] = pB[i]; cF[i] = pF[i]; }
-        prefetch_up(base + LV);
 #pragma unroll
         for (int i = 0; i < LV; i++) {
             const int lev = base + i;
             acc[i] = Part2{0.0, 0.0};
             accd[i] = Part2{0.0, 0.0};
-            if (!(active && lev <= nlay)) continue;
-            if (lev == 0) { acc[i] = surf; accd[i] = dsurf; continue; }
-            int cloudy = 0, flags = 0;
-            double cf = 0.0, efcl = 0.0;
-            if constexpr (MODE != 0) {
-                flags = cF[i];
-                cloudy = flags & 1;
-                if (cloudy) {
-                    if constexpr (MODE != 3 && MODE != 4) cf = a.cldfrac[gc + (size_t)nct * (lev - 1)];
-                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
-                }
+            const int s = i % PF;
+            const SweepLev cur = p[s];
+            const int cloudy = fl[0][s];
+            fl[0][s] = fl[1][s];
+            fill(lev + PF, lev + PF, lev + PF + 1, fl[0][s], p[s]);
+            fl[1][s] = ldflag(lev + 2 * PF);
+            if (lev > nlay) continue;                                           // uniform
+            if (lev == 0) { acc[i] = surf; accd[i] = dsurf; continue; }         // uniform
+            double fr[NGC], atr[NGC], bbu[NGC];
+            fracs(lev, cur.w, fr);
+            const double blay = planck_at(tp0, tp0, cur.tl);
+            const double dplankup = planck_at(tp0, tp0, cur.tz) - blay;
+#pragma unroll
+            for (int j = 0; j < NGC; j++) {
+                double tfn;
+                decode(cur.c.v[j], s_lut[code_index(cur.c.v[j])], atr[j], tfn);
+                bbu[j] = fr[j] * (blay + tfn * dplankup);
             }
-            const size_t so = (size_t)(lev - 1) * ncb;
-            const scr4 vatr = cA[i], vbbu = cB[i];
             double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
-            if (!cloudy) {
+            if (MODE == 0 || !cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    const double atr = vatr.v[j], bbu = vbbu.v[j];
-                    radlu[j] = radlu[j] + (bbu - radlu[j]) * atr;
+                    radlu[j] = radlu[j] + (bbu[j] - radlu[j]) * atr[j];
                     usum = usum + radlu[j];
-                    if (idrv) { drad[j] = drad[j] * (1.0 - atr); dusum = dusum + drad[j]; }
+                    if (idrv) { drad[j] = drad[j] * (1.0 - atr[j]); dusum = dusum + drad[j]; }
                     if constexpr (MODE != 0) {
-                        if (colcloud) {
-                            radclru[j] = radclru[j] + (bbu - radclru[j]) * atr;
-                            if (idrv) { dradc[j] = dradc[j] * (1.0 - atr); dusumc = dusumc + dradc[j]; }
-                        } else {
-                            radclru[j] = radlu[j];
-                            if (idrv) { dradc[j] = drad[j]; dusumc = dusumc + dradc[j]; }
-                        }
+                        const double upd = radclru[j] + (bbu[j] - radclru[j]) * atr[j];
+                        radclru[j] = colcloud ? upd : radlu[j];
+                        if (idrv) { dradc[j] = colcloud ? dradc[j] * (1.0 - atr[j]) : drad[j]; dusumc = dusumc + dradc[j]; }
                         usumc = usumc + radclru[j];
                     }
                 }
+                if constexpr (MODE == 2) prevcld = false;
             } else {
                 if constexpr (MODE != 0) {
-                    const scr4 vatot = scr_load(sT + so), vbbut = scr_load(sTu + so);
-                    double fclr1 = 0, fcld1 = 0, fcmb1 = 0, fcmb2 = 0, fclr2 = 0, fcld2 = 0;
+                    const double cf = cur.cf;
+                    double efcl = 0.0;
+                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
+                    OvlFac mf{0, 0, 0, 0, 0, 0, 0, 0};
+                    bool first = false;
                     if constexpr (MODE == 2) {
-                        const size_t mo = (size_t)(lev + 1) * ncb + col, ms = (size_t)(nlay + 2) * ncb;
-                        fclr1 = W.mrfac[MR_FACCLR1 * ms + mo]; fcld1 = W.mrfac[MR_FACCLD1 * ms + mo];
-                        fcmb1 = W.mrfac[MR_FACCMB1 * ms + mo]; fcmb2 = W.mrfac[MR_FACCMB2 * ms + mo];
-                        fclr2 = W.mrfac[MR_FACCLR2 * ms + mo]; fcld2 = W.mrfac[MR_FACCLD2 * ms + mo];
+                        first = !prevcld;
+                        mf = mr_step(cf, cur.cfn, cfprev, first, lev == nlay, rat1, rat2);
+                        rat1 = mf.rat1; rat2 = mf.rat2;
+                        prevcld = true;
+                        cfprev = cf;
                     }
                     double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
                     if constexpr (MODE == 3) {
-                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + col) * 8);
+                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + colc) * 8);
                         const float4 c4 = pc[0], e4 = pc[1];
                         cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
                         efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
                     }
                     if constexpr (MODE == 4) {
                         const unsigned bits = quad_bits(lev);
-                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + col];
+                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
 #pragma unroll
                         for (int j = 0; j < NGC; j++) { const bool on = (bits >> j) & 1u; cfj[j] = on ? 1.0 : 0.0; efj[j] = on ? ef : 0.0; }
                     }
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
-                        const double atr = vatr.v[j], bbu = vbbu.v[j], atot = vatot.v[j], bbutot = vbbut.v[j];
-                        const double gassrc = bbu * atr;
+                        double atot, tftot;
+                        decode(cur.ct.v[j], s_lut[code_index(cur.ct.v[j])], atot, tftot);
+                        const double bbutot = fr[j] * (blay + tftot * dplankup);
+                        const double gassrc = bbu[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
-                            radlu[j] = radlu[j] - radlu[j] * (atr + efj[j] * (1. - atr)) + gassrc + cfj[j] * (bbutot * atot - gassrc);
+                            radlu[j] = radlu[j] - radlu[j] * (atr[j] + efj[j] * (1. - atr[j])) + gassrc + cfj[j] * (bbutot * atot - gassrc);
                         } else {            // rtrnmr :680-703
-                            if (flags & 2) {        // istcld(lev) == 1
+                            if (first) {        // istcld(lev) == 1
                                 cldrad[j] = cf * radlu[j];
                                 clrrad[j] = radlu[j] - cldrad[j];
                                 radmr[j] = 0.0;
@@ -2144,23 +2173,23 @@ __global__ __launch_bounds__(64 * NQ, RRLW_SWEEP_WAVES) void k_sweep(DevTables T
                             const double ttot = 1. - atot;
                             const double cldsrc = bbutot * atot;
                             cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                            clrrad[j] = clrrad[j] * (1.0 - atr) + (1. - cf) * gassrc;
+                            clrrad[j] = clrrad[j] * (1.0 - atr[j]) + (1. - cf) * gassrc;
                             radlu[j] = cldrad[j] + clrrad[j];
-                            const double radmod = radmr[j] * (fclr1 * (1.0 - atr) + fcld1 * ttot) - fcmb1 * gassrc + fcmb2 * cldsrc;
+                            const double radmod = radmr[j] * (mf.clr1 * (1.0 - atr[j]) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
                             const double oldcld = cldrad[j] - radmod;
                             const double oldclr = clrrad[j] + radmod;
-                            radmr[j] = -radmod + fclr2 * oldclr - fcld2 * oldcld;
+                            radmr[j] = -radmod + mf.clr2 * oldclr - mf.cld2 * oldcld;
                             cldrad[j] = cldrad[j] + radmr[j];
                             clrrad[j] = clrrad[j] - radmr[j];
                         }
                         usum = usum + radlu[j];
                         if (idrv) {
-                            drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr);
+                            drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr[j]);
                             dusum = dusum + drad[j];
-                            dradc[j] = dradc[j] * (1.0 - atr);
+                            dradc[j] = dradc[j] * (1.0 - atr[j]);
                             dusumc = dusumc + dradc[j];
                         }
-                        radclru[j] = radclru[j] + (bbu - radclru[j]) * atr;
+                        radclru[j] = radclru[j] + (bbu[j] - radclru[j]) * atr[j];
                         usumc = usumc + radclru[j];
                     }
                 }

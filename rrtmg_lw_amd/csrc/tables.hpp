@@ -144,6 +144,7 @@ struct StaticLayout {
     int absliq1;                  // [16][58]
     int lut;                      // [10001][2]  (exp_tbl, tfn_tbl)
     int tau_tbl;                  // [10001]
+    int lutf;                     // [10002] float pairs {1 - exp_tbl, tfn_tbl} (8 bytes each; the copy k_sweep stages in LDS)
 };
 
 struct HostTables {
@@ -334,6 +335,13 @@ inline bool build_tables(const std::string &static_path, const std::string &kdat
         }
         T.sl.lut = put(lut.data(), lut.size());
         T.sl.tau_tbl = put(tau.data(), tau.size());
+        // float copy for k_sweep: the transmittance complement is formed in float64 and rounded once
+        std::vector<double> lutf(NTBL + 2, 0.0);
+        for (int i = 0; i <= NTBL; i++) {
+            const float pr[2] = {(float)(1.0 - lut[2 * i]), (float)lut[2 * i + 1]};
+            std::memcpy(&lutf[i], pr, 8);
+        }
+        T.sl.lutf = put(lutf.data(), lutf.size());
     }
     // per-band reference ratios of taumol (refrat_planck_a/b, refrat_m_a/b/..; src/rrtmg_lw_taumol.f90:504-513,
     // :812-815, :1080-1086, :1442-1445, :1839-1842, :2242, :2454-2460, :2770-2773, :2991)

@@ -103,6 +103,10 @@ def main():
             row.update(wait_any=round(m.get("SQ_WAIT_ANY", 0.0) / wc, 3), wait_inst_any=round(m.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3),
                        active_inst_any=round(m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3),
                        active_inst_valu=round(m.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 3))
+            if "SQ_INSTS_LDS" in m:
+                row.update(lds_per_wave=round(m["SQ_INSTS_LDS"] / waves, 1) if waves else None,
+                           wait_inst_lds=round(m.get("SQ_WAIT_INST_LDS", 0.0) / wc, 3),
+                           lds_bank_conflict_frac=round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(m.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 3))
         rows.append(row)
     cols = list(rows[0].keys()) if rows else []
     for r in rows:
