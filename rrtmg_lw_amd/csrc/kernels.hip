@@ -22,6 +22,7 @@
 // Reference lines are cited per routine.  No CPU fallback exists anywhere in this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <utility>
 
 #include "tables.hpp"
@@ -850,6 +851,87 @@ __device__ __forceinline__ double2 ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned ele
     return d;
 }
 
+// the same 16 bytes from the band's tables staged in LDS (element offset into the staging buffer)
+__device__ __forceinline__ double2 ldl(const double2 *lds, unsigned elem_off) { return lds[elem_off >> 1]; }
+
+// ------------------------------------------------------------------------------------------------
+// Staging of a band's tables in LDS.  The table evaluation returns ~15 KB of table rows per (layer, column) to registers; through the
+// vector L1 that is bound by its 64 B/clk return path (measured: 90 % of it), LDS returns 256 B/clk.  All threads of a k_layer
+// workgroup work on the SAME layer, so they need the same few pressure planes of the key-species tables: the workgroup stages the
+// planes jp0 .. jp0+2 (jp0 = its smallest reference-pressure index; a cell uses planes jp and jp+1), the whole self / foreign /
+// minor-gas / halocarbon tables of the band, and evaluates from LDS.  A wave with a cell outside the window (other region of the
+// atmosphere, or jp > jp0 + 1) evaluates from global memory as before - same values either way.
+// ------------------------------------------------------------------------------------------------
+enum Role { RL_MAJOR, RL_SELF, RL_FOR, RL_MINOR0, RL_MINOR1, RL_MINOR2, RL_CFC0, RL_CFC1, NROLE };
+
+template <int B, bool LOWER>
+struct Stage {
+    static constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
+    static constexpr int ng = BT<B>::ng;
+    static constexpr int nsp = R.key == K_BINARY ? (LOWER ? 9 : 5) : 1;          // mixture points per (P, T) node
+    static constexpr int NPL = 3;                                                // pressure planes staged
+    static constexpr bool has_major = R.key == K_SINGLE || R.key == K_BINARY;
+    static constexpr int major_rows = has_major ? NPL * 5 * nsp + 3 : 0;         // + 3: zero-weight stencil rows may lie past the last plane
+    static constexpr int mrows(int k) { return k < R.nm ? 19 * (R.m[k].two_d ? (LOWER ? 9 : 5) : 1) : 0; }
+    static constexpr int l_major = 0;                                            // LDS start of each segment, in doubles
+    static constexpr int l_self = l_major + major_rows * ng;
+    static constexpr int l_for = l_self + (R.self_ ? 10 * ng : 0);
+    static constexpr int l_m0 = l_for + (R.for_ ? 4 * ng : 0);
+    static constexpr int l_m1 = l_m0 + mrows(0) * ng;
+    static constexpr int l_m2 = l_m1 + mrows(1) * ng;
+    static constexpr int l_c0 = l_m2 + mrows(2) * ng;
+    static constexpr int l_c1 = l_c0 + (R.ncfc > 0 ? ng : 0);
+    static constexpr int total = l_c1 + (R.ncfc > 1 ? ng : 0);
+};
+template <int B> constexpr int stage_max() { return std::max(std::max(Stage<B, true>::total, Stage<B, false>::total), stage_max<B - 1>()); }
+template <> constexpr int stage_max<0>() { return 0; }
+constexpr int STAGE_DOUBLES = stage_max<16>();       // 5166 doubles = 41.3 KB (bands 3 and 5, lower atmosphere)
+
+// copies [g0, g0 + n) doubles of the packed table buffer to lds[l0 ..) (all even) and returns l0 - g0
+__device__ __forceinline__ unsigned stage_seg(__amdgpu_buffer_rsrc_t kt, double2 *lds, unsigned g0, int n, int l0, int tid, int nth)
+{
+    for (int i = tid; i < n / 2; i += nth) lds[l0 / 2 + i] = ld2(kt, g0 + 2u * (unsigned)i);
+    return (unsigned)l0 - g0;
+}
+
+template <int B, bool LOWER>
+__device__ __forceinline__ void stage_band(const DevTables &T, __amdgpu_buffer_rsrc_t kt, double2 *lds, int jp0, int tid, int nth, unsigned (&delta)[NROLE])
+{
+    using S = Stage<B, LOWER>;
+    constexpr Region R = S::R;
+    constexpr int ng = S::ng;
+    const BandLayout &L = T.band[B - 1];
+#pragma unroll
+    for (int r = 0; r < NROLE; r++) delta[r] = 0u;
+    if constexpr (S::has_major) {
+        const int plane0 = LOWER ? jp0 - 1 : jp0 - 13;
+        const unsigned g0 = (unsigned)(LOWER ? L.absa : L.absb) + (unsigned)(plane0 * 5 * S::nsp * ng);
+        delta[RL_MAJOR] = stage_seg(kt, lds, g0, S::major_rows * ng, S::l_major, tid, nth);
+    }
+    if constexpr (R.self_) delta[RL_SELF] = stage_seg(kt, lds, (unsigned)L.selfref, 10 * ng, S::l_self, tid, nth);
+    if constexpr (R.for_) delta[RL_FOR] = stage_seg(kt, lds, (unsigned)L.forref, 4 * ng, S::l_for, tid, nth);
+    if constexpr (R.nm > 0) delta[RL_MINOR0] = stage_seg(kt, lds, (unsigned)(LOWER ? L.minor_lo[0] : L.minor_up[0]), S::mrows(0) * ng, S::l_m0, tid, nth);
+    if constexpr (R.nm > 1) delta[RL_MINOR1] = stage_seg(kt, lds, (unsigned)(LOWER ? L.minor_lo[1] : L.minor_up[1]), S::mrows(1) * ng, S::l_m1, tid, nth);
+    if constexpr (R.nm > 2) delta[RL_MINOR2] = stage_seg(kt, lds, (unsigned)L.minor_lo[2], S::mrows(2) * ng, S::l_m2, tid, nth);
+    if constexpr (R.ncfc > 0) delta[RL_CFC0] = stage_seg(kt, lds, (unsigned)L.vec[0], ng, S::l_c0, tid, nth);
+    if constexpr (R.ncfc > 1) delta[RL_CFC1] = stage_seg(kt, lds, (unsigned)L.vec[1], ng, S::l_c1, tid, nth);
+}
+
+// row offsets of the packed table buffer -> offsets into the staging buffer (rows_prep's row order: key species, self, foreign, minors, halocarbons)
+template <int B, bool LOWER, int N>
+__device__ __forceinline__ void rows_to_lds(Rows<N> &rw, const unsigned (&delta)[NROLE])
+{
+    constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
+    constexpr int IS = region_major_rows(R, LOWER), IF = IS + (R.self_ ? 2 : 0), IM0 = IF + (R.for_ ? 2 : 0);
+    constexpr int IM1 = region_minor_base(R, LOWER, 1), IM2 = region_minor_base(R, LOWER, 2), IC = region_minor_base(R, LOWER, R.nm);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int role = i < IS ? RL_MAJOR : i < IF ? RL_SELF : i < IM0 ? RL_FOR :
+                         (i < IC ? (R.nm > 1 && i >= IM1 ? (R.nm > 2 && i >= IM2 ? RL_MINOR2 : RL_MINOR1) : RL_MINOR0) : (i == IC ? RL_CFC0 : RL_CFC1));
+        rw.off[i] = rw.off[i] + delta[role];
+    }
+}
+
 // tau and Planck fraction of ALL g-points of band B (padded to whole quads with zeros).
 // Measured on MI355X (profiles/round1_pmc_v2_two_phase.md): k_layer is bound by exposed memory latency at one wave
 // per SIMD (VALU 12-20 % busy; making every gather wave-uniform or dropping the stores changes little).  The table
@@ -874,14 +956,13 @@ struct BandLoads {
     static constexpr int CH = RRLW_LOAD_CHUNK;
     static constexpr int NCH = (NL + CH - 1) / CH;
 
-    template <int C>
-    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double2 (&b)[CH])
+    template <int C, bool LDS>
+    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t kt, const double2 *lds, const Rows<N> &rw, double2 (&b)[CH])
     {
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-            constexpr int dummy = 0; (void)dummy;
             const int idx = C * CH + k;
-            if (idx < NK) b[k] = ld2(kt, rw.off[idx / HP] + 2u * (unsigned)(idx % HP));
+            if (idx < NK) b[k] = LDS ? ldl(lds, rw.off[idx / HP] + 2u * (unsigned)(idx % HP)) : ld2(kt, rw.off[idx / HP] + 2u * (unsigned)(idx % HP));
         }
     }
 
@@ -899,22 +980,22 @@ struct BandLoads {
         }
     }
 
-    template <int C>
-    static __device__ __forceinline__ void step(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double2 (&cur)[CH], double2 (&nxt)[CH],
+    template <int C, bool LDS>
+    static __device__ __forceinline__ void step(__amdgpu_buffer_rsrc_t kt, const double2 *lds, const Rows<N> &rw, double2 (&cur)[CH], double2 (&nxt)[CH],
                                                 double *tau)
     {
         if constexpr (C < NCH) {
-            if constexpr (C + 1 < NCH) issue<C + 1>(kt, rw, nxt);
+            if constexpr (C + 1 < NCH) issue<C + 1, LDS>(kt, lds, rw, nxt);
             __builtin_amdgcn_sched_barrier(0);
             consume<C>(rw, cur, tau);
             __builtin_amdgcn_sched_barrier(0);
-            step<C + 1>(kt, rw, nxt, cur, tau);
+            step<C + 1, LDS>(kt, lds, rw, nxt, cur, tau);
         }
     }
 };
 
-template <int B, bool LOWER, int N>
-__device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, double (&tau)[4 * band_nquad(B)])
+template <int B, bool LOWER, int N, bool LDS>
+__device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const double2 *lds, const Rows<N> &rw, double (&tau)[4 * band_nquad(B)])
 {
     using BL = BandLoads<B, LOWER, N>;
     constexpr int NP = 4 * band_nquad(B);
@@ -922,8 +1003,8 @@ __device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const 
     for (int j = 0; j < NP; j++) tau[j] = 0.0;
     if constexpr (BL::NL > 0) {
         double2 b0[BL::CH], b1[BL::CH];
-        BL::template issue<0>(kt, rw, b0);
-        BL::template step<0>(kt, rw, b0, b1, tau);
+        BL::template issue<0, LDS>(kt, lds, rw, b0);
+        BL::template step<0, LDS>(kt, lds, rw, b0, b1, tau);
 #pragma unroll
         for (int j = 0; j < BL::ng; j++) {
             if constexpr (BL::R.mult == 4) tau[j] = tau[j] * kMult4[j];
@@ -986,9 +1067,9 @@ __device__ __forceinline__ scr_t cell_code(double od, bool series, double bpade)
 // all cells (g-points) of band B of one (layer, column).
 // CLOUD: 0 clear-sky set, 1 one cloud optical depth per band (rtrn / rtrnmr), 2 one per g-point from W.odg (rtrnmc, sub-column
 // arrays), 3 the band's value where the sub-column mask has a bit (rtrnmc, generator mask; gbits = the band's ng mask bits)
-template <int B, int CLOUD, bool LOWER, int N>
-__device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const Rows<N> &rw, int lay, int col,
-                                           double secdiff, double taua, int cloudy, double odcld, unsigned gbits)
+template <int B, int CLOUD, bool LOWER, int N, bool LDS>
+__device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &W, __amdgpu_buffer_rsrc_t kt, const double2 *lds, const Rows<N> &rw, int lay, int col,
+                                           bool incol, double secdiff, double taua, int cloudy, double odcld, unsigned gbits)
 {
     constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
     constexpr int ng = BT<B>::ng;
@@ -996,7 +1077,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
     double od[NP];
-    rows_eval_band<B, LOWER, N>(kt, rw, od);
+    rows_eval_band<B, LOWER, N, LDS>(kt, lds, rw, od);
     const double *S = T.stat;
     const double *__restrict__ tau_tbl = S + T.sl.tau_tbl;
     const double bpade = T.bpade;
@@ -1010,7 +1091,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     }
 #pragma unroll
     for (int j = 0; j < NP; j++) asm volatile("" : "+v"(od[j]));   // pin: the values exist here (LLVM's Sink pass may not move their FMA chains past this point)
-    if constexpr (R.key == K_BINARY) W.fw[((size_t)fw_slot(B) * nlay + (lay - 1)) * ncb + col] = rw.fw;
+    if constexpr (R.key == K_BINARY) { if (incol) W.fw[((size_t)fw_slot(B) * nlay + (lay - 1)) * ncb + col] = rw.fw; }
     const size_t so0 = ((size_t)QS * nlay + (lay - 1)) * ncb + col;     // scratch cell of the band's first quad
     const size_t qstride = (size_t)nlay * ncb;
     // gas: series for od <= 0.06, else the table (rtrn :372-451; in a cloudy layer the branch taken for the gas terms depends on od alone)
@@ -1019,7 +1100,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
         scr4 c;
 #pragma unroll
         for (int k = 0; k < 4; k++) c.v[k] = cell_code(od[4 * q + k], od[4 * q + k] <= 0.06, bpade);
-        scr_store(W.scr[S_CODE], so0 + q * qstride, c);
+        if (incol) scr_store(W.scr[S_CODE], so0 + q * qstride, c);
     }
     if (CLOUD && cloudy) {
         // cloudy layer, the three sub-branches of rtrn :372-435:
@@ -1069,7 +1150,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
                         const double odtot = (p3 ? tg[k] : od[j]) + odc[k];
                         c.v[kk] = j < ng ? cell_code(odtot, p1, bpade) : (scr_t)0;
                     }
-                    scr_store(W.scr[S_CODET], so0 + (q0 + q) * qstride, c);
+                    if (incol) scr_store(W.scr[S_CODET], so0 + (q0 + q) * qstride, c);
                 }
             }
         }
@@ -1081,11 +1162,27 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
                                   // spill space), so a 512-register budget buys nothing
 #endif
 
+// workgroup-level state of the LDS staging: the staged region (lower / upper atmosphere) and first pressure plane, this thread's
+// place in the copy loops, and whether this thread's cell lies inside the staged window
+struct LayerWg { double2 *lds; int jp0, tid, nth; bool lower, ok; };
+
 // all cells of band B for one (layer, column)
 template <int B, int CLOUD>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
-                                           __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy, const unsigned (&mw)[5])
+                                           __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol, int cloudy,
+                                           const unsigned (&mw)[5])
 {
+    // the band's tables -> LDS (see Stage); the barriers are reached by every thread of the workgroup (the band test is uniform)
+    unsigned delta[NROLE];
+#pragma unroll
+    for (int r = 0; r < NROLE; r++) delta[r] = 0u;
+    if ((wg.lower ? Stage<B, true>::total : Stage<B, false>::total) > 0) {      // uniform; regions without tables stage nothing
+        __syncthreads();                // the previous band's readers are done with the staging buffer
+        if (wg.lower) stage_band<B, true>(T, kt, wg.lds, wg.jp0, wg.tid, wg.nth, delta);
+        else stage_band<B, false>(T, kt, wg.lds, wg.jp0, wg.tid, wg.nth, delta);
+        __syncthreads();
+    }
+    const bool use_lds = __builtin_amdgcn_ballot_w64(!wg.ok) == 0ull;       // wave-uniform: every cell of the wave lies in the staged window
     const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
     double odcld = 0.0;
     if constexpr (CLOUD == 1 || CLOUD == 3) odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col];   // zero for clear layers (k_cloud / k_cloudmc)
@@ -1101,12 +1198,22 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         constexpr int N = region_nrows(BT<B>::lo, true);
         Rows<N> rw;
         rows_prep<B, true, N>(T, C, rw);
-        band_cells<B, CLOUD, true, N>(T, W, kt, rw, lay, col, secdiff, taua, cloudy, odcld, gbits);
+        if (use_lds) {
+            rows_to_lds<B, true, N>(rw, delta);
+            band_cells<B, CLOUD, true, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
+        } else {
+            band_cells<B, CLOUD, true, N, false>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
+        }
     } else {
         constexpr int N = region_nrows(BT<B>::up, false);
         Rows<N> rw;
         rows_prep<B, false, N>(T, C, rw);
-        band_cells<B, CLOUD, false, N>(T, W, kt, rw, lay, col, secdiff, taua, cloudy, odcld, gbits);
+        if (use_lds) {
+            rows_to_lds<B, false, N>(rw, delta);
+            band_cells<B, CLOUD, false, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
+        } else {
+            band_cells<B, CLOUD, false, N, false>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
+        }
     }
 }
 
@@ -1136,17 +1243,20 @@ GROUP_BANDS(9, 6, 1, 10) GROUP_BANDS(9, 7, 2, 11) GROUP_BANDS(9, 8, 6, 12)
 
 template <class GB, int CLOUD, int... K>
 __device__ __forceinline__ void group_run(std::integer_sequence<int, K...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
-                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, bool lower, int lay, int col, int cloudy,
-                                          const unsigned (&mw)[5])
+                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
+                                          int cloudy, const unsigned (&mw)[5])
 {
-    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, lower, lay, col, cloudy, mw) : (void)0), ...);
+    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw) : (void)0), ...);
 }
 
 template <bool GCM, int CLOUD, int GROUP>
 __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= a.ncol) return;
+    __shared__ double2 s_tab[STAGE_DOUBLES / 2];
+    __shared__ int s_wg[2];
+    const int colr = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool incol = colr < a.ncol;
+    const int col = incol ? colr : a.ncol - 1;      // threads past the end shadow the last column (they take part in the staging and the barriers)
     const int lay = blockIdx.y + 1;
     const size_t gc = (size_t)a.col0 + col;
     const int nct = a.nct;
@@ -1261,7 +1371,17 @@ __global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Wo
         }
     }
     using GB = GroupBands<NLGROUP, GROUP>;
-    group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, lower, lay, col, cloudy, mw);
+    // staging window of the workgroup: the region of its first thread, the smallest jp among the cells of that region
+    if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; }
+    __syncthreads();
+    LayerWg wg;
+    wg.lds = s_tab; wg.tid = threadIdx.x; wg.nth = blockDim.x;
+    wg.lower = s_wg[0] != 0;
+    if (lower == wg.lower) atomicMin(&s_wg[1], jp);
+    __syncthreads();
+    wg.jp0 = s_wg[1];
+    wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= 1u;
+    group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
 }
 
 // ------------------------------------------------------------------------------------------------
