@@ -33,7 +33,7 @@ struct State {
     bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloud of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *taucloud, *odcld, *efcl, *mrfac; int *cflag; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *taucloud, *odcld, *efcl; int *cflag; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by k_sweep exists twice as well: k_sweep/k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -149,7 +149,8 @@ hipEvent_t get_event()
 template <int M, int Q>
 int sweep_attr_one()
 {
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M)));
     return 0;
 }
 template <int M>
@@ -210,7 +211,6 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
             items.push_back({(void **)&ps.taucloud, 16 * L * n * 8});
             items.push_back({(void **)&ps.odcld, 16 * L * n * 8});
             items.push_back({(void **)&ps.efcl, 16 * L * n * 8});
-            items.push_back({(void **)&ps.mrfac, (size_t)NMRFAC * (L + 2) * n * 8});
         }
     }
     if (mc) {
@@ -230,7 +230,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     {   // G.W itself carries prep set 0 and scratch set 0
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
-        W.taucloud = ps.taucloud; W.odcld = ps.odcld; W.efcl = ps.efcl; W.mrfac = ps.mrfac;
+        W.taucloud = ps.taucloud; W.odcld = ps.odcld; W.efcl = ps.efcl;
     }
     G.ws_bytes = total;
     G.ws_nlay = nlay;
@@ -258,7 +258,7 @@ Workspace ws_for(int k)
     Workspace w = G.W;
     const State::PrepSet &ps = G.prep[k];
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
-    w.taucloud = ps.taucloud; w.odcld = ps.odcld; w.efcl = ps.efcl; w.mrfac = ps.mrfac;
+    w.taucloud = ps.taucloud; w.odcld = ps.odcld; w.efcl = ps.efcl;
     const State::ScrSet &ss = G.scrset[G.ws_two_scr ? k : 0];
     for (int a = 0; a < NSCR; a++) w.scr[a] = ss.scr[a];
     w.fw = ss.fw;
@@ -297,13 +297,13 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     la.ncol = nb; la.col0 = col0; la.nct = nct; la.idrv = idrv; la.istart = istart; la.iend = iend;
     la.ktab_bytes = (int)(G.H.ktab.size() * 8);
     la.tauaer = GCM ? g.tauaer : c.taua;
-    const unsigned gx = (nb + BLOCK - 1) / BLOCK;
-    const dim3 lgrid(gx, nlay);
+    const unsigned gx = (nb + LAYER_BLOCK - 1) / LAYER_BLOCK;
+    const dim3 lgrid(gx, nlay), lblock(LAYER_BLOCK);
 #define LAYER_GROUP(GR)                                                                                              \
-    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, block, s, G.D, Wk, g, c, la);         \
-    else if (mode == 3) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<GCM, 2, GR>), lgrid, block, s, G.D, Wk, g, c, la); \
-                          else if constexpr (GCM) LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, block, s, G.D, Wk, g, c, la); } \
-    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, block, s, G.D, Wk, g, c, la);
+    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, lblock, s, G.D, Wk, g, c, la);         \
+    else if (mode == 3) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<GCM, 2, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); \
+                          else if constexpr (GCM) LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); } \
+    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, lblock, s, G.D, Wk, g, c, la);
     LAYER_GROUP(0)
 #if RRLW_LAYER_GROUPS > 1
     LAYER_GROUP(1)
@@ -349,7 +349,8 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     do {                                                                                                             \
         const int ns = sweep_ns(Q, M);                                                                               \
         const dim3 sgrid((nb + 64 * ns - 1) / (64 * ns), nb_bands), sblock(64, Q, ns);                               \
-        LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q>), sgrid, sblock, sweep_lds_bytes(Q, M), s, G.D, Wk, sa);  \
+        if (idrv == 1) LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, true>), sgrid, sblock, sweep_lds_bytes(Q, M), s, G.D, Wk, sa);  \
+        else LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, false>), sgrid, sblock, sweep_lds_bytes(Q, M), s, G.D, Wk, sa);          \
     } while (0)
 #define SWEEP_MODE(Q)                                                          \
         if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q);

@@ -53,9 +53,6 @@ enum Field {
 };
 // per-column doubles, each [ncolb]
 enum PerCol { PC_PLANKBND = 0, PC_DPLANKBND = 16, PC_SECDIFF = 32, NPERCOL = 48 };
-// rtrnmr overlap factors, each [(nlay+2)][ncolb], level index 0..nlay+1
-enum MrFac { MR_FACCLD1, MR_FACCLD2, MR_FACCLR1, MR_FACCLR2, MR_FACCMB1, MR_FACCMB2,
-             MR_FACCLD1D, MR_FACCLD2D, MR_FACCLR1D, MR_FACCLR2D, MR_FACCMB1D, MR_FACCMB2D, NMRFAC };
 // per-cell transmittance codes handed from k_layer to k_sweep, each [NQUAD][nlay][ncolb][4] (see cell_code):
 // gas optical depth of every cell, total (gas + cloud) optical depth of the cells of cloudy layers
 enum Scr { S_CODE, S_CODET, NSCR };
@@ -74,7 +71,6 @@ struct Workspace {
     double *taucloud;   // [16][nlay][ncolb]   cldprop output
     double *odcld;      // [16][nlay][ncolb]   secdiff(ib) * taucloud
     double *efcl;       // [16][nlay][ncolb]   rtrn: (1 - exp(-odcld)) * cldfrac
-    double *mrfac;      // [NMRFAC][nlay+2][ncolb]
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcld, bit2 istcldd; cflag[0] bit3 = column has cloud
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
     unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
@@ -209,9 +205,7 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
 
 // ------------------------------------------------------------------------------------------------
 // k_cloud : cldprop (src/rrtmg_lw_cldprop.f90:50-295), cloud optical depth along the diffusivity
-//           angle (rtrn :321-334 / rtrnmr :333-343) and the maximum-random overlap factors
-//           (src/rrtmg_lw_rtrnmr.f90:347-506).  mode 1 = rtrn, 2 = rtrnmr.
-//           Values the reference reads uninitialised (faccmb1/2, faccmb1d/2d: SURVEY.md 0.4) are ZERO.
+//           angle (rtrn :321-334 / rtrnmr :333-343).  mode 1 = rtrn, 2 = rtrnmr.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int icb_map(int ib, int ind)   // cldprop :167-169 (1-based ib)
 {
@@ -344,159 +338,7 @@ __global__ __launch_bounds__(256) void k_cloud(DevTables T, Workspace W, GcmIn g
     }
     W.cflag[col] = anycloud ? 8 : 0;
     W.cflag[(size_t)(nlay + 1) * W.ncolb + col] = 0;
-    if (mode != 2) return;
-
-    // ---- maximum-random overlap factors: rtrnmr :347-506 ----------------------------------------------
-#define CF(l) cldfr[gc + (size_t)nct * ((l)-1)]
-#define ICLD(l) (W.cflag[(size_t)(l) * W.ncolb + col] & 1)
-#define MR(k, l) W.mrfac[((size_t)(k) * (nlay + 2) + (l)) * W.ncolb + col]
-    for (int k = 0; k < NMRFAC; k++)
-        for (int l = 0; l <= nlay + 1; l++) MR(k, l) = 0.0;
-    double rat1 = 0.0, rat2 = 0.0;
-    {
-        int ist = 1;           // istcld(lev)
-        for (int lev = 1; lev <= nlay; lev++) {
-            int ist_next;
-            if (ICLD(lev)) {
-                ist_next = 0;
-                const double cl = CF(lev);
-                if (lev == nlay) {
-                    // all factors at lev+1 stay zero
-                } else {
-                    const double cu = CF(lev + 1);
-                    if (cu >= cl) {
-                        // faccld1/2(lev+1) = 0
-                        if (ist == 1) {
-                            double v2 = 0.0;
-                            if (cl < 1.) v2 = (cu - cl) / (1. - cl);
-                            MR(MR_FACCLR1, lev + 1) = 0.0;
-                            MR(MR_FACCLR2, lev + 1) = v2;
-                            MR(MR_FACCLR2, lev) = 0.0;
-                            MR(MR_FACCLD2, lev) = 0.0;
-                        } else {
-                            const double cd = CF(lev - 1);
-                            const double fmx = fmax(cl, cd);
-                            if (cu > fmx) {
-                                MR(MR_FACCLR1, lev + 1) = rat2;
-                                MR(MR_FACCLR2, lev + 1) = (cu - fmx) / (1. - fmx);
-                            } else if (cu < fmx) {
-                                MR(MR_FACCLR1, lev + 1) = (cu - cl) / (cd - cl);
-                                MR(MR_FACCLR2, lev + 1) = 0.0;
-                            } else {
-                                MR(MR_FACCLR1, lev + 1) = rat2;
-                                MR(MR_FACCLR2, lev + 1) = 0.0;
-                            }
-                        }
-                        if (MR(MR_FACCLR1, lev + 1) > 0. || MR(MR_FACCLR2, lev + 1) > 0.) { rat1 = 1.; rat2 = 0.; }
-                        else { rat1 = 0.; rat2 = 0.; }
-                    } else {
-                        // facclr1/2(lev+1) = 0
-                        if (ist == 1) {
-                            MR(MR_FACCLD1, lev + 1) = 0.0;
-                            MR(MR_FACCLD2, lev + 1) = (cl - cu) / cl;
-                            MR(MR_FACCLR2, lev) = 0.0;
-                            MR(MR_FACCLD2, lev) = 0.0;
-                        } else {
-                            const double cd = CF(lev - 1);
-                            const double fmn = fmin(cl, cd);
-                            if (cu <= fmn) {
-                                MR(MR_FACCLD1, lev + 1) = rat1;
-                                MR(MR_FACCLD2, lev + 1) = (fmn - cu) / fmn;
-                            } else {
-                                MR(MR_FACCLD1, lev + 1) = (cl - cu) / (cl - fmn);
-                                MR(MR_FACCLD2, lev + 1) = 0.0;
-                            }
-                        }
-                        if (MR(MR_FACCLD1, lev + 1) > 0. || MR(MR_FACCLD2, lev + 1) > 0.) { rat1 = 0.; rat2 = 1.; }
-                        else { rat1 = 0.; rat2 = 0.; }
-                    }
-                }
-                if (ist != 1) {
-                    const double cd = CF(lev - 1);
-                    const double cu = lev < nlay ? CF(lev + 1) : 0.0;   // lev == nlay: the reference reads cldfrac(nlayers+1), out of bounds; both
-                    // terms are then irrelevant because faccmb*(nlayers+1) is never used (up-sweep reads lev+1 <= nlayers only when lev < nlayers...)
-                    MR(MR_FACCMB1, lev + 1) = fmax(0., fmin(cu - cl, cd - cl));
-                    MR(MR_FACCMB2, lev + 1) = fmax(0., fmin(cl - cu, cl - cd));
-                }
-            } else {
-                ist_next = 1;
-            }
-            W.cflag[(size_t)lev * W.ncolb + col] |= (ist << 1);
-            ist = ist_next;
-        }
-    }
-    {
-        int ist = 1;           // istcldd(lev)
-        for (int lev = nlay; lev >= 1; lev--) {
-            int ist_next;
-            if (ICLD(lev)) {
-                ist_next = 0;
-                const double cl = CF(lev);
-                if (lev == 1) {
-                    // factors at lev-1 = 0 stay zero
-                } else {
-                    const double cd = CF(lev - 1);
-                    if (cd >= cl) {
-                        if (ist == 1) {
-                            double v2 = 0.0;
-                            if (cl < 1.) v2 = (cd - cl) / (1. - cl);
-                            MR(MR_FACCLR1D, lev - 1) = 0.0;
-                            MR(MR_FACCLR2D, lev - 1) = v2;
-                            MR(MR_FACCLR2D, lev) = 0.0;
-                            MR(MR_FACCLD2D, lev) = 0.0;
-                        } else {
-                            const double cu = CF(lev + 1);
-                            const double fmx = fmax(cl, cu);
-                            if (cd > fmx) {
-                                MR(MR_FACCLR1D, lev - 1) = rat2;
-                                MR(MR_FACCLR2D, lev - 1) = (cd - fmx) / (1. - fmx);
-                            } else if (cd < fmx) {
-                                MR(MR_FACCLR1D, lev - 1) = (cd - cl) / (cu - cl);
-                                MR(MR_FACCLR2D, lev - 1) = 0.0;
-                            } else {
-                                MR(MR_FACCLR1D, lev - 1) = rat2;
-                                MR(MR_FACCLR2D, lev - 1) = 0.0;
-                            }
-                        }
-                        if (MR(MR_FACCLR1D, lev - 1) > 0. || MR(MR_FACCLR2D, lev - 1) > 0.) { rat1 = 1.; rat2 = 0.; }
-                        else { rat1 = 0.; rat2 = 0.; }
-                    } else {
-                        if (ist == 1) {
-                            MR(MR_FACCLD1D, lev - 1) = 0.0;
-                            MR(MR_FACCLD2D, lev - 1) = (cl - cd) / cl;
-                            MR(MR_FACCLR2D, lev) = 0.0;
-                            MR(MR_FACCLD2D, lev) = 0.0;
-                        } else {
-                            const double cu = CF(lev + 1);
-                            const double fmn = fmin(cl, cu);
-                            if (cd <= fmn) {
-                                MR(MR_FACCLD1D, lev - 1) = rat1;
-                                MR(MR_FACCLD2D, lev - 1) = (fmn - cd) / fmn;
-                            } else {
-                                MR(MR_FACCLD1D, lev - 1) = (cl - cd) / (cl - fmn);
-                                MR(MR_FACCLD2D, lev - 1) = 0.0;
-                            }
-                        }
-                        if (MR(MR_FACCLD1D, lev - 1) > 0. || MR(MR_FACCLD2D, lev - 1) > 0.) { rat1 = 0.; rat2 = 1.; }
-                        else { rat1 = 0.; rat2 = 0.; }
-                    }
-                }
-                if (ist != 1) {
-                    const double cu = CF(lev + 1);
-                    const double cd = lev > 1 ? CF(lev - 1) : 0.0;
-                    MR(MR_FACCMB1D, lev - 1) = fmax(0., fmin(cu - cl, cd - cl));
-                    MR(MR_FACCMB2D, lev - 1) = fmax(0., fmin(cl - cu, cl - cd));
-                }
-            } else {
-                ist_next = 1;
-            }
-            W.cflag[(size_t)lev * W.ncolb + col] |= (ist << 2);
-            ist = ist_next;
-        }
-    }
-#undef CF
-#undef ICLD
-#undef MR
+    // (the maximum-random overlap factors of rtrnmr :347-506 are formed by k_sweep itself, level by level: mr_step)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1157,6 +999,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     }
 }
 
+constexpr int LAYER_BLOCK = 256;   // threads of a k_layer workgroup: two workgroups per CU (a 41 KB staging buffer each), two waves per SIMD
 #ifndef RRLW_LAYER_WAVES
 #define RRLW_LAYER_WAVES 2        // waves per SIMD k_layer is compiled for.  VALU operands must be architectural VGPRs (<= 256; AGPRs are only
                                   // spill space), so a 512-register budget buys nothing
@@ -1250,7 +1093,7 @@ __device__ __forceinline__ void group_run(std::integer_sequence<int, K...>, cons
 }
 
 template <bool GCM, int CLOUD, int GROUP>
-__global__ __launch_bounds__(256, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
+__global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
 {
     __shared__ double2 s_tab[STAGE_DOUBLES / 2];
     __shared__ int s_wg[2];
@@ -1797,12 +1640,25 @@ constexpr int SWEEP_LV = 4;       // levels per reduction round
                                   // the rtrnmr sweep spill (58-67 dwords) and are slower (81.5 vs 76.9 ms per 1e6 cloudy columns)
 #endif
 #ifndef RRLW_SWEEP_WAVES_CLEAR
-#define RRLW_SWEEP_WAVES_CLEAR 4  // waves per SIMD the clear-sky sweep (MODE 0) is compiled for (128 VGPRs, no spills; 31.8 vs 39.0 ms per 1e6 columns at 2)
+#define RRLW_SWEEP_WAVES_CLEAR 4  // waves per SIMD the clear-sky sweep (MODE 0) is compiled for (<= 128 VGPRs: it needs 82-94)
 #endif
-#ifndef RRLW_SWEEP_WAVES_CLOUD
-#define RRLW_SWEEP_WAVES_CLOUD 2  // ... and the cloudy sweeps
+#ifndef RRLW_SWEEP_WAVES_RTRN
+#define RRLW_SWEEP_WAVES_RTRN 3   // MODE 1 (159 VGPRs)
 #endif
-__host__ __device__ constexpr int sweep_waves(int MODE) { return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : RRLW_SWEEP_WAVES_CLOUD; }
+#ifndef RRLW_SWEEP_WAVES_RTRNMR
+#define RRLW_SWEEP_WAVES_RTRNMR 2 // MODE 2 (181-184 VGPRs; at 168 it spills 49-56 dwords)
+#endif
+#ifndef RRLW_SWEEP_WAVES_MCARR
+#define RRLW_SWEEP_WAVES_MCARR 2  // MODE 3
+#endif
+#ifndef RRLW_SWEEP_WAVES_MCMASK
+#define RRLW_SWEEP_WAVES_MCMASK 3 // MODE 4 (145-151 VGPRs)
+#endif
+__host__ __device__ constexpr int sweep_waves(int MODE)
+{
+    return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
+           MODE == 3 ? RRLW_SWEEP_WAVES_MCARR : RRLW_SWEEP_WAVES_MCMASK;
+}
 // column sub-blocks (of 64 columns) per workgroup for bands of NQ quads: one workgroup per CU (the table in LDS), 4 x sweep_waves waves
 // (3 x for NQ = 3)
 __host__ __device__ constexpr int sweep_ns(int NQ, int MODE) { return (NQ >= 3 ? 1 : NQ == 2 ? 2 : 4) * sweep_waves(MODE); }
@@ -1847,9 +1703,17 @@ __device__ __forceinline__ float code_od(scr_t c) { return __int_as_float(max(__
 // cell adds the series terms of od = 0, a series cell adds the table terms of entry 0 - both exact zeros.
 __device__ __forceinline__ void decode(scr_t c, const float2 &e, double &atr, double &tfn)
 {
+#ifdef RRLW_DECODE_F64
     const double od = (double)code_od(c);
     atr = (double)e.x + (od - 0.5 * od * od);
     tfn = (double)e.y + 0.166667 * od;
+#else
+    // float arithmetic up to the two conversions: the table values are floats already, and of the two summands one is an exact
+    // zero; the series terms carry ~1e-7 relative error (od <= 0.06), the same class as the float table entries
+    const float od = code_od(c);
+    atr = (double)(e.x + __builtin_fmaf(-0.5f * od, od, od));
+    tfn = (double)(e.y + 0.166667f * od);
+#endif
 }
 // integrated Planck function at temperature t from one band's row of totplnk: setcoef :173-269
 __device__ __forceinline__ double planck_at(const double *tp, const double *tq, double t)
@@ -1903,7 +1767,7 @@ __device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool 
 
 struct SweepLev { scr4 c, ct; double tl, tz, cf, cfn; unsigned w; };     // one level's prefetched inputs
 
-template <int MODE, int NQ>
+template <int MODE, int NQ, bool IDRV>
 __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) void k_sweep(DevTables T, Workspace W, SweepArgs a)
 {
     constexpr int NGC = 4;
@@ -1926,7 +1790,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) vo
     const int nlay = W.nlay, nct = a.nct;
     const size_t ncb = W.ncolb;
     const double wtdelw = T.delwave[B - 1];
-    const bool idrv = a.idrv == 1;
+    constexpr bool idrv = IDRV;          // d(upward flux)/dT carried along (idrv = 1): a separate instantiation, the common case carries nothing
     const bool alt16 = (B == 16 && a.istart == 16);
     const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
     const bool any_bin = lo_bin || up_bin;
@@ -1979,6 +1843,33 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) vo
         } else {
 #pragma unroll
             for (int i = 0; i < LV; i++) red[(slot * LV + i) * 64 + tx] = acc[i];
+            __syncthreads();
+#pragma unroll
+            for (int i0 = 0; i0 < LV; i0 += NQ) {
+                const int i = i0 + slot;
+                const int lv = lev0 + dir * i;
+                if (i < LV && incol && lv >= 0 && lv <= nlay) {
+                    Part2 sum = red[i * 64 + tx];
+#pragma unroll
+                    for (int q = 1; q < NQ; q++) {
+                        const Part2 v = red[(q * LV + i) * 64 + tx];
+                        sum.a = sum.a + v.a;
+                        sum.b = sum.b + v.b;
+                    }
+                    dst[(size_t)lv * ncb] = sum;
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    // a level's partial goes straight to the reduction buffer (or, for a one-quad band, to memory): nothing is held across the round
+    auto put_part = [&](int i, int lv, const Part2 &v, Part2 *__restrict__ dst) {
+        if constexpr (NQ == 1) { if (incol) dst[(size_t)lv * ncb] = v; }
+        else red[(slot * LV + i) * 64 + tx] = v;
+    };
+    auto reduce_round = [&](Part2 *__restrict__ dst, int lev0, int dir) {
+        if constexpr (NQ > 1) {
             __syncthreads();
 #pragma unroll
             for (int i0 = 0; i0 < LV; i0 += NQ) {
@@ -2075,18 +1966,19 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) vo
     bool prevcld = false;                // the previous level of the sweep was cloudy (istcldd(lev) == 0)
     double cfprev = 0.0, rat1 = 0.0, rat2 = 0.0;
     for (int top = nlay; top >= 1; top -= LV) {
-        Part2 acc[LV];
 #pragma unroll
         for (int i = 0; i < LV; i++) {
             const int lev = top - i;
-            acc[i] = Part2{0.0, 0.0};
             const int s = i % PF;
-            const SweepLev cur = p[s];
+            const SweepLev &cur = p[s];
             const int cloudy = fl[0][s];
-            fl[0][s] = fl[1][s];
-            fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[0][s], p[s]);
-            fl[1][s] = ldflag(lev - 2 * PF);
-            if (lev < 1) continue;          // uniform
+            // the slot is refilled (level lev - PF) once this level has consumed it
+            auto advance = [&]() {
+                fl[0][s] = fl[1][s];
+                fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[0][s], p[s]);
+                fl[1][s] = ldflag(lev - 2 * PF);
+            };
+            if (lev < 1) { advance(); continue; }          // uniform
             double fr[NGC], atr[NGC], bbd[NGC];
             fracs(lev, cur.w, fr);
             const double blay = planck_at(tp0, tp0, cur.tl);
@@ -2170,9 +2062,10 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) vo
                     }
                 }
             }
-            acc[i] = Part2{(dsum * 0.5) * wtdelw, (dsumc * 0.5) * wtdelw};
+            put_part(i, lev - 1, Part2{(dsum * 0.5) * wtdelw, (dsumc * 0.5) * wtdelw}, pdn);
+            advance();
         }
-        reduce_store(acc, pdn, top - 1, -1);
+        reduce_round(pdn, top - 1, -1);
     }
 
     // ------------------------------------------------------------------ surface: rtrn :476-495
@@ -2210,20 +2103,26 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) vo
     for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i]);
     prevcld = false; cfprev = 0.0; rat1 = 0.0; rat2 = 0.0;
     for (int base = 0; base <= nlay; base += LV) {
-        Part2 acc[LV], accd[LV];
+        Part2 accd[idrv ? LV : 1];
 #pragma unroll
         for (int i = 0; i < LV; i++) {
             const int lev = base + i;
-            acc[i] = Part2{0.0, 0.0};
-            accd[i] = Part2{0.0, 0.0};
+            if constexpr (idrv) accd[i] = Part2{0.0, 0.0};
             const int s = i % PF;
-            const SweepLev cur = p[s];
+            const SweepLev &cur = p[s];
             const int cloudy = fl[0][s];
-            fl[0][s] = fl[1][s];
-            fill(lev + PF, lev + PF, lev + PF + 1, fl[0][s], p[s]);
-            fl[1][s] = ldflag(lev + 2 * PF);
-            if (lev > nlay) continue;                                           // uniform
-            if (lev == 0) { acc[i] = surf; accd[i] = dsurf; continue; }         // uniform
+            auto advance = [&]() {
+                fl[0][s] = fl[1][s];
+                fill(lev + PF, lev + PF, lev + PF + 1, fl[0][s], p[s]);
+                fl[1][s] = ldflag(lev + 2 * PF);
+            };
+            if (lev > nlay) { advance(); continue; }                            // uniform
+            if (lev == 0) {                                                     // uniform
+                put_part(i, 0, surf, pup);
+                if constexpr (idrv) accd[i] = dsurf;
+                advance();
+                continue;
+            }
             double fr[NGC], atr[NGC], bbu[NGC];
             fracs(lev, cur.w, fr);
             const double blay = planck_at(tp0, tp0, cur.tl);
@@ -2314,11 +2213,12 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) vo
                     }
                 }
             }
-            acc[i] = Part2{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
-            if (idrv) accd[i] = Part2{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusumc * 0.5) * wtdelw) * T.fluxfac};
+            put_part(i, lev, Part2{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw}, pup);
+            if constexpr (idrv) accd[i] = Part2{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusumc * 0.5) * wtdelw) * T.fluxfac};
+            advance();
         }
-        reduce_store(acc, pup, base, +1);
-        if (idrv) reduce_store(accd, dbase, base, +1);
+        reduce_round(pup, base, +1);
+        if constexpr (idrv) reduce_store(accd, dbase, base, +1);
     }
 }
 
