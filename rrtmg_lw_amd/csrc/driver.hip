@@ -149,8 +149,8 @@ hipEvent_t get_event()
 template <int M, int Q>
 int sweep_attr_one()
 {
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M)));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M, false)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M, true)));
     return 0;
 }
 template <int M>
@@ -345,18 +345,19 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             if (band_nquad(B) == nq && B >= istart && B <= iend) list |= (unsigned long long)(B - 1) << (4 * nb_bands++);
         if (nb_bands == 0) continue;
         sa.bands = list;
-#define SWEEP(M, Q)                                                                                                  \
+#define SWEEP_I(M, Q, I)                                                                                             \
     do {                                                                                                             \
-        const int ns = sweep_ns(Q, M);                                                                               \
+        const int ns = sweep_ns(Q, M, I);                                                                            \
         const dim3 sgrid((nb + 64 * ns - 1) / (64 * ns), nb_bands), sblock(64, Q, ns);                               \
-        if (idrv == 1) LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, true>), sgrid, sblock, sweep_lds_bytes(Q, M), s, G.D, Wk, sa);  \
-        else LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, false>), sgrid, sblock, sweep_lds_bytes(Q, M), s, G.D, Wk, sa);          \
+        LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, I>), sgrid, sblock, sweep_lds_bytes(Q, M, I), s, G.D, Wk, sa); \
     } while (0)
+#define SWEEP(M, Q) do { if (idrv == 1) SWEEP_I(M, Q, true); else SWEEP_I(M, Q, false); } while (0)
 #define SWEEP_MODE(Q)                                                          \
         if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q);
         if (nq == 4) { SWEEP_MODE(4) } else if (nq == 3) { SWEEP_MODE(3) } else if (nq == 2) { SWEEP_MODE(2) } else { SWEEP_MODE(1) }
 #undef SWEEP_MODE
 #undef SWEEP
+#undef SWEEP_I
     }
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
     LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);

@@ -1635,38 +1635,45 @@ struct SweepArgs {
 };
 
 constexpr int SWEEP_LV = 4;       // levels per reduction round
+// prefetch distance in levels (= register slots of the rolling prefetch; divides SWEEP_LV).  Two levels everywhere except the rtrnmr
+// sweep, which fits three waves per SIMD (168 VGPRs) only with one slot: measured 61.2 ms per 1e6 cloudy columns (1 slot, 3 waves)
+// against 70.2 ms (2 slots, 2 waves) and 71.5 ms (1 slot, 2 waves).
 #ifndef RRLW_SWEEP_PF
-#define RRLW_SWEEP_PF 2           // prefetch distance in levels (= register slots of the rolling prefetch); divides SWEEP_LV.  4 slots make
-                                  // the rtrnmr sweep spill (58-67 dwords) and are slower (81.5 vs 76.9 ms per 1e6 cloudy columns)
+#define RRLW_SWEEP_PF 2
 #endif
+#ifndef RRLW_SWEEP_PF_RTRNMR
+#define RRLW_SWEEP_PF_RTRNMR 1
+#endif
+__host__ __device__ constexpr int sweep_pf(int MODE, bool IDRV) { return MODE == 2 && !IDRV ? RRLW_SWEEP_PF_RTRNMR : RRLW_SWEEP_PF; }
 #ifndef RRLW_SWEEP_WAVES_CLEAR
 #define RRLW_SWEEP_WAVES_CLEAR 4  // waves per SIMD the clear-sky sweep (MODE 0) is compiled for (<= 128 VGPRs: it needs 82-94)
 #endif
 #ifndef RRLW_SWEEP_WAVES_RTRN
-#define RRLW_SWEEP_WAVES_RTRN 3   // MODE 1 (159 VGPRs)
+#define RRLW_SWEEP_WAVES_RTRN 4   // MODE 1 (121-123 VGPRs)
 #endif
 #ifndef RRLW_SWEEP_WAVES_RTRNMR
-#define RRLW_SWEEP_WAVES_RTRNMR 2 // MODE 2 (181-184 VGPRs; at 168 it spills 49-56 dwords)
+#define RRLW_SWEEP_WAVES_RTRNMR 3 // MODE 2 (one prefetch slot: 168 VGPRs + 6-7 spilled dwords; two slots: 181-184, 49-56 spilled at 168)
 #endif
 #ifndef RRLW_SWEEP_WAVES_MCARR
 #define RRLW_SWEEP_WAVES_MCARR 2  // MODE 3
 #endif
 #ifndef RRLW_SWEEP_WAVES_MCMASK
-#define RRLW_SWEEP_WAVES_MCMASK 3 // MODE 4 (145-151 VGPRs)
+#define RRLW_SWEEP_WAVES_MCMASK 4 // MODE 4 (125-127 VGPRs; 130.3 vs 143.2 ms per 1e6 McICA columns at 3)
 #endif
-__host__ __device__ constexpr int sweep_waves(int MODE)
+__host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV)
 {
+    if (IDRV) return MODE == 0 ? 3 : 2;       // the d(flux)/dT instantiations carry 32 more registers
     return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
            MODE == 3 ? RRLW_SWEEP_WAVES_MCARR : RRLW_SWEEP_WAVES_MCMASK;
 }
 // column sub-blocks (of 64 columns) per workgroup for bands of NQ quads: one workgroup per CU (the table in LDS), 4 x sweep_waves waves
 // (3 x for NQ = 3)
-__host__ __device__ constexpr int sweep_ns(int NQ, int MODE) { return (NQ >= 3 ? 1 : NQ == 2 ? 2 : 4) * sweep_waves(MODE); }
+__host__ __device__ constexpr int sweep_ns(int NQ, int MODE, bool IDRV) { return (NQ >= 3 ? 1 : NQ == 2 ? 2 : 4) * sweep_waves(MODE, IDRV); }
 // dynamic LDS of k_sweep<., NQ>: transmittance table (float pairs), Planck rows, fraction rows, reduction buffer
 constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8, SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
-__host__ __device__ constexpr int sweep_lds_bytes(int NQ, int MODE)
+__host__ __device__ constexpr int sweep_lds_bytes(int NQ, int MODE, bool IDRV)
 {
-    return SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES + (NQ > 1 ? sweep_ns(NQ, MODE) * NQ * SWEEP_LV * 64 * 16 : 0);
+    return SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES + (NQ > 1 ? sweep_ns(NQ, MODE, IDRV) * NQ * SWEEP_LV * 64 * 16 : 0);
 }
 
 // Loads of k_sweep: wave-uniform base pointer in a buffer descriptor (scalar registers), per-lane 32-bit byte offset that does not
@@ -1768,12 +1775,12 @@ __device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool 
 struct SweepLev { scr4 c, ct; double tl, tz, cf, cfn; unsigned w; };     // one level's prefetched inputs
 
 template <int MODE, int NQ, bool IDRV>
-__global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE), sweep_waves(MODE)) void k_sweep(DevTables T, Workspace W, SweepArgs a)
+__global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MODE, IDRV)) void k_sweep(DevTables T, Workspace W, SweepArgs a)
 {
     constexpr int NGC = 4;
-    constexpr int LV = SWEEP_LV, PF = RRLW_SWEEP_PF;
+    constexpr int LV = SWEEP_LV, PF = sweep_pf(MODE, IDRV);
     static_assert(LV % PF == 0, "prefetch slots");
-    constexpr int NS = sweep_ns(NQ, MODE);
+    constexpr int NS = sweep_ns(NQ, MODE, IDRV);
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *s_lut = reinterpret_cast<float2 *>(smem);                                              // [NTBL + 1] {1 - exp, tfn}
     double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);              // [0] this band's Planck integrals, [1] band 16's (istart = 16 quirk)
