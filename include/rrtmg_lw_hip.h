@@ -196,7 +196,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     double *duflx_dt, double *duflxc_dt, void *stream);
 
 /* Tuning / introspection ------------------------------------------------------------------------- */
-/* Columns processed per internal batch (bounds the device workspace); default 65536 (about 0.65 MB of device workspace per column at 72 layers). */
+/* Columns processed per internal batch (bounds the device workspace); default 131072 (about 0.2 MB of device workspace per column at 72 layers). */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
 /* on = 1 (default): device-pointer entries run k_sweep/k_flux of column batch i on a second stream while k_layer of batch i+1
  * runs on the caller's stream (second scratch set, +0.26 MB of workspace per column; measured +5.6 % columns/s).  on = 0

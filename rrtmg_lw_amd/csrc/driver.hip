@@ -44,7 +44,7 @@ struct State {
     // McICA sub-column masks of all columns of the current call
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
-    int batch = 65536;      // columns per internal batch: ~0.65 MB of workspace per column at 72 layers (42 GB); measured 32768: 153 ms, 65536: 149 ms, 262144: 145 ms per 1e6 columns
+    int batch = 131072;     // columns per internal batch: ~0.2 MB of workspace per column at 72 layers (27 GB); measured per 1e6 cloudy columns: 32768: 117.9 ms, 65536: 112.6 ms, 131072: 108.4 ms, 262144: 106.8 ms
     bool split_sweep = false;    // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: k_sweep
                                  // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -3 %)
                                  // at 65536-column batches (147.3 vs 155.6 ms per 1e6 columns)

@@ -144,7 +144,7 @@ def test_device_entry_with_caller_stream(hip, oracle):
             hip.rrtmg_lw_device(d, out, stream=side.cuda_stream)        # back to back: prep sets are reused safely
         hip.check(side.cuda_stream)
     finally:
-        hip.set_batch(65536)
+        hip.set_batch(131072)
     dn = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=9)
     ref = oracle.rrtmg_lw(ncol, nlay, dn["icld"], dn["idrv"], dn)
     got = {k: out[k].T.cpu().numpy() for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")}
@@ -197,7 +197,7 @@ def test_pinned_host_arrays_and_pipelined_batches(hip, oracle):
         for v in pinned:
             hip.host_unregister(v)
     finally:
-        hip.set_batch(65536)
+        hip.set_batch(131072)
     for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
         assert np.array_equal(got[k], plain[k]), k
     ref = oracle.rrtmg_lw(1100, 51, d["icld"], d["idrv"], d)
@@ -259,7 +259,7 @@ def test_device_entry_from_two_streams(hip, oracle):
         hip.check(sa.cuda_stream)
         hip.check(sb.cuda_stream)
     finally:
-        hip.set_batch(65536)
+        hip.set_batch(131072)
     for d0, o in ((0, oa), (50_000, ob)):
         dn = make_gcm_inputs(200, nlay, "cloudy", col0=d0)
         ref = oracle.rrtmg_lw(200, nlay, dn["icld"], dn["idrv"], dn)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Workload for rocprofv3 counter passes (run as `rocprofv3 --pmc <counters> --kernel-trace -d <dir> -f csv -- python3 tools/pmc_run.py`).
 
-One warm-up call and ONE measured-shape call of the hot path on `--ncol` device-resident columns (default 262144 = four
-internal batches of 65536 columns, the launch shape bench.py times), preceded by a calibration kernel that moves a known
+One warm-up call and ONE measured-shape call of the hot path on `--ncol` device-resident columns (default 262144 = two
+internal batches of 131072 columns), preceded by a calibration kernel that moves a known
 number of bytes (rrtmg_lw_hip_calibrate_stream) so that tools/pmc_summarize.py can fix the unit/scale of FETCH_SIZE and
 WRITE_SIZE in the same session (MI355X_MICROARCH.md, HBM section).
 """

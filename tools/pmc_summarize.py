@@ -25,13 +25,16 @@ def short_name(k):
     k = k.replace("rrlw::", "")
     m = re.match(r"k_layer<(\w+), (\d+), (\d+)>", k)
     if m:
-        return "k_layer<%s,%s>" % ({"0": "clear", "1": "cloud", "2": "mcica"}[m.group(2)], m.group(3))
+        return "k_layer<%s,%s>" % ({"0": "clear", "1": "cloud", "2": "mcica", "3": "mcmask"}[m.group(2)], m.group(3))
     m = re.match(r"k_cloudmc<(\w+)>", k)
     if m:
         return "k_cloudmc<%s>" % ("mask" if m.group(1) == "true" else "arrays")
     m = re.match(r"(k_colprep|k_cloud)<\w+>", k)
     if m:
         return m.group(1)
+    m = re.match(r"k_sweep<(\d+), (\d+), (\w+)>", k)       # the d(flux)/dT instantiation shares the bench's kernel name
+    if m:
+        return "k_sweep<%s,%s>" % (m.group(1), m.group(2))
     return k.replace(", ", ",")
 
 
