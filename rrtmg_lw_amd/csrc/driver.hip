@@ -348,7 +348,9 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #define SWEEP_I(M, Q, I)                                                                                             \
     do {                                                                                                             \
         const int ns = sweep_ns(Q, M, I);                                                                            \
-        const dim3 sgrid((nb + 64 * ns - 1) / (64 * ns), nb_bands), sblock(64, Q, ns);                               \
+        sa.ncb = (nb + 64 * ns - 1) / (64 * ns);                                                                     \
+        sa.nbands = nb_bands;                                                                                        \
+        const dim3 sgrid((unsigned)(((sa.ncb + 7) / 8) * 8 * nb_bands)), sblock(64, Q, ns);                          \
         LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, I>), sgrid, sblock, sweep_lds_bytes(Q, M, I), s, G.D, Wk, sa); \
     } while (0)
 #define SWEEP(M, Q) do { if (idrv == 1) SWEEP_I(M, Q, true); else SWEEP_I(M, Q, false); } while (0)

@@ -1625,7 +1625,8 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 // Lanes beyond the last column work on a copy of the last column (no divergence); only their stores are masked.
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
-    unsigned long long bands;  // the launch's bands (all with the same number of quads), one nibble (band - 1) per blockIdx.y
+    unsigned long long bands;  // the launch's bands (all with the same number of quads), one nibble (band - 1) each
+    int nbands, ncb;           // number of those bands, number of column blocks (workgroups per band)
     int ncol, col0, nct, idrv;
     int istart, iend;          // only bands in [istart, iend] are swept
     const double *emis;        // semiss (nct,16)
@@ -1787,8 +1788,14 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);   // Planck fractions: rows 0-8 fracrefa, 9-13 fracrefb, 14-15 zeros
     const int tx = threadIdx.x, slot = threadIdx.y, sub = threadIdx.z;
     Part2 *red = reinterpret_cast<Part2 *>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES) + (size_t)sub * NQ * LV * 64;   // [slot][level-in-round][column]
-    const int col = (blockIdx.x * NS + sub) * 64 + tx;
-    const int B = (int)((a.bands >> (4 * blockIdx.y)) & 15ull) + 1;     // bands with NQ quads, packed as nibbles (band - 1)
+    // Workgroup -> (column block, band).  Consecutive workgroup ids go round the 8 XCDs (each with its own L2), and the bands of one
+    // column block read the same temperatures, flags and cloud fractions: ids that share an XCD (same id % 8) walk the bands of one
+    // column block before they move to the next block, so those re-reads hit that XCD's L2 instead of HBM.
+    const int wq = blockIdx.x >> 3;
+    const int cblock = (wq / a.nbands) * 8 + (blockIdx.x & 7);
+    if (cblock >= a.ncb) return;                    // uniform over the workgroup (the grid is padded to a multiple of 8 column blocks)
+    const int col = (cblock * NS + sub) * 64 + tx;
+    const int B = (int)((a.bands >> (4 * (wq % a.nbands))) & 15ull) + 1;     // bands with NQ quads, packed as nibbles (band - 1)
     if (B < a.istart || B > a.iend) return;         // uniform over the workgroup
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;      // lanes past the end shadow the last column
