@@ -18,6 +18,7 @@ namespace {
 using namespace rrlw;
 
 constexpr int BLOCK = 256;
+constexpr int HOST_BATCH = 32768;      // columns per batch of the host-pointer entries (H2D | kernels | D2H pipeline)
 
 struct State {
     bool init = false;
@@ -38,6 +39,9 @@ struct State {
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
     hipStream_t aux = nullptr, sw = nullptr;
+    hipStream_t swq[3] = {nullptr, nullptr, nullptr};     // the sweep launches of the 3-, 2- and 1-quad bands run beside the 4-quad launch
+    hipEvent_t ev_swq_go = nullptr, ev_swq_done[3] = {nullptr, nullptr, nullptr};
+    bool sweep_fanout = true;
     hipEvent_t ev_last = nullptr;           // end of the previous device-entry call (calls on different streams share the workspace)
     bool ev_last_valid = false;
     hipEvent_t ev_in = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_layer[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -331,6 +335,22 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     const dim3 block(BLOCK);
     const unsigned gx = (nb + BLOCK - 1) / BLOCK;
     if (int rc = ensure_sweep_attrs()) return rc;
+    // The four sweep launches of a batch (bands of 4, 3, 2, 1 quads) are independent.  Each workgroup owns a CU, so a launch ends with
+    // a partly filled last round (1-quad bands: 2.5 rounds); on separate streams the other launches' workgroups fill those CUs.
+    // Measured: 10 000 columns 1.22 -> 0.98 ms; 125 000-column batches no gain (cloudy 98.9 -> 98.4 ms per 1e6 columns, McICA 115.5 -> 122.6).
+    const bool fan = G.sweep_fanout && nb < 65536;
+    if (fan && !G.swq[0]) {
+        for (int k = 0; k < 3; k++) {
+            HIP_TRY(hipStreamCreateWithFlags(&G.swq[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&G.ev_swq_done[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&G.ev_swq_go, hipEventDisableTiming));
+    }
+    if (fan) {
+        HIP_TRY(hipEventRecord(G.ev_swq_go, s));
+        for (int k = 0; k < 3; k++) HIP_TRY(hipStreamWaitEvent(G.swq[k], G.ev_swq_go, 0));
+    }
+    const hipStream_t s_main = s;
     SweepArgs sa;
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
     sa.emis = GCM ? g.emis : c.semiss;
@@ -345,6 +365,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             if (band_nquad(B) == nq && B >= istart && B <= iend) list |= (unsigned long long)(B - 1) << (4 * nb_bands++);
         if (nb_bands == 0) continue;
         sa.bands = list;
+        const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;     // (shadows the function's stream for the launch macros below)
 #define SWEEP_I(M, Q, I)                                                                                             \
     do {                                                                                                             \
         const int ns = sweep_ns(Q, M, I);                                                                            \
@@ -360,6 +381,12 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #undef SWEEP_MODE
 #undef SWEEP
 #undef SWEEP_I
+    }
+    if (fan) {
+        for (int k = 0; k < 3; k++) {
+            HIP_TRY(hipEventRecord(G.ev_swq_done[k], G.swq[k]));
+            HIP_TRY(hipStreamWaitEvent(s_main, G.ev_swq_done[k], 0));
+        }
     }
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
     LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);
@@ -763,6 +790,10 @@ void rrtmg_lw_hip_finalize(void)
         (void)hipEventDestroy(G.ev_last);
         for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_ready[k]); (void)hipEventDestroy(G.ev_layer[k]); (void)hipEventDestroy(G.ev_done[k]); }
     }
+    if (G.swq[0]) {
+        for (int k = 0; k < 3; k++) { (void)hipStreamDestroy(G.swq[k]); (void)hipEventDestroy(G.ev_swq_done[k]); }
+        (void)hipEventDestroy(G.ev_swq_go);
+    }
     G = State();
 }
 
@@ -879,7 +910,9 @@ int rrtmg_lw_hip_run_nomcica(
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);
     const bool cloud = *icld >= 1;          // inatm copies the cloud arrays only when icld >= 1 (:893-910)
-    const int nbmax = balanced_batch(ncol, G.batch);
+    // host arrays: the copies bound the rate (PCIe), and they overlap with the kernels only across batches - smaller batches than
+    // the device-resident default
+    const int nbmax = balanced_batch(ncol, std::min(G.batch, HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
     const size_t L = (size_t)nlay;
     std::vector<HostIn> ins = {

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Workload for rocprofv3 counter passes (run as `rocprofv3 --pmc <counters> --kernel-trace -d <dir> -f csv -- python3 tools/pmc_run.py`).
 
-One warm-up call and ONE measured-shape call of the hot path on `--ncol` device-resident columns (default 262144 = two
-internal batches of 131072 columns), preceded by a calibration kernel that moves a known
+One warm-up call and ONE measured-shape call of the hot path on `--ncol` device-resident columns (default 250000 = two
+internal batches of 125000 columns, the launch shape of the 1e6-column bench), preceded by a calibration kernel that moves a known
 number of bytes (rrtmg_lw_hip_calibrate_stream) so that tools/pmc_summarize.py can fix the unit/scale of FETCH_SIZE and
 WRITE_SIZE in the same session (MI355X_MICROARCH.md, HBM section).
 """
@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ncol", type=int, default=262144)
+    ap.add_argument("--ncol", type=int, default=250000)
     ap.add_argument("--nlay", type=int, default=72)
     ap.add_argument("--config", default="cloudy")
     ap.add_argument("--mcica", type=int, default=0)
