@@ -266,3 +266,23 @@ def test_device_entry_from_two_streams(hip, oracle):
         got = {k: o[k][:, :200].T.cpu().numpy() for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")}
         got["icld"] = ref["icld"]
         _compare(got, ref, 0, f"two streams, col0={d0}")
+
+
+@pytest.mark.parametrize("icld,lo", [(2, 0.45), (0, 0.70)])
+def test_orography_spread_of_pressure_levels(hip, oracle, icld, lo):
+    """Neighbouring columns on very different pressure grids (surface pressure 45 % ... 105 % of 1013 hPa, as over steep
+    orography with terrain-following levels): within one k_layer workgroup the reference-pressure index jp then spans several
+    values and tropospheric and stratospheric cells share a layer index, so cells fall outside the absorption-table window staged
+    in LDS and whole waves take the global-memory evaluation instead.  Both evaluations must give the oracle's numbers."""
+    ncol, nlay = 700, 72
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=4242)
+    rng = np.random.default_rng(11)
+    f = rng.uniform(lo, 1.05, ncol)
+    f[::7] = 1.0                                           # a few standard columns in between
+    for k in ("play", "plev"):
+        d[k] = np.asfortranarray(np.array(d[k]) * f[:, None])
+    got = hip.rrtmg_lw_from_dict(d, icld=icld)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+    _compare(got, ref, d["idrv"], f"orography icld={icld}")
+    jp = np.floor(36.0 - 5.0 * (np.log(np.array(d["play"])) + 0.04)).astype(int)
+    assert (jp.max(axis=0) - jp.min(axis=0)).max() >= 3        # the spread the staging window cannot hold
