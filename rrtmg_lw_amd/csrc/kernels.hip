@@ -7,15 +7,17 @@
 //
 //   k_colprep  per-column scalars: laytrop, precipitable water -> diffusivity secants, surface Planck
 //              terms                                                    1 thread / column
-//   k_cloud    cldprop + cloud-overlap factors of rtrnmr (serial in the vertical)
+//   k_cloud    cldprop, cloud optical depth per spectral band (serial in the vertical)
 //                                                                       1 thread / column
 //   k_cloudmc  cldprmc + the cloud set-up of rtrnmc (McICA)             1 thread / (column, layer)
-//   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for the bands of one group,
-//              then each cell's transmittance and Planck sources (the exp/LUT part of rtrn)
+//   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for all bands (each band's absorption tables
+//              staged in LDS for the 256 columns of a workgroup, which share the layer), then for each cell the decision
+//              rtrn takes on its optical depth (series / table index) as a 4-byte code
 //                                                                       1 thread / (column, layer)
-//   k_sweep    the only vertically serial part: the down/up recurrences of rtrn / rtrnmr / rtrnmc, streaming
-//              the per-cell terms written by k_layer; workgroup = 64 columns x the quads of one band,
-//              flux partials reduced over the band in LDS                 1 thread / (column, quad)
+//   k_sweep    the only vertically serial part: the down/up recurrences of rtrn / rtrnmr / rtrnmc over the cell codes
+//              (transmittance table, the band's Planck integrals and fractions in LDS; rtrnmr overlap factors on the fly);
+//              workgroup = 64 x ns columns x the quads of one band, flux partials reduced over the band in LDS
+//                                                                       1 thread / (column, quad)
 //   k_flux     band slabs -> fluxes;  k_rates  net flux -> heating rates   1 thread / (column, level)
 //   k_subcol_* McICA sub-column generator (bit masks), k_alpha           see the section below
 //
@@ -774,13 +776,11 @@ __device__ __forceinline__ void rows_to_lds(Rows<N> &rw, const unsigned (&delta)
     }
 }
 
-// tau and Planck fraction of ALL g-points of band B (padded to whole quads with zeros).
-// Measured on MI355X (profiles/round1_pmc_v2_two_phase.md): k_layer is bound by exposed memory latency at one wave
-// per SIMD (VALU 12-20 % busy; making every gather wave-uniform or dropping the stores changes little).  The table
-// loads of a band are all independent, so they are issued as a software pipeline: the band's loads form one list
-// (row-major: N rows x ng/2 16-byte loads, then the Planck-fraction rows), cut into chunks of RRLW_LOAD_CHUNK; chunk
-// c+1 is in flight while chunk c is consumed.  sched_barrier keeps the compiler from hoisting every load to the top
-// (which spills) or sinking them to their uses (which serialises the latency again).
+// Optical depth of ALL g-points of band B (padded to whole quads with zeros).  The table loads of a band are all independent, so
+// they are issued as a software pipeline: the band's loads form one list (row-major: N rows x ng/2 16-byte loads), cut into chunks
+// of RRLW_LOAD_CHUNK; chunk c+1 is in flight while chunk c is consumed.  sched_barrier keeps the compiler from hoisting every load
+// to the top (which spills) or sinking them to their uses (which serialises the latency again).  LDS = the rows come from the
+// workgroup's staging buffer (rw.off then holds staging offsets, rows_to_lds), otherwise from global memory through the vector L1.
 #ifndef RRLW_LOAD_CHUNK
 #define RRLW_LOAD_CHUNK 2       // loads in flight per pipeline stage.  From LDS two suffice (8 were needed through the vector L1) and the
 #endif                          // registers saved allow three waves per SIMD: 36.4 vs 40.9 ms per 1e6 cloudy columns
@@ -857,10 +857,10 @@ __device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const 
 
 // ------------------------------------------------------------------------------------------------
 // k_layer : for one (column, layer):  inatm's layer part (src/rrtmg_lw_rad.nomcica.f90:785-867), setcoef
-//           (src/rrtmg_lw_setcoef.f90:189-429), taumol for all bands (src/rrtmg_lw_taumol.f90:299-3164), taut = taug +
-//           taua (src/rrtmg_lw_rad.nomcica.f90:527-539) and, per g-point, the layer's transmittance and Planck source
-//           terms - the part of rtrn's sweep body that does not depend on the incoming radiance
-//           (src/rrtmg_lw_rtrn.f90:362-451).  Results go to the [g][layer][column] scratch arrays.
+//           (src/rrtmg_lw_setcoef.f90:276-429), taumol for all bands (src/rrtmg_lw_taumol.f90:299-3164), taut = taug +
+//           taua (src/rrtmg_lw_rad.nomcica.f90:527-539) and, per g-point, the optical depth along the diffusivity angle and
+//           the branch rtrn's sweep body takes on it (src/rrtmg_lw_rtrn.f90:362-451) as a 4-byte code (cell_code).
+//           Results go to the [quad][layer][column][4] code arrays.
 // ------------------------------------------------------------------------------------------------
 struct LayerArgs {
     int ncol, col0, nct, idrv, istart, iend;
