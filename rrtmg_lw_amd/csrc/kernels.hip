@@ -1668,9 +1668,13 @@ __host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV)
     return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
            MODE == 3 ? RRLW_SWEEP_WAVES_MCARR : RRLW_SWEEP_WAVES_MCMASK;
 }
-// column sub-blocks (of 64 columns) per workgroup for bands of NQ quads: one workgroup per CU (the table in LDS), 4 x sweep_waves waves
-// (3 x for NQ = 3)
-__host__ __device__ constexpr int sweep_ns(int NQ, int MODE, bool IDRV) { return (NQ >= 3 ? 1 : NQ == 2 ? 2 : 4) * sweep_waves(MODE, IDRV); }
+// column sub-blocks (of 64 columns) per workgroup for bands of NQ quads: one workgroup per CU (the table in LDS) that fills the
+// 4 x sweep_waves wave slots the kernel is compiled for
+__host__ __device__ constexpr int sweep_ns(int NQ, int MODE, bool IDRV)
+{
+    const int waves = 4 * sweep_waves(MODE, IDRV);         // per workgroup = per CU
+    return NQ == 3 ? (waves / 3 > 1 ? waves / 3 : 1) : waves / NQ;     // (3-quad bands: 12 of 12, 15 of 16 or 6 of 8 wave slots)
+}
 // dynamic LDS of k_sweep<., NQ>: transmittance table (float pairs), Planck rows, fraction rows, reduction buffer
 constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8, SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
 __host__ __device__ constexpr int sweep_lds_bytes(int NQ, int MODE, bool IDRV)
