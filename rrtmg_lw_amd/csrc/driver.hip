@@ -2,6 +2,7 @@
 // Replaces the serial `do iplon = 1, ncol` loop of the reference's rrtmg_lw
 // (src/rrtmg_lw_rad.nomcica.f90:472-586) with batched launches of the kernels in kernels.hip.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdint>
@@ -434,20 +435,24 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
 {
     if (int rc = ensure_pipeline()) return rc;
     const int nbmax = balanced_batch(ncol, G.batch);
+    const hipStream_t aux = G.aux;
     ColIn c{};
     // sub-column arrays mode keeps per-g-point cloud arrays (odg/cfef) in one set only: no layer/sweep overlap there
     const bool split = G.split_sweep && G.ws_two_scr && !(mode == 3 && mc);
     if (G.ev_last_valid) HIP_TRY(hipStreamWaitEvent(s, G.ev_last, 0));      // an earlier call, possibly on another stream, still owns the workspace
     HIP_TRY(hipEventRecord(G.ev_in, s));                 // inputs are ready when the caller's stream gets here
-    HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_in, 0));
+    HIP_TRY(hipStreamWaitEvent(aux, G.ev_in, 0));
     int i = 0;
     for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
         const Workspace Wk = ws_for(k);
-        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.aux, G.ev_done[k], 0));       // prep set k is free again (sweep of batch i-2 done)
-        if (int rc = run_prep<true>(G.aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
-        if (gen.on) launch_kiss(G.aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha});
-        HIP_TRY(hipEventRecord(G.ev_ready[k], G.aux));
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(aux, G.ev_done[k], 0));       // prep set k is free again (sweep of batch i-2 done)
+        // (The per-column kernels of batch i thus run beside k_layer of batch i-1.  Their few long-lived waves cost whatever runs beside
+        // them about what the overlap saves - measured per 1e6 columns: k_layer 32.7 ms beside them, 28.3 alone, step 93.9 vs 96.0 on one
+        // stream; held back until k_layer is done they slow the sweep instead, 94.4, and the McICA generator then costs 7 ms more.)
+        if (int rc = run_prep<true>(aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
+        if (gen.on) launch_kiss(aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha});
+        HIP_TRY(hipEventRecord(G.ev_ready[k], aux));
         HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
         if (split) {
             // k_layer of this batch on the caller's stream, its sweep on `sw`: the HBM-bound sweep of batch i overlaps the
