@@ -1664,7 +1664,7 @@ __host__ __device__ constexpr int sweep_pf(int MODE, bool IDRV) { return MODE ==
 #endif
 __host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV)
 {
-    if (IDRV) return MODE == 0 ? 3 : 2;       // the d(flux)/dT instantiations carry 32 more registers
+    if (IDRV) return MODE == 0 ? 4 : 2;       // the d(flux)/dT instantiations carry 32 more registers (clear sky 100-106; rtrnmr spills 170 dwords at 168)
     return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
            MODE == 3 ? RRLW_SWEEP_WAVES_MCARR : RRLW_SWEEP_WAVES_MCMASK;
 }
