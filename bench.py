@@ -265,9 +265,9 @@ def main():
         roof = None
         path = None
         if kern:
-            # dominant kernel of the critical path: k_colprep / k_cloud run on the auxiliary stream underneath the previous
+            # dominant kernel of the critical path: k_colprep / k_cloudscan / k_cloudlay run on the auxiliary stream underneath the previous
             # batch's k_layer / k_sweep (driver.hip: run_pipelined) and are left out of the choice
-            crit = {k: v for k, v in kern.items() if not (k.startswith("k_colprep") or k == "k_cloud")} or kern
+            crit = {k: v for k, v in kern.items() if not (k.startswith("k_colprep") or k in ("k_cloudscan", "k_cloudlay"))} or kern
             dom = max(crit, key=lambda k: crit[k][1])
             cnt, tot = kern[dom]
             avg_ms = tot / cnt

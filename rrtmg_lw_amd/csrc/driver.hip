@@ -34,8 +34,8 @@ struct State {
     int ws_nlay = 0, ws_ncolb = 0;
     bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
-    // per-column / cloud-property arrays exist twice: k_colprep + k_cloud of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *taucloud, *odcld, *efcl; int *cflag; } prep[2] = {};
+    // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by k_sweep exists twice as well: k_sweep/k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -213,7 +213,6 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     }
     if (cloud) {
         for (auto &ps : G.prep) {
-            items.push_back({(void **)&ps.taucloud, 16 * L * n * 8});
             items.push_back({(void **)&ps.odcld, 16 * L * n * 8});
             items.push_back({(void **)&ps.efcl, 16 * L * n * 8});
         }
@@ -235,7 +234,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     {   // G.W itself carries prep set 0 and scratch set 0
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
-        W.taucloud = ps.taucloud; W.odcld = ps.odcld; W.efcl = ps.efcl;
+        W.odcld = ps.odcld; W.efcl = ps.efcl;
     }
     G.ws_bytes = total;
     G.ws_nlay = nlay;
@@ -263,14 +262,14 @@ Workspace ws_for(int k)
     Workspace w = G.W;
     const State::PrepSet &ps = G.prep[k];
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
-    w.taucloud = ps.taucloud; w.odcld = ps.odcld; w.efcl = ps.efcl;
+    w.odcld = ps.odcld; w.efcl = ps.efcl;
     const State::ScrSet &ss = G.scrset[G.ws_two_scr ? k : 0];
     for (int a = 0; a < NSCR; a++) w.scr[a] = ss.scr[a];
     w.fw = ss.fw;
     return w;
 }
 
-// per-column part of one batch: k_colprep (+ k_cloud for rtrn / rtrnmr).  Few threads, long serial loops: it runs on the
+// per-column part of one batch: k_colprep (+ k_cloudscan / k_cloudlay for rtrn / rtrnmr): it runs on the
 // auxiliary stream one batch ahead of the heavy kernels (run_pipelined).
 template <bool GCM>
 int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int mode, int idrv, int istart,
@@ -279,8 +278,11 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
     // thread-per-column kernels: one wave per workgroup so that a batch (one wave per 64 columns) spreads over all 256 CUs
     const dim3 cgrid1((nb + 63) / 64), cblock1(64);
     LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, idrv, istart);
-    if (mode == 1 || mode == 2)
-        LAUNCH("k_cloud", (k_cloud<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+    if (mode == 1 || mode == 2) {
+        LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag);
+        const dim3 lgrid((nb + BLOCK - 1) / BLOCK, Wk.nlay), lblock(BLOCK);
+        LAUNCH("k_cloudlay", (k_cloudlay<GCM>), lgrid, lblock, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;

@@ -7,8 +7,8 @@
 //
 //   k_colprep  per-column scalars: laytrop, precipitable water -> diffusivity secants, surface Planck
 //              terms                                                    1 thread / column
-//   k_cloud    cldprop, cloud optical depth per spectral band (serial in the vertical)
-//                                                                       1 thread / column
+//   k_cloudscan / k_cloudlay   cldprop, cloud optical depth per spectral band: the one quantity cldprop carries from layer
+//              to layer per column, then the per-layer physics        1 thread / column, 1 thread / (column, layer)
 //   k_cloudmc  cldprmc + the cloud set-up of rtrnmc (McICA)             1 thread / (column, layer)
 //   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for all bands (each band's absorption tables
 //              staged in LDS for the 256 columns of a workgroup, which share the layer), then for each cell the decision
@@ -70,7 +70,6 @@ struct Workspace {
     double *percol;     // [NPERCOL][ncolb]
     int *laytrop;       // [ncolb]
     int *ncbands;       // [ncolb]
-    double *taucloud;   // [16][nlay][ncolb]   cldprop output
     double *odcld;      // [16][nlay][ncolb]   secdiff(ib) * taucloud
     double *efcl;       // [16][nlay][ncolb]   rtrn: (1 - exp(-odcld)) * cldfrac
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcld, bit2 istcldd; cflag[0] bit3 = column has cloud
@@ -216,131 +215,155 @@ __device__ __forceinline__ int icb_map(int ib, int ind)   // cldprop :167-169 (1
     return ib <= 2 ? ib : (ib <= 5 ? 3 : (ib <= 8 ? 4 : 5));
 }
 
+// cldprop carries two things from layer to layer of a column (src/rrtmg_lw_cldprop.f90:173-293): `ncbands`, assigned by the layers that
+// hold ice or liquid water and left alone by the others, and nothing else that matters (iceind / liqind are reassigned before every
+// use).  k_cloudscan walks a column once and records the band count in effect at each layer; k_cloudlay then does the per-layer physics
+// for all (column, layer) pairs in parallel - the serial kernel this replaces kept one wave per 64 columns busy for 0.8 ms per batch.
+__device__ __forceinline__ bool cloud_layer_enters(double cf, double cwp, double tauctot)      // cldprop :186
+{
+    const double cldmin = 1.e-20;
+    return cf >= cldmin && (cwp >= cldmin || tauctot >= cldmin);
+}
 template <bool GCM>
-__global__ __launch_bounds__(256) void k_cloud(DevTables T, Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int mode,
-                                               int inflag, int iceflag, int liqflag)
+__device__ __forceinline__ double cloud_tauctot(const GcmIn &g, const ColIn &c, size_t gc, size_t gi, int nct, int lay)
+{
+    double tauctot = 0.0;                               // taucld (16,ncol,nlay) | tauc (ncol,16,nlayers)
+    for (int ib = 0; ib < NBND; ib++)
+        tauctot = tauctot + (GCM ? g.taucld[ib + (size_t)NBND * gi] : c.tauc[gc + (size_t)nct * (ib + (size_t)NBND * (lay - 1))]);
+    return tauctot;
+}
+
+// cflag[lay][col]: bit 0 = the layer holds cloud for the sweeps (cldfrac >= 1e-6), bits 8.. = cldprop's ncbands in effect at the layer;
+// cflag[0][col] bit 3 = the column holds cloud
+template <bool GCM>
+__global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int inflag, int iceflag, int liqflag)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
     const size_t gc = (size_t)col0 + col;
     const int nlay = W.nlay;
-    const double *S = T.stat;
-    const double *absice1 = S + T.sl.absice1, *absice2 = S + T.sl.absice2, *absice3 = S + T.sl.absice3, *absliq1 = S + T.sl.absliq1;
     const double *cldfr = GCM ? g.cldfr : c.cldfrac;
     const double *ciwp_ = GCM ? g.cicewp : c.ciwp, *clwp_ = GCM ? g.cliqwp : c.clwp;
-    const double *rei_ = GCM ? g.reice : c.rei, *rel_ = GCM ? g.reliq : c.rel;
-    const double cldmin = 1.e-20;
-    int ncbands = 1, iceind = 0, liqind = 0, err = 0;
-    // persistent single-coefficient slots (abscoice(1)/abscoliq(1) of the reference)
+    int ncbands = 1, anycloud = 0;
     for (int lay = 1; lay <= nlay; lay++) {
         const size_t gi = gc + (size_t)nct * (lay - 1);
         const double cf = cldfr[gi], ciwp = ciwp_[gi], clwp = clwp_[gi];
-        double tauc[NBND], tauctot = 0.0;
-#pragma unroll
-        for (int ib = 0; ib < NBND; ib++) {
-            // taucld (16,ncol,nlay) | tauc (ncol,16,nlayers)
-            tauc[ib] = GCM ? g.taucld[ib + (size_t)NBND * gi] : c.tauc[gc + (size_t)nct * (ib + (size_t)NBND * (lay - 1))];
-            tauctot = tauctot + tauc[ib];
-        }
-        double tcl[NBND];
-#pragma unroll
-        for (int ib = 0; ib < NBND; ib++) tcl[ib] = 0.0;
         const double cwp = ciwp + clwp;
-        if (cf >= cldmin && (cwp >= cldmin || tauctot >= cldmin)) {
-            if (inflag == 0) {
-                ncbands = 16;
-#pragma unroll
-                for (int ib = 0; ib < NBND; ib++) tcl[ib] = tauc[ib];
-            } else if (inflag == 1) {
-                ncbands = 16;
-#pragma unroll
-                for (int ib = 0; ib < NBND; ib++) tcl[ib] = T.abscld1 * cwp;
-            } else if (inflag == 2) {
-                const double radice = rei_[gi];
-                int icemode = -1;        // how abscoice(k) is evaluated for this layer
-                double ice_single = 0.0, fint_i = 0.0;
-                int index_i = 1;
-                if (ciwp == 0.0) { icemode = 0; ice_single = 0.0; iceind = 0; }
-                else if (iceflag == 0) {
-                    if (radice < 10.0) err = E_ICE_SMALL;
-                    icemode = 0; ice_single = T.absice0[0] + T.absice0[1] / radice; iceind = 0;
-                } else if (iceflag == 1) {
-                    if (radice < 13.0 || radice > 130.) err = E_ICE_BOUNDS;
-                    ncbands = 5; icemode = 1; iceind = 1;
-                } else if (iceflag == 2) {
-                    if (radice < 5.0 || radice > 131.0) err = E_ICE_BOUNDS;
-                    ncbands = 16;
-                    const double factor = (radice - 2.) / 3.;
-                    index_i = (int)factor; if (index_i == 43) index_i = 42;
-                    fint_i = factor - (double)index_i;
-                    icemode = 2; iceind = 2;
-                } else if (iceflag == 3) {
-                    if (radice < 5.0 || radice > 140.0) err = E_ICE_GEN_BOUNDS;
-                    ncbands = 16;
-                    const double factor = (radice - 2.) / 3.;
-                    index_i = (int)factor; if (index_i == 46) index_i = 45;
-                    fint_i = factor - (double)index_i;
-                    icemode = 3; iceind = 2;
-                } else err = E_BAD_FLAG;
-                int liqmode = -1, index_l = 1;
-                double liq_single = 0.0, fint_l = 0.0;
-                if (clwp == 0.0) { liqmode = 0; liq_single = 0.0; liqind = 0; if (iceind == 1) iceind = 2; }
-                else if (liqflag == 0) { liqmode = 0; liq_single = T.absliq0; liqind = 0; if (iceind == 1) iceind = 2; }
-                else if (liqflag == 1) {
-                    const double radliq = rel_[gi];
-                    if (radliq < 2.5 || radliq > 60.) err = E_LIQ_BOUNDS;
-                    index_l = (int)(radliq - 1.5);
-                    if (index_l == 0) index_l = 1;
-                    if (index_l == 58) index_l = 57;
-                    fint_l = radliq - 1.5 - (double)index_l;
-                    ncbands = 16; liqmode = 1; liqind = 2;
-                } else err = E_BAD_FLAG;
-                if (err) index_i = clampi(index_i, 1, 42), index_l = clampi(index_l, 1, 57);
-                for (int ib = 1; ib <= ncbands; ib++) {
-                    const int ki = icb_map(ib, iceind), kl = icb_map(ib, liqind);
-                    double ai, al;
-                    if (icemode == 0) ai = ice_single;
-                    else if (icemode == 1) ai = absice1[2 * (ki - 1)] + absice1[2 * (ki - 1) + 1] / radice;
-                    else if (icemode == 2) { const double *t = absice2 + 43 * (ki - 1); ai = t[index_i - 1] + fint_i * (t[index_i] - t[index_i - 1]); }
-                    else if (icemode == 3) { const double *t = absice3 + 46 * (ki - 1); ai = t[index_i - 1] + fint_i * (t[index_i] - t[index_i - 1]); }
-                    else ai = 0.0;
-                    if (liqmode == 0) al = liq_single;
-                    else if (liqmode == 1) { const double *t = absliq1 + 58 * (kl - 1); al = t[index_l - 1] + fint_l * (t[index_l] - t[index_l - 1]); }
-                    else al = 0.0;
-                    tcl[ib - 1] = ciwp * ai + clwp * al;
-                }
+        bool enters = cf >= 1.e-20 && cwp >= 1.e-20;
+        if (cf >= 1.e-20 && !enters) enters = cloud_layer_enters(cf, cwp, cloud_tauctot<GCM>(g, c, gc, gi, nct, lay));
+        if (enters) {
+            if (inflag == 0 || inflag == 1) ncbands = 16;
+            else if (inflag == 2) {
+                if (ciwp != 0.0) { if (iceflag == 1) ncbands = 5; else if (iceflag == 2 || iceflag == 3) ncbands = 16; }
+                if (clwp != 0.0 && liqflag == 1) ncbands = 16;
             }
         }
-#pragma unroll
-        for (int ib = 0; ib < NBND; ib++) W.taucloud[((size_t)ib * nlay + (lay - 1)) * W.ncolb + col] = tcl[ib];
-    }
-    W.ncbands[col] = ncbands;
-    if (err) atomicCAS(W.err, 0, err);
-
-    // optical depth along the diffusivity angle; note secdiff is indexed by the CLOUD band ib (rtrn :323)
-    int anycloud = 0;
-    for (int lay = 1; lay <= nlay; lay++) {
-        const double cf = cldfr[gc + (size_t)nct * (lay - 1)];
         const int cloudy = cf >= 1.e-6;
         anycloud |= cloudy;
-        W.cflag[(size_t)lay * W.ncolb + col] = cloudy;
-        // stored per SPECTRAL band B (1..16) with the band -> cloud-band map of rtrn :343-349 already applied, so that the
-        // consumers need neither ncbands nor a dependent index load
-        for (int B = 1; B <= NBND; B++) {
-            const int ib = ncbands == 1 ? 0 : (ncbands == 5 ? (B <= 2 ? B - 1 : (B <= 5 ? 2 : (B <= 8 ? 3 : 4))) : B - 1);
-            double od = 0.0, ef = 0.0;
-            if (cloudy) {
-                od = W.percol[(size_t)(PC_SECDIFF + ib) * W.ncolb + col] * W.taucloud[((size_t)ib * nlay + (lay - 1)) * W.ncolb + col];
-                if (mode == 1) ef = (1. - exp(-od)) * cf;
+        W.cflag[(size_t)lay * W.ncolb + col] = cloudy | (ncbands << 8);
+    }
+    W.ncbands[col] = ncbands;
+    W.cflag[col] = anycloud ? 8 : 0;
+    W.cflag[(size_t)(nlay + 1) * W.ncolb + col] = 0;
+}
+
+// k_cloudlay : cldprop for one (column, layer) (src/rrtmg_lw_cldprop.f90:173-293) and the cloud optical depth along the diffusivity
+//              angle per SPECTRAL band (rtrn :321-349 / rtrnmr :333-343).  mode 1 = rtrn (also the effective emissivity term), 2 = rtrnmr.
+template <bool GCM>
+__global__ __launch_bounds__(256) void k_cloudlay(DevTables T, Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int mode,
+                                                  int inflag, int iceflag, int liqflag)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncol) return;
+    const int lay = blockIdx.y + 1;
+    const size_t gc = (size_t)col0 + col;
+    const int nlay = W.nlay;
+    const size_t ncb = W.ncolb;
+    const size_t gi = gc + (size_t)nct * (lay - 1);
+    const double *S = T.stat;
+    const double *absice1 = S + T.sl.absice1, *absice2 = S + T.sl.absice2, *absice3 = S + T.sl.absice3, *absliq1 = S + T.sl.absliq1;
+    const double cf = (GCM ? g.cldfr : c.cldfrac)[gi];
+    const double ciwp = (GCM ? g.cicewp : c.ciwp)[gi], clwp = (GCM ? g.cliqwp : c.clwp)[gi];
+    const int flagword = W.cflag[(size_t)lay * ncb + col];
+    const int cloudy = flagword & 1, nb_at = flagword >> 8;       // the band count cldprop had reached when it worked on this layer
+    const int ncbands = W.ncbands[col];                            // ... and at the end of the column: rtrn's band -> cloud-band map (:343-349)
+    const double cwp = ciwp + clwp;
+    bool enters = cf >= 1.e-20 && cwp >= 1.e-20;
+    if (cf >= 1.e-20 && !enters) enters = cloud_layer_enters(cf, cwp, cloud_tauctot<GCM>(g, c, gc, gi, nct, lay));
+    // inflag 2: how the ice / liquid absorption coefficients of this layer are evaluated (cldprop :199-262)
+    int err = 0, icemode = -1, liqmode = -1, iceind = 0, liqind = 0, index_i = 1, index_l = 1;
+    double radice = 0.0, ice_single = 0.0, fint_i = 0.0, liq_single = 0.0, fint_l = 0.0;
+    if (enters && inflag == 2) {
+        radice = (GCM ? g.reice : c.rei)[gi];
+        if (ciwp == 0.0) { icemode = 0; ice_single = 0.0; iceind = 0; }
+        else if (iceflag == 0) {
+            if (radice < 10.0) err = E_ICE_SMALL;
+            icemode = 0; ice_single = T.absice0[0] + T.absice0[1] / radice; iceind = 0;
+        } else if (iceflag == 1) {
+            if (radice < 13.0 || radice > 130.) err = E_ICE_BOUNDS;
+            icemode = 1; iceind = 1;
+        } else if (iceflag == 2) {
+            if (radice < 5.0 || radice > 131.0) err = E_ICE_BOUNDS;
+            const double factor = (radice - 2.) / 3.;
+            index_i = (int)factor; if (index_i == 43) index_i = 42;
+            fint_i = factor - (double)index_i;
+            icemode = 2; iceind = 2;
+        } else if (iceflag == 3) {
+            if (radice < 5.0 || radice > 140.0) err = E_ICE_GEN_BOUNDS;
+            const double factor = (radice - 2.) / 3.;
+            index_i = (int)factor; if (index_i == 46) index_i = 45;
+            fint_i = factor - (double)index_i;
+            icemode = 3; iceind = 2;
+        } else err = E_BAD_FLAG;
+        if (clwp == 0.0) { liqmode = 0; liq_single = 0.0; liqind = 0; if (iceind == 1) iceind = 2; }
+        else if (liqflag == 0) { liqmode = 0; liq_single = T.absliq0; liqind = 0; if (iceind == 1) iceind = 2; }
+        else if (liqflag == 1) {
+            const double radliq = (GCM ? g.reliq : c.rel)[gi];
+            if (radliq < 2.5 || radliq > 60.) err = E_LIQ_BOUNDS;
+            index_l = (int)(radliq - 1.5);
+            if (index_l == 0) index_l = 1;
+            if (index_l == 58) index_l = 57;
+            fint_l = radliq - 1.5 - (double)index_l;
+            liqmode = 1; liqind = 2;
+        } else err = E_BAD_FLAG;
+        if (err) index_i = clampi(index_i, 1, 42), index_l = clampi(index_l, 1, 57);
+    }
+    if (err) atomicCAS(W.err, 0, err);
+    // cloud bands of the final count, each written to the spectral bands it serves
+    for (int ib = 1; ib <= ncbands; ib++) {
+        double t = 0.0;                                             // taucloud(lay, ib)
+        if (enters && ib <= nb_at) {
+            if (inflag == 0) t = GCM ? g.taucld[(ib - 1) + (size_t)NBND * gi] : c.tauc[gc + (size_t)nct * ((ib - 1) + (size_t)NBND * (lay - 1))];
+            else if (inflag == 1) t = T.abscld1 * cwp;
+            else if (inflag == 2) {
+                const int ki = icb_map(ib, iceind), kl = icb_map(ib, liqind);
+                double ai, al;
+                if (icemode == 0) ai = ice_single;
+                else if (icemode == 1) ai = absice1[2 * (ki - 1)] + absice1[2 * (ki - 1) + 1] / radice;
+                else if (icemode == 2) { const double *tb = absice2 + 43 * (ki - 1); ai = tb[index_i - 1] + fint_i * (tb[index_i] - tb[index_i - 1]); }
+                else if (icemode == 3) { const double *tb = absice3 + 46 * (ki - 1); ai = tb[index_i - 1] + fint_i * (tb[index_i] - tb[index_i - 1]); }
+                else ai = 0.0;
+                if (liqmode == 0) al = liq_single;
+                else if (liqmode == 1) { const double *tb = absliq1 + 58 * (kl - 1); al = tb[index_l - 1] + fint_l * (tb[index_l] - tb[index_l - 1]); }
+                else al = 0.0;
+                t = ciwp * ai + clwp * al;
             }
-            const size_t o = ((size_t)(B - 1) * nlay + (lay - 1)) * W.ncolb + col;
+        }
+        double od = 0.0, ef = 0.0;
+        if (cloudy) {        // optical depth along the diffusivity angle; secdiff is indexed by the CLOUD band ib (rtrn :323)
+            od = W.percol[(size_t)(PC_SECDIFF + ib - 1) * ncb + col] * t;
+            if (mode == 1) ef = (1. - exp(-od)) * cf;
+        }
+        // spectral bands served by cloud band ib: rtrn :343-349
+        int Blo = ib, Bhi = ib;
+        if (ncbands == 1) { Blo = 1; Bhi = NBND; }
+        else if (ncbands == 5) { Blo = ib <= 2 ? ib : (ib == 3 ? 3 : (ib == 4 ? 6 : 9)); Bhi = ib <= 2 ? ib : (ib == 3 ? 5 : (ib == 4 ? 8 : NBND)); }
+        for (int B = Blo; B <= Bhi; B++) {
+            const size_t o = ((size_t)(B - 1) * nlay + (lay - 1)) * ncb + col;
             W.odcld[o] = od;
             if (mode == 1) W.efcl[o] = ef;
         }
     }
-    W.cflag[col] = anycloud ? 8 : 0;
-    W.cflag[(size_t)(nlay + 1) * W.ncolb + col] = 0;
-    // (the maximum-random overlap factors of rtrnmr :347-506 are formed by k_sweep itself, level by level: mr_step)
 }
 
 // ------------------------------------------------------------------------------------------------

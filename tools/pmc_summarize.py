@@ -29,7 +29,7 @@ def short_name(k):
     m = re.match(r"k_cloudmc<(\w+)>", k)
     if m:
         return "k_cloudmc<%s>" % ("mask" if m.group(1) == "true" else "arrays")
-    m = re.match(r"(k_colprep|k_cloud)<\w+>", k)
+    m = re.match(r"(k_colprep|k_cloudscan|k_cloudlay|k_cloud)<\w+>", k)
     if m:
         return m.group(1)
     m = re.match(r"k_sweep<(\d+), (\d+), (\w+)>", k)       # the d(flux)/dT instantiation shares the bench's kernel name
