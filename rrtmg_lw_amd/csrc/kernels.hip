@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void k_cloudlay(DevTables T, Workspace W, GcmI
         if (err) index_i = clampi(index_i, 1, 42), index_l = clampi(index_l, 1, 57);
     }
     if (err) atomicCAS(W.err, 0, err);
+    if (!cloudy) return;          // k_layer and the sweeps read odcld / efcl of cloudy layers only
     // cloud bands of the final count, each written to the spectral bands it serves
     for (int ib = 1; ib <= ncbands; ib++) {
         double t = 0.0;                                             // taucloud(lay, ib)
@@ -349,11 +350,10 @@ __global__ __launch_bounds__(256) void k_cloudlay(DevTables T, Workspace W, GcmI
                 t = ciwp * ai + clwp * al;
             }
         }
-        double od = 0.0, ef = 0.0;
-        if (cloudy) {        // optical depth along the diffusivity angle; secdiff is indexed by the CLOUD band ib (rtrn :323)
-            od = W.percol[(size_t)(PC_SECDIFF + ib - 1) * ncb + col] * t;
-            if (mode == 1) ef = (1. - exp(-od)) * cf;
-        }
+        // optical depth along the diffusivity angle; secdiff is indexed by the CLOUD band ib (rtrn :323)
+        const double od = W.percol[(size_t)(PC_SECDIFF + ib - 1) * ncb + col] * t;
+        double ef = 0.0;
+        if (mode == 1) ef = (1. - exp(-od)) * cf;
         // spectral bands served by cloud band ib: rtrn :343-349
         int Blo = ib, Bhi = ib;
         if (ncbands == 1) { Blo = 1; Bhi = NBND; }
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
     const bool use_lds = __builtin_amdgcn_ballot_w64(!wg.ok) == 0ull;       // wave-uniform: every cell of the wave lies in the staged window
     const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
     double odcld = 0.0;
-    if constexpr (CLOUD == 1 || CLOUD == 3) odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col];   // zero for clear layers (k_cloud / k_cloudmc)
+    if constexpr (CLOUD == 1 || CLOUD == 3) { if (cloudy) odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col]; }   // (written for cloudy layers only)
     const double secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
     const double taua = a.tauaer[gcx + (size_t)a.nct * ((lay - 1) + (size_t)W.nlay * (B - 1))];
     unsigned gbits = 0u;
@@ -1287,12 +1287,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
     }
     if constexpr (FROMMASK) {
         if ((mw[0] | mw[1] | mw[2] | mw[3] | (mw[4] & 0xfffu)) == 0u) {       // no cloudy sub-column in this layer (140 = 4 x 32 + 12 bits)
-            for (int b = 0; b < NBND; b++) {
-                const size_t o = ((size_t)b * nlay + (lay - 1)) * ncb + col;
-                W.odcld[o] = 0.0;
-                W.efcl[o] = 0.0;
-            }
-            W.cflag[(size_t)lay * ncb + col] = 0;
+            W.cflag[(size_t)lay * ncb + col] = 0;      // (odcld / efcl of a layer are read only when its flag is set)
             if (lay == 1) W.cflag[(size_t)(nlay + 1) * ncb + col] = 0;
             return;
         }
