@@ -1805,6 +1805,9 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     constexpr int LV = SWEEP_LV, PF = sweep_pf(MODE, IDRV);
     static_assert(LV % PF == 0, "prefetch slots");
     constexpr int NS = sweep_ns(NQ, MODE, IDRV);
+    // refill a slot's first part in mid-level?  Pays where registers are not the limit (the two-wave d(flux)/dT sweeps: 137 layers
+    // 68.4 -> 60.3 ms per 5e5 columns); at the rtrnmr sweep's 168-register cap it doubles the spills (51.9 -> 70.0 ms)
+    constexpr bool EARLY = IDRV && MODE != 0;
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *s_lut = reinterpret_cast<float2 *>(smem);                                              // [NTBL + 1] {1 - exp, tfn}
     double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);              // [0] this band's Planck integrals, [1] band 16's (istart = 16 quirk)
@@ -1961,16 +1964,20 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     };
     // the loads of level `lev`: zlev = the interface whose temperature the sweep direction needs, nlev = the next level in sweep
     // direction; cloudy = the level's flag (known a round earlier) selects the extra loads of a cloudy level
-    auto fill = [&](int lev, int zlev, int nlev, int cloudy, SweepLev &q) {
-        q.w = 0u;
+    // part 1: what a level consumes first (codes, temperatures, fraction word), part 2: what only a cloudy level's recurrence needs;
+    // 3 = both.  A slot's first part is refilled as soon as the level has decoded it, half a level before the second.
+    auto fill = [&](int lev, int zlev, int nlev, int cloudy, SweepLev &q, int part) {
+        if (part & 1) q.w = 0u;
         if (lev >= 1 && lev <= nlay) {                         // uniform
             const size_t so = (size_t)(lev - 1) * ncb;
-            q.c = bload_scr4_nt(sC + so, off16);
-            q.tl = bload_f64(tlay + (size_t)nct * (lev - 1), off8);
-            q.tz = bload_f64(tlev + (size_t)nct * zlev, off8);
-            if (any_bin) q.w = bload_u32(sFw + so, off4);
+            if (part & 1) {
+                q.c = bload_scr4_nt(sC + so, off16);
+                q.tl = bload_f64(tlay + (size_t)nct * (lev - 1), off8);
+                q.tz = bload_f64(tlev + (size_t)nct * zlev, off8);
+                if (any_bin) q.w = bload_u32(sFw + so, off4);
+            }
             if constexpr (MODE != 0) {
-                if (cloudy) {
+                if ((part & 2) && cloudy) {
                     q.ct = bload_scr4_nt(sCt + so, off16);
                     if constexpr (MODE == 1 || MODE == 2) q.cf = bload_f64(cldf + (size_t)nct * (lev - 1), off8);
                     if constexpr (MODE == 2) q.cfn = (nlev >= 1 && nlev <= nlay) ? bload_f64(cldf + (size_t)nct * (nlev - 1), off8) : 0.0;
@@ -1999,7 +2006,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
     for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(nlay - i); fl[1][i] = ldflag(nlay - PF - i); }
 #pragma unroll
-    for (int i = 0; i < PF; i++) fill(nlay - i, nlay - i - 1, nlay - i - 1, fl[0][i], p[i]);
+    for (int i = 0; i < PF; i++) fill(nlay - i, nlay - i - 1, nlay - i - 1, fl[0][i], p[i], 3);
     bool prevcld = false;                // the previous level of the sweep was cloudy (istcldd(lev) == 0)
     double cfprev = 0.0, rat1 = 0.0, rat2 = 0.0;
     for (int top = nlay; top >= 1; top -= LV) {
@@ -2010,12 +2017,13 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
             const SweepLev &cur = p[s];
             const int cloudy = fl[0][s];
             // the slot is refilled (level lev - PF) once this level has consumed it
+            auto advance_early = [&]() { if constexpr (EARLY) fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[1][s], p[s], 1); };
             auto advance = [&]() {
                 fl[0][s] = fl[1][s];
-                fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[0][s], p[s]);
+                fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[0][s], p[s], EARLY ? 2 : 3);
                 fl[1][s] = ldflag(lev - 2 * PF);
             };
-            if (lev < 1) { advance(); continue; }          // uniform
+            if (lev < 1) { advance_early(); advance(); continue; }          // uniform
             double fr[NGC], atr[NGC], bbd[NGC];
             fracs(lev, cur.w, fr);
             const double blay = planck_at(tp0, tp0, cur.tl);
@@ -2026,6 +2034,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                 decode(cur.c.v[j], s_lut[code_index(cur.c.v[j])], atr[j], tfn);
                 bbd[j] = fr[j] * (blay + tfn * dplankdn);
             }
+            advance_early();
             double dsum = 0.0, dsumc = 0.0;
             if (MODE == 0 || !cloudy) {
 #pragma unroll
@@ -2137,7 +2146,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
     for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(i); fl[1][i] = ldflag(PF + i); }
 #pragma unroll
-    for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i]);
+    for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i], 3);
     prevcld = false; cfprev = 0.0; rat1 = 0.0; rat2 = 0.0;
     for (int base = 0; base <= nlay; base += LV) {
         Part2 accd[idrv ? LV : 1];
@@ -2148,15 +2157,17 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
             const int s = i % PF;
             const SweepLev &cur = p[s];
             const int cloudy = fl[0][s];
+            auto advance_early = [&]() { if constexpr (EARLY) fill(lev + PF, lev + PF, lev + PF + 1, fl[1][s], p[s], 1); };
             auto advance = [&]() {
                 fl[0][s] = fl[1][s];
-                fill(lev + PF, lev + PF, lev + PF + 1, fl[0][s], p[s]);
+                fill(lev + PF, lev + PF, lev + PF + 1, fl[0][s], p[s], EARLY ? 2 : 3);
                 fl[1][s] = ldflag(lev + 2 * PF);
             };
-            if (lev > nlay) { advance(); continue; }                            // uniform
+            if (lev > nlay) { advance_early(); advance(); continue; }                            // uniform
             if (lev == 0) {                                                     // uniform
                 put_part(i, 0, surf, pup);
                 if constexpr (idrv) accd[i] = dsurf;
+                advance_early();
                 advance();
                 continue;
             }
@@ -2170,6 +2181,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                 decode(cur.c.v[j], s_lut[code_index(cur.c.v[j])], atr[j], tfn);
                 bbu[j] = fr[j] * (blay + tfn * dplankup);
             }
+            advance_early();
             double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
             if (MODE == 0 || !cloudy) {
 #pragma unroll
