@@ -1807,7 +1807,11 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     constexpr int NS = sweep_ns(NQ, MODE, IDRV);
     // refill a slot's first part in mid-level?  Pays where registers are not the limit (the two-wave d(flux)/dT sweeps: 137 layers
     // 68.4 -> 60.3 ms per 5e5 columns); at the rtrnmr sweep's 168-register cap it doubles the spills (51.9 -> 70.0 ms)
+#ifdef RRLW_SWEEP_EARLY_ALL        // (tuning: rtrnmr at two waves, two slots and early refill 62.7 ms against 51.9 ms at three waves and one slot)
+    constexpr bool EARLY = MODE != 0;
+#else
     constexpr bool EARLY = IDRV && MODE != 0;
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *s_lut = reinterpret_cast<float2 *>(smem);                                              // [NTBL + 1] {1 - exp, tfn}
     double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);              // [0] this band's Planck integrals, [1] band 16's (istart = 16 quirk)
