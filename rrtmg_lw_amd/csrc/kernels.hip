@@ -1762,38 +1762,39 @@ __device__ __forceinline__ double planck_at(const double *tp, const double *tq, 
 struct OvlFac { double clr1, cld1, cmb1, cmb2, clr2, cld2, rat1, rat2; };     // rat1 / rat2: the values carried to the next cloudy level
 __device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool first, bool last, double rat1, double rat2)
 {
-    // (everything by value: carried state behind references ends up in scratch memory)
-    double clr1 = 0.0, clr2 = 0.0, cld1 = 0.0, cld2 = 0.0, cmb1 = 0.0, cmb2 = 0.0;
-    if (!last) {
-        if (cn >= cl) {
-            if (first) {
-                if (cl < 1.) clr2 = fdiv(cn - cl, 1. - cl);
-            } else {
-                const double fmx = fmax(cl, cp);
-                if (cn > fmx) { clr1 = rat2; clr2 = fdiv(cn - fmx, 1. - fmx); }
-                else if (cn < fmx) { clr1 = fdiv(cn - cl, cp - cl); }
-                else { clr1 = rat2; }
-            }
-            rat1 = (clr1 > 0. || clr2 > 0.) ? 1. : 0.;
-            rat2 = 0.;
-        } else {
-            if (first) {
-                cld2 = fdiv(cl - cn, cl);
-            } else {
-                const double fmn = fmin(cl, cp);
-                if (cn <= fmn) { cld1 = rat1; cld2 = fdiv(fmn - cn, fmn); }
-                else { cld1 = fdiv(cl - cn, cl - fmn); }
-            }
-            rat2 = (cld1 > 0. || cld2 > 0.) ? 1. : 0.;
-            rat1 = 0.;
-        }
-    }
+    // (everything by value: carried state behind references ends up in scratch memory).  Of the reference's seven ways through this
+    // block at most one needs a quotient, so the ways are told apart by predicates, ONE division runs on the selected operands and the
+    // result is routed by selects: no divergent branches (the nested form cost ~200 instructions per cloudy level, this one ~70).
+    const bool act = !last, up = cn >= cl;
+    const double fmx = fmax(cl, cp), fmn = fmin(cl, cp);
+    const bool u_f = act && up && first && cl < 1.;                 // facclr2 = (cn - cl) / (1 - cl)
+    const bool u_gt = act && up && !first && cn > fmx;              // facclr1 = rat2, facclr2 = (cn - fmx) / (1 - fmx)
+    const bool u_lt = act && up && !first && cn < fmx;              // facclr1 = (cn - cl) / (cp - cl)
+    const bool u_eq = act && up && !first && !(cn > fmx) && !(cn < fmx);      // facclr1 = rat2
+    const bool d_f = act && !up && first;                           // faccld2 = (cl - cn) / cl
+    const bool d_le = act && !up && !first && cn <= fmn;            // faccld1 = rat1, faccld2 = (fmn - cn) / fmn
+    const bool d_gt = act && !up && !first && !(cn <= fmn);         // faccld1 = (cl - cn) / (cl - fmn)
+    double num = 0.0, den = 1.0;
+    num = u_f ? cn - cl : num;     den = u_f ? 1. - cl : den;
+    num = u_gt ? cn - fmx : num;   den = u_gt ? 1. - fmx : den;
+    num = u_lt ? cn - cl : num;    den = u_lt ? cp - cl : den;
+    num = d_f ? cl - cn : num;     den = d_f ? cl : den;
+    num = d_le ? fmn - cn : num;   den = d_le ? fmn : den;
+    num = d_gt ? cl - cn : num;    den = d_gt ? cl - fmn : den;
+    const double q = fdiv(num, den);
+    const double clr1 = (u_gt || u_eq) ? rat2 : (u_lt ? q : 0.0);
+    const double clr2 = (u_f || u_gt) ? q : 0.0;
+    const double cld1 = d_le ? rat1 : (d_gt ? q : 0.0);
+    const double cld2 = (d_f || d_le) ? q : 0.0;
+    const double r1 = (act && up) ? ((clr1 > 0. || clr2 > 0.) ? 1. : 0.) : (act ? 0. : rat1);
+    const double r2 = (act && !up) ? ((cld1 > 0. || cld2 > 0.) ? 1. : 0.) : (act ? 0. : rat2);
+    double cmb1 = 0.0, cmb2 = 0.0;
     if (!first) {
         const double cx = last ? 0.0 : cn;          // beyond the last level the reference's neighbour fraction is taken as 0
         cmb1 = fmax(0., fmin(cx - cl, cp - cl));
         cmb2 = fmax(0., fmin(cl - cx, cl - cp));
     }
-    return OvlFac{clr1, cld1, cmb1, cmb2, clr2, cld2, rat1, rat2};
+    return OvlFac{clr1, cld1, cmb1, cmb2, clr2, cld2, r1, r2};
 }
 
 struct SweepLev { scr4 c, ct; double tl, tz, cf, cfn; unsigned w; };     // one level's prefetched inputs
