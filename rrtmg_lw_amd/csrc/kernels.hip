@@ -1759,9 +1759,10 @@ __device__ __forceinline__ double planck_at(const double *tp, const double *tq, 
 // the two loops are mirror images).  cl = cloud fraction of the level, cn = of the next level in sweep direction, cp = of the previous
 // one (read only when that level is cloudy, i.e. !first), last = the level is the last of the sweep.  rat1 / rat2 carry from cloudy
 // level to cloudy level as in the reference.  faccmb1/2, which the reference reads uninitialised when first, are ZERO.
-struct OvlFac { double clr1, cld1, cmb1, cmb2, clr2, cld2, rat1, rat2; };     // rat1 / rat2: the values carried to the next cloudy level
-__device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool first, bool last, double rat1, double rat2)
+struct OvlFac { double clr1, cld1, cmb1, cmb2, clr2, cld2; bool rat1, rat2; };     // rat1 / rat2 (0 or 1 in the reference): carried to the next cloudy level
+__device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool first, bool last, bool brat1, bool brat2)
 {
+    const double rat1 = brat1 ? 1. : 0., rat2 = brat2 ? 1. : 0.;
     // (everything by value: carried state behind references ends up in scratch memory).  Of the reference's seven ways through this
     // block at most one needs a quotient, so the ways are told apart by predicates, ONE division runs on the selected operands and the
     // result is routed by selects: no divergent branches (the nested form cost ~200 instructions per cloudy level, this one ~70).
@@ -1786,8 +1787,8 @@ __device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool 
     const double clr2 = (u_f || u_gt) ? q : 0.0;
     const double cld1 = d_le ? rat1 : (d_gt ? q : 0.0);
     const double cld2 = (d_f || d_le) ? q : 0.0;
-    const double r1 = (act && up) ? ((clr1 > 0. || clr2 > 0.) ? 1. : 0.) : (act ? 0. : rat1);
-    const double r2 = (act && !up) ? ((cld1 > 0. || cld2 > 0.) ? 1. : 0.) : (act ? 0. : rat2);
+    const bool r1 = (act && up) ? (clr1 > 0. || clr2 > 0.) : (act ? false : brat1);
+    const bool r2 = (act && !up) ? (cld1 > 0. || cld2 > 0.) : (act ? false : brat2);
     double cmb1 = 0.0, cmb2 = 0.0;
     if (!first) {
         const double cx = last ? 0.0 : cn;          // beyond the last level the reference's neighbour fraction is taken as 0
@@ -1963,15 +1964,15 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
         }
     };
     // layer flag (bit 0: the layer holds cloud) - out-of-range levels are clear
-    auto ldflag = [&](int lev) -> int {
-        if constexpr (MODE == 0) return 0;
-        return (lev >= 1 && lev <= nlay) ? (int)(bload_u32(sFlag + (size_t)lev * ncb, off4) & 1u) : 0;
+    auto ldflag = [&](int lev) -> bool {        // (bool: a lane mask in scalar registers, no vector register)
+        if constexpr (MODE == 0) return false;
+        return (lev >= 1 && lev <= nlay) ? (bload_u32(sFlag + (size_t)lev * ncb, off4) & 1u) != 0u : false;
     };
     // the loads of level `lev`: zlev = the interface whose temperature the sweep direction needs, nlev = the next level in sweep
     // direction; cloudy = the level's flag (known a round earlier) selects the extra loads of a cloudy level
     // part 1: what a level consumes first (codes, temperatures, fraction word), part 2: what only a cloudy level's recurrence needs;
     // 3 = both.  A slot's first part is refilled as soon as the level has decoded it, half a level before the second.
-    auto fill = [&](int lev, int zlev, int nlev, int cloudy, SweepLev &q, int part) {
+    auto fill = [&](int lev, int zlev, int nlev, bool cloudy, SweepLev &q, int part) {
         if (part & 1) q.w = 0u;
         if (lev >= 1 && lev <= nlay) {                         // uniform
             const size_t so = (size_t)(lev - 1) * ncb;
@@ -2007,20 +2008,21 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     // Rolling prefetch: the loads of a level are issued SWEEP_LV levels before it is processed (into the slot of the level just
     // consumed), its cloud flag 2 x SWEEP_LV levels before, so that the conditional loads of a cloudy level are part of the prefetch.
     SweepLev p[PF];
-    int fl[2][PF];
+    bool fl[2][PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(nlay - i); fl[1][i] = ldflag(nlay - PF - i); }
 #pragma unroll
     for (int i = 0; i < PF; i++) fill(nlay - i, nlay - i - 1, nlay - i - 1, fl[0][i], p[i], 3);
     bool prevcld = false;                // the previous level of the sweep was cloudy (istcldd(lev) == 0)
-    double cfprev = 0.0, rat1 = 0.0, rat2 = 0.0;
+    double cfprev = 0.0;
+    bool rat1 = false, rat2 = false;
     for (int top = nlay; top >= 1; top -= LV) {
 #pragma unroll
         for (int i = 0; i < LV; i++) {
             const int lev = top - i;
             const int s = i % PF;
             const SweepLev &cur = p[s];
-            const int cloudy = fl[0][s];
+            const bool cloudy = fl[0][s];
             // the slot is refilled (level lev - PF) once this level has consumed it
             auto advance_early = [&]() { if constexpr (EARLY) fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[1][s], p[s], 1); };
             auto advance = [&]() {
@@ -2059,7 +2061,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                     const double cf = cur.cf;
                     double efcl = 0.0;
                     if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
-                    OvlFac mf{0, 0, 0, 0, 0, 0, 0, 0};
+                    OvlFac mf{0, 0, 0, 0, 0, 0, false, false};
                     bool first = false;
                     if constexpr (MODE == 2) {
                         first = !prevcld;
@@ -2152,7 +2154,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(i); fl[1][i] = ldflag(PF + i); }
 #pragma unroll
     for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i], 3);
-    prevcld = false; cfprev = 0.0; rat1 = 0.0; rat2 = 0.0;
+    prevcld = false; cfprev = 0.0; rat1 = false; rat2 = false;
     for (int base = 0; base <= nlay; base += LV) {
         Part2 accd[idrv ? LV : 1];
 #pragma unroll
@@ -2161,7 +2163,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
             if constexpr (idrv) accd[i] = Part2{0.0, 0.0};
             const int s = i % PF;
             const SweepLev &cur = p[s];
-            const int cloudy = fl[0][s];
+            const bool cloudy = fl[0][s];
             auto advance_early = [&]() { if constexpr (EARLY) fill(lev + PF, lev + PF, lev + PF + 1, fl[1][s], p[s], 1); };
             auto advance = [&]() {
                 fl[0][s] = fl[1][s];
@@ -2207,7 +2209,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                     const double cf = cur.cf;
                     double efcl = 0.0;
                     if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
-                    OvlFac mf{0, 0, 0, 0, 0, 0, 0, 0};
+                    OvlFac mf{0, 0, 0, 0, 0, 0, false, false};
                     bool first = false;
                     if constexpr (MODE == 2) {
                         first = !prevcld;
