@@ -894,7 +894,7 @@ struct LayerArgs {
 struct alignas(16) scr4 { scr_t v[4]; };
 
 // The per-cell codes are written once by k_layer and read twice (down and up sweep) by k_sweep, gigabytes later: streaming
-// (non-temporal) accesses keep them from evicting the absorption tables and LUTs from L2.
+// (non-temporal) stores here and loads there (bload_scr4_nt) keep them from evicting the absorption tables from L2.
 typedef float scr_vec __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &v)
 {
@@ -905,17 +905,6 @@ __device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &
     __builtin_nontemporal_store(x, reinterpret_cast<scr_vec *>(base) + cell);
 #endif
 }
-__device__ __forceinline__ scr4 scr_load(const scr4 *p)
-{
-#ifdef RRLW_NO_NT
-    return *p;
-#else
-    const scr_vec x = __builtin_nontemporal_load(reinterpret_cast<const scr_vec *>(p));
-    scr4 v; v.v[0] = x.x; v.v[1] = x.y; v.v[2] = x.z; v.v[3] = x.w;
-    return v;
-#endif
-}
-
 // transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
 __device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * fdiv(od, bpade + od) + 0.5); }
 
