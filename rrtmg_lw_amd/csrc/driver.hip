@@ -51,10 +51,9 @@ struct State {
     size_t mask_bytes = 0;
     int batch = 131072;     // columns per internal batch: ~0.2 MB of workspace per column at 72 layers (27 GB); measured per 1e6 cloudy columns: 32768: 117.9 ms, 65536: 112.6 ms, 131072: 108.4 ms, 262144: 106.8 ms
     bool split_sweep = false;    // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: k_sweep
-                                 // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -3 %)
-                                 // at 65536-column batches (147.3 vs 155.6 ms per 1e6 columns)
+                                 // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -1 %)
     bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device
-    bool ws_two_scr = false;     // the workspace holds the second scratch set that needs
+    bool ws_two_scr = false;     // the workspace holds the second scratch set that split_sweep needs
     // host-entry staging
     void *stage_base = nullptr;
     size_t stage_bytes = 0;
