@@ -1798,6 +1798,12 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     constexpr int NS = sweep_ns(NQ, MODE, IDRV);
     // refill a slot's first part in mid-level?  Pays where registers are not the limit (the two-wave d(flux)/dT sweeps: 137 layers
     // 68.4 -> 60.3 ms per 5e5 columns); at the rtrnmr sweep's 168-register cap it doubles the spills (51.9 -> 70.0 ms)
+    // The code load is the one true HBM stream of the sweep (everything else a level needs hits L2); where the slot count is 1, the
+    // codes alone get a second slot (4 registers): issued two levels ahead
+#ifndef RRLW_SWEEP_CODES2
+#define RRLW_SWEEP_CODES2 1
+#endif
+    constexpr bool CODES2 = RRLW_SWEEP_CODES2 && PF == 1;
 #ifdef RRLW_SWEEP_EARLY_ALL        // (tuning: rtrnmr at two waves, two slots and early refill 62.7 ms against 51.9 ms at three waves and one slot)
     constexpr bool EARLY = MODE != 0;
 #else
@@ -1966,7 +1972,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
         if (lev >= 1 && lev <= nlay) {                         // uniform
             const size_t so = (size_t)(lev - 1) * ncb;
             if (part & 1) {
-                q.c = bload_scr4_nt(sC + so, off16);
+                if (!CODES2) q.c = bload_scr4_nt(sC + so, off16);
                 q.tl = bload_f64(tlay + (size_t)nct * (lev - 1), off8);
                 q.tz = bload_f64(tlev + (size_t)nct * zlev, off8);
                 if (any_bin) q.w = bload_u32(sFw + so, off4);
@@ -1997,11 +2003,17 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     // Rolling prefetch: the loads of a level are issued SWEEP_LV levels before it is processed (into the slot of the level just
     // consumed), its cloud flag 2 x SWEEP_LV levels before, so that the conditional loads of a cloudy level are part of the prefetch.
     SweepLev p[PF];
+    scr4 cq[2];                          // CODES2: gas codes of the next two levels
+    auto ldcodes = [&](int lev) -> scr4 {
+        scr4 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
+        return (lev >= 1 && lev <= nlay) ? bload_scr4_nt(sC + (size_t)(lev - 1) * ncb, off16) : z;
+    };
     bool fl[2][PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(nlay - i); fl[1][i] = ldflag(nlay - PF - i); }
 #pragma unroll
     for (int i = 0; i < PF; i++) fill(nlay - i, nlay - i - 1, nlay - i - 1, fl[0][i], p[i], 3);
+    if constexpr (CODES2) { cq[0] = ldcodes(nlay); cq[1] = ldcodes(nlay - 1); }
     bool prevcld = false;                // the previous level of the sweep was cloudy (istcldd(lev) == 0)
     double cfprev = 0.0;
     bool rat1 = false, rat2 = false;
@@ -2027,9 +2039,11 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
                 double tfn;
-                decode(cur.c.v[j], s_lut[code_index(cur.c.v[j])], atr[j], tfn);
+                const scr_t cj = CODES2 ? cq[i & 1].v[j] : cur.c.v[j];
+                decode(cj, s_lut[code_index(cj)], atr[j], tfn);
                 bbd[j] = fr[j] * (blay + tfn * dplankdn);
             }
+            if constexpr (CODES2) cq[i & 1] = ldcodes(lev - 2);
             advance_early();
             double dsum = 0.0, dsumc = 0.0;
             if (MODE == 0 || !cloudy) {
@@ -2143,6 +2157,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(i); fl[1][i] = ldflag(PF + i); }
 #pragma unroll
     for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i], 3);
+    if constexpr (CODES2) { cq[0] = ldcodes(0); cq[1] = ldcodes(1); }
     prevcld = false; cfprev = 0.0; rat1 = false; rat2 = false;
     for (int base = 0; base <= nlay; base += LV) {
         Part2 accd[idrv ? LV : 1];
@@ -2163,6 +2178,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
             if (lev == 0) {                                                     // uniform
                 put_part(i, 0, surf, pup);
                 if constexpr (idrv) accd[i] = dsurf;
+                if constexpr (CODES2) cq[i & 1] = ldcodes(lev + 2);
                 advance_early();
                 advance();
                 continue;
@@ -2174,9 +2190,11 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
                 double tfn;
-                decode(cur.c.v[j], s_lut[code_index(cur.c.v[j])], atr[j], tfn);
+                const scr_t cj = CODES2 ? cq[i & 1].v[j] : cur.c.v[j];
+                decode(cj, s_lut[code_index(cj)], atr[j], tfn);
                 bbu[j] = fr[j] * (blay + tfn * dplankup);
             }
+            if constexpr (CODES2) cq[i & 1] = ldcodes(lev + 2);
             advance_early();
             double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
             if (MODE == 0 || !cloudy) {
