@@ -1959,15 +1959,18 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
         }
     };
     // layer flag (bit 0: the layer holds cloud) - out-of-range levels are clear
-    auto ldflag = [&](int lev) -> bool {        // (bool: a lane mask in scalar registers, no vector register)
-        if constexpr (MODE == 0) return false;
-        return (lev >= 1 && lev <= nlay) ? (bload_u32(sFlag + (size_t)lev * ncb, off4) & 1u) != 0u : false;
+    // (the raw word stays in a vector register until the level that needs it: turning it into a lane mask at once would wait for the
+    // load - and, completion being in order, for every prefetch before it - right where it is issued)
+    auto ldflag = [&](int lev) -> unsigned {
+        if constexpr (MODE == 0) return 0u;
+        return (lev >= 1 && lev <= nlay) ? bload_u32(sFlag + (size_t)lev * ncb, off4) : 0u;
     };
     // the loads of level `lev`: zlev = the interface whose temperature the sweep direction needs, nlev = the next level in sweep
     // direction; cloudy = the level's flag (known a round earlier) selects the extra loads of a cloudy level
     // part 1: what a level consumes first (codes, temperatures, fraction word), part 2: what only a cloudy level's recurrence needs;
     // 3 = both.  A slot's first part is refilled as soon as the level has decoded it, half a level before the second.
-    auto fill = [&](int lev, int zlev, int nlev, bool cloudy, SweepLev &q, int part) {
+    auto fill = [&](int lev, int zlev, int nlev, unsigned flagword, SweepLev &q, int part) {
+        const bool cloudy = (flagword & 1u) != 0u;
         if (part & 1) q.w = 0u;
         if (lev >= 1 && lev <= nlay) {                         // uniform
             const size_t so = (size_t)(lev - 1) * ncb;
@@ -2008,7 +2011,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
         scr4 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
         return (lev >= 1 && lev <= nlay) ? bload_scr4_nt(sC + (size_t)(lev - 1) * ncb, off16) : z;
     };
-    bool fl[2][PF];
+    unsigned fl[2][PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(nlay - i); fl[1][i] = ldflag(nlay - PF - i); }
 #pragma unroll
@@ -2023,7 +2026,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
             const int lev = top - i;
             const int s = i % PF;
             const SweepLev &cur = p[s];
-            const bool cloudy = fl[0][s];
+            const bool cloudy = (fl[0][s] & 1u) != 0u;
             // the slot is refilled (level lev - PF) once this level has consumed it
             auto advance_early = [&]() { if constexpr (EARLY) fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[1][s], p[s], 1); };
             auto advance = [&]() {
@@ -2167,7 +2170,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
             if constexpr (idrv) accd[i] = Part2{0.0, 0.0};
             const int s = i % PF;
             const SweepLev &cur = p[s];
-            const bool cloudy = fl[0][s];
+            const bool cloudy = (fl[0][s] & 1u) != 0u;
             auto advance_early = [&]() { if constexpr (EARLY) fill(lev + PF, lev + PF, lev + PF + 1, fl[1][s], p[s], 1); };
             auto advance = [&]() {
                 fl[0][s] = fl[1][s];
