@@ -2096,7 +2096,9 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                         const double bbdtot = fr[j] * (blay + tftot * dplankdn);
                         const double gassrc = bbd[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
-                            radld[j] = radld[j] - radld[j] * (atr[j] + efj[j] * (1. - atr[j])) + gassrc + cfj[j] * (bbdtot * atot - gassrc);
+                            // (explicit fused operations: the array and the mask flavour of rtrnmc must round identically, whatever the
+                            // compiler would contract in either instantiation)
+                            radld[j] = fma(cfj[j], fma(bbdtot, atot, -gassrc), fma(-radld[j], fma(efj[j], 1. - atr[j], atr[j]), radld[j]) + gassrc);
                         } else {            // rtrnmr :591-615
                             if (first) {        // istcldd(lev) == 1
                                 cldrad[j] = cf * radld[j];
@@ -2248,7 +2250,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                         const double bbutot = fr[j] * (blay + tftot * dplankup);
                         const double gassrc = bbu[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
-                            radlu[j] = radlu[j] - radlu[j] * (atr[j] + efj[j] * (1. - atr[j])) + gassrc + cfj[j] * (bbutot * atot - gassrc);
+                            radlu[j] = fma(cfj[j], fma(bbutot, atot, -gassrc), fma(-radlu[j], fma(efj[j], 1. - atr[j], atr[j]), radlu[j]) + gassrc);
                         } else {            // rtrnmr :680-703
                             if (first) {        // istcld(lev) == 1
                                 cldrad[j] = cf * radlu[j];
