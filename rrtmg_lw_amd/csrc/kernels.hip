@@ -754,11 +754,30 @@ template <int B> constexpr int stage_max() { return std::max(std::max(Stage<B, t
 template <> constexpr int stage_max<0>() { return 0; }
 constexpr int STAGE_DOUBLES = stage_max<16>();       // 5166 doubles = 41.3 KB (bands 3 and 5, lower atmosphere)
 
-// copies [g0, g0 + n) doubles of the packed table buffer to lds[l0 ..) (all even) and returns l0 - g0
-__device__ __forceinline__ unsigned stage_seg(__amdgpu_buffer_rsrc_t kt, double2 *lds, unsigned g0, int n, int l0, int tid, int nth)
+constexpr int LAYER_BLOCK = 256;   // threads of a k_layer workgroup: three workgroups per CU (a 41 KB staging buffer each), three waves per SIMD
+
+// One segment of a band's staging list: [g0, g0 + N) doubles of the packed table buffer -> lds[l0 ..) (all even).  The copy of a band
+// is two-phase - every thread first issues ALL its 16-byte loads of ALL segments (at most 11, independent), then writes them to LDS -
+// so that a band's copy costs one memory round trip, not one per 4 KB (a load / wait / write loop: the first version).
+template <int N>
+struct SegRegs {
+    static constexpr int IT = (N / 2 + LAYER_BLOCK - 1) / LAYER_BLOCK;
+    double2 v[IT > 0 ? IT : 1];
+};
+template <int N>
+__device__ __forceinline__ void seg_load(__amdgpu_buffer_rsrc_t kt, unsigned g0, int tid, SegRegs<N> &r)
 {
-    for (int i = tid; i < n / 2; i += nth) lds[l0 / 2 + i] = ld2(kt, g0 + 2u * (unsigned)i);
-    return (unsigned)l0 - g0;
+#pragma unroll
+    for (int k = 0; k < SegRegs<N>::IT; k++) r.v[k] = ld2(kt, g0 + 2u * (unsigned)(tid + k * LAYER_BLOCK));     // (past the segment: following table data or, past the buffer, zeros; not stored)
+}
+template <int N>
+__device__ __forceinline__ void seg_store(double2 *lds, int l0, int tid, const SegRegs<N> &r)
+{
+#pragma unroll
+    for (int k = 0; k < SegRegs<N>::IT; k++) {
+        const int i = tid + k * LAYER_BLOCK;
+        if (i < N / 2) lds[l0 / 2 + i] = r.v[k];
+    }
 }
 
 template <int B, bool LOWER>
@@ -767,21 +786,36 @@ __device__ __forceinline__ void stage_band(const DevTables &T, __amdgpu_buffer_r
     using S = Stage<B, LOWER>;
     constexpr Region R = S::R;
     constexpr int ng = S::ng;
+    (void)nth;                                       // == LAYER_BLOCK
     const BandLayout &L = T.band[B - 1];
+    unsigned g[NROLE];
 #pragma unroll
-    for (int r = 0; r < NROLE; r++) delta[r] = 0u;
+    for (int r = 0; r < NROLE; r++) { delta[r] = 0u; g[r] = 0u; }
     if constexpr (S::has_major) {
         const int plane0 = LOWER ? jp0 - 1 : jp0 - 13;
-        const unsigned g0 = (unsigned)(LOWER ? L.absa : L.absb) + (unsigned)(plane0 * 5 * S::nsp * ng);
-        delta[RL_MAJOR] = stage_seg(kt, lds, g0, S::major_rows * ng, S::l_major, tid, nth);
+        g[RL_MAJOR] = (unsigned)(LOWER ? L.absa : L.absb) + (unsigned)(plane0 * 5 * S::nsp * ng);
     }
-    if constexpr (R.self_) delta[RL_SELF] = stage_seg(kt, lds, (unsigned)L.selfref, 10 * ng, S::l_self, tid, nth);
-    if constexpr (R.for_) delta[RL_FOR] = stage_seg(kt, lds, (unsigned)L.forref, 4 * ng, S::l_for, tid, nth);
-    if constexpr (R.nm > 0) delta[RL_MINOR0] = stage_seg(kt, lds, (unsigned)(LOWER ? L.minor_lo[0] : L.minor_up[0]), S::mrows(0) * ng, S::l_m0, tid, nth);
-    if constexpr (R.nm > 1) delta[RL_MINOR1] = stage_seg(kt, lds, (unsigned)(LOWER ? L.minor_lo[1] : L.minor_up[1]), S::mrows(1) * ng, S::l_m1, tid, nth);
-    if constexpr (R.nm > 2) delta[RL_MINOR2] = stage_seg(kt, lds, (unsigned)L.minor_lo[2], S::mrows(2) * ng, S::l_m2, tid, nth);
-    if constexpr (R.ncfc > 0) delta[RL_CFC0] = stage_seg(kt, lds, (unsigned)L.vec[0], ng, S::l_c0, tid, nth);
-    if constexpr (R.ncfc > 1) delta[RL_CFC1] = stage_seg(kt, lds, (unsigned)L.vec[1], ng, S::l_c1, tid, nth);
+    if constexpr (R.self_) g[RL_SELF] = (unsigned)L.selfref;
+    if constexpr (R.for_) g[RL_FOR] = (unsigned)L.forref;
+    if constexpr (R.nm > 0) g[RL_MINOR0] = (unsigned)(LOWER ? L.minor_lo[0] : L.minor_up[0]);
+    if constexpr (R.nm > 1) g[RL_MINOR1] = (unsigned)(LOWER ? L.minor_lo[1] : L.minor_up[1]);
+    if constexpr (R.nm > 2) g[RL_MINOR2] = (unsigned)L.minor_lo[2];
+    if constexpr (R.ncfc > 0) g[RL_CFC0] = (unsigned)L.vec[0];
+    if constexpr (R.ncfc > 1) g[RL_CFC1] = (unsigned)L.vec[1];
+    constexpr int n_major = S::major_rows * ng, n_self = R.self_ ? 10 * ng : 0, n_for = R.for_ ? 4 * ng : 0;
+    constexpr int n_m0 = S::mrows(0) * ng, n_m1 = S::mrows(1) * ng, n_m2 = S::mrows(2) * ng;
+    constexpr int n_c0 = R.ncfc > 0 ? ng : 0, n_c1 = R.ncfc > 1 ? ng : 0;
+    SegRegs<n_major> r_major; SegRegs<n_self> r_self; SegRegs<n_for> r_for;
+    SegRegs<n_m0> r_m0; SegRegs<n_m1> r_m1; SegRegs<n_m2> r_m2; SegRegs<n_c0> r_c0; SegRegs<n_c1> r_c1;
+    seg_load(kt, g[RL_MAJOR], tid, r_major); seg_load(kt, g[RL_SELF], tid, r_self); seg_load(kt, g[RL_FOR], tid, r_for);
+    seg_load(kt, g[RL_MINOR0], tid, r_m0); seg_load(kt, g[RL_MINOR1], tid, r_m1); seg_load(kt, g[RL_MINOR2], tid, r_m2);
+    seg_load(kt, g[RL_CFC0], tid, r_c0); seg_load(kt, g[RL_CFC1], tid, r_c1);
+    seg_store(lds, S::l_major, tid, r_major); seg_store(lds, S::l_self, tid, r_self); seg_store(lds, S::l_for, tid, r_for);
+    seg_store(lds, S::l_m0, tid, r_m0); seg_store(lds, S::l_m1, tid, r_m1); seg_store(lds, S::l_m2, tid, r_m2);
+    seg_store(lds, S::l_c0, tid, r_c0); seg_store(lds, S::l_c1, tid, r_c1);
+    const int l[NROLE] = {S::l_major, S::l_self, S::l_for, S::l_m0, S::l_m1, S::l_m2, S::l_c0, S::l_c1};
+#pragma unroll
+    for (int r = 0; r < NROLE; r++) delta[r] = (unsigned)l[r] - g[r];
 }
 
 // row offsets of the packed table buffer -> offsets into the staging buffer (rows_prep's row order: key species, self, foreign, minors, halocarbons)
@@ -1011,7 +1045,6 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     }
 }
 
-constexpr int LAYER_BLOCK = 256;   // threads of a k_layer workgroup: two workgroups per CU (a 41 KB staging buffer each), two waves per SIMD
 #ifndef RRLW_LAYER_WAVES
 #define RRLW_LAYER_WAVES 3        // waves per SIMD k_layer is compiled for (168 VGPRs; three workgroups of 256 threads and 41 KB of LDS per CU)
 #endif
