@@ -1873,7 +1873,15 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
         const int tid = (sub * NQ + slot) * 64 + tx, nth = 64 * NQ * NS;
         const double2 *src = reinterpret_cast<const double2 *>(T.stat + T.sl.lutf);
         double2 *dst = reinterpret_cast<double2 *>(smem);
-        for (int i = tid; i < SWEEP_LUT_BYTES / 16; i += nth) dst[i] = src[i];
+        // (loads first, then the LDS writes, eight at a time: a plain copy loop waits for every load before it issues the next)
+        constexpr int NLUT = SWEEP_LUT_BYTES / 16;
+        for (int i0 = tid; i0 < NLUT; i0 += 8 * nth) {
+            double2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = src[min(i0 + k * nth, NLUT - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (i0 + k * nth < NLUT) dst[i0 + k * nth] = v[k];
+        }
         const double *tp = alt16 ? T.stat + T.sl.totplk16 : T.stat + T.sl.totplnk + 181 * (B - 1);
         const double *tq = T.stat + T.sl.totplnk + 181 * 15;
         for (int i = tid; i < 181; i += nth) { s_pl[0][i] = tp[i]; s_pl[1][i] = tq[i]; }
