@@ -546,6 +546,12 @@ __host__ __device__ constexpr int band_g0(int B)      // 0-based first g-point o
 static_assert(band_g0(17) == NGPT, "g-point table");
 static_assert(NQUAD == 38, "quad table");
 
+// setcoef's chi_mls ratios and mixing ratios (6 x 59 and 7 x 59 doubles, contiguous in the static buffer): rows_prep reads two or three
+// of them per band and needs them at once; k_layer copies them into LDS once per workgroup (a global read costs ~500 cycles of
+// exposed latency each, 16 bands x 3).
+constexpr int NRATCHI = 6 * 59 + 7 * 59;
+__shared__ double s_ratchi[NRATCHI];
+
 template <int N>
 struct Rows {
     unsigned off[N > 0 ? N : 1];   // element offsets into the packed k-table buffer (row start, g = 0)
@@ -586,7 +592,7 @@ __device__ __forceinline__ void rows_prep_minor(const DevTables &T, const LayerC
     else if constexpr (M.amt == A_BRD) amount = C.f[F_COLBRD] * C.f[F_SCALEMINOR];
     else {                                              // A_ADJ: taumol :547-554
         const double colx = C.f[F_COLH2O + M.sp], coldry = C.f[F_COLDRY];
-        const double chiref = M.chiconst > 0. ? M.chiconst : (T.stat + T.sl.chi)[M.sp * 59 + C.jp];     // chi_mls(sp+1, jp+1)
+        const double chiref = M.chiconst > 0. ? M.chiconst : s_ratchi[(T.sl.chi - T.sl.rat) + M.sp * 59 + C.jp];     // chi_mls(sp+1, jp+1)
         const double chi = fdiv(colx, coldry);
         const double ratx = fdiv(1.e20 * chi, chiref);
         amount = colx;
@@ -615,7 +621,7 @@ __device__ __forceinline__ void rows_prep(const DevTables &T, const LayerCoef &C
     constexpr unsigned ng = BT<B>::ng;
     const BandLayout &L = T.band[B - 1];
     const int jp = C.jp, jt = C.jt, jt1 = C.jt1;
-    const double *rat_tab = T.stat + T.sl.rat;
+    const double *rat_tab = s_ratchi;
     rw.fw = 0u;
     if constexpr (R.key == K_ZERO) return;
 
@@ -1261,6 +1267,7 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
     }
     using GB = GroupBands<NLGROUP, GROUP>;
     // staging window of the workgroup: the region of its first thread, the smallest jp among the cells of that region
+    for (int i = threadIdx.x; i < NRATCHI; i += LAYER_BLOCK) s_ratchi[i] = S[T.sl.rat + i];
     if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; }
     __syncthreads();
     LayerWg wg;
