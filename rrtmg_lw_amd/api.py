@@ -50,12 +50,22 @@ def _check(rc):
 
 def default_kdata():
     """Real absorption coefficients if they have been converted into data/rrtmg_lw.kdata.bin
-    (rrtmg_lw_amd/kdata.py), otherwise the synthetic stand-in tables."""
-    return REAL_KDATA if os.path.exists(REAL_KDATA) else STANDIN_KDATA
+    (rrtmg_lw_amd/kdata.py); otherwise the synthetic stand-in tables - with a warning, because every flux computed
+    from them is non-physical (right shapes and magnitudes only).  Pass kdata=STANDIN_KDATA explicitly (tests, bench)
+    or set RRTMG_LW_ALLOW_STANDIN=1 to silence it."""
+    if os.path.exists(REAL_KDATA):
+        return REAL_KDATA
+    if os.environ.get("RRTMG_LW_ALLOW_STANDIN", "") != "1":
+        import warnings
+        warnings.warn(f"{REAL_KDATA} not found: rrtmg_lw_ini falls back to the STAND-IN absorption coefficients - fluxes and "
+                      "heating rates will be non-physical.  Convert the AER data with `python -m rrtmg_lw_amd.kdata "
+                      "<rrtmg_lw_k_g.f90 | rrtmg_lw.nc> data/rrtmg_lw.kdata.bin`.", RuntimeWarning, stacklevel=3)
+    return STANDIN_KDATA
 
 
 def rrtmg_lw_ini(cpdair=1004.0, kdata=None, device=None, static=STATIC_BLOB):
-    """rrtmg_lw_ini(cpdair): one-time table setup on this process's GPU (reference src/rrtmg_lw_init.f90:47)."""
+    """rrtmg_lw_ini(cpdair): one-time table setup on this process's GPU (reference src/rrtmg_lw_init.f90:47).
+    kdata=None: the converted real coefficients, or (with a RuntimeWarning) the stand-in tables; kdata_is_standin() tells."""
     global _initialised
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))

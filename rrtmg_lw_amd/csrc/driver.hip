@@ -70,6 +70,19 @@ struct State {
 State G;
 std::mutex g_mu;
 
+// The HIP current device is per host thread: an entry called from another thread (an OpenMP host model, a Python worker) must
+// select the device the workspace lives on, and leaves the caller's device selection as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    DeviceGuard()
+    {
+        if (G.init && hipGetDevice(&prev) == hipSuccess && prev != G.device) switched = hipSetDevice(G.device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define ENTRY_LOCK std::lock_guard<std::mutex> lk(g_mu); DeviceGuard dg_
+
 int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -452,7 +465,8 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         // them about what the overlap saves - measured per 1e6 columns: k_layer 32.7 ms beside them, 28.3 alone, step 93.9 vs 96.0 on one
         // stream; held back until k_layer is done they slow the sweep instead, 94.4, and the McICA generator then costs 7 ms more.)
         if (int rc = run_prep<true>(aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
-        if (gen.on) launch_kiss(aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha});
+        if (gen.on)
+            if (int rc = launch_kiss(aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha})) return rc;
         HIP_TRY(hipEventRecord(G.ev_ready[k], aux));
         HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
         if (split) {
@@ -655,6 +669,8 @@ int launch_kiss(hipStream_t s, const Workspace &Wk, int ncol, int col0, int nb, 
     } else {
         hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, Wk, in, ncol, col0, nb, nlay, icld, permuteseed);
     }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "k_subcol_kiss launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 
@@ -682,9 +698,11 @@ int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, 
                   const double *cldfrac, const double *alpha)
 {
     if (int rc = prepare_mask(ncol, nlay, icld, irng, alpha)) return rc;
+    // the mask buffer is shared with an earlier device-entry call that may still be running on another stream
+    if (G.ev_last_valid) HIP_TRY(hipStreamWaitEvent(s, G.ev_last, 0));
     SubcolIn in{play, cldfrac, alpha};
     if (irng == 0) {
-        launch_kiss(s, G.W, ncol, 0, ncol, nlay, icld, permuteseed, in);
+        if (int rc = launch_kiss(s, G.W, ncol, 0, ncol, nlay, icld, permuteseed, in)) return rc;
     } else {
         // one stream over (sub-column, column, layer): drawn here, applied per sub-column slab on the device
         HIP_TRY(hipMemsetAsync(G.mask, 0, (size_t)5 * nlay * ncol * sizeof(unsigned), s));
@@ -774,7 +792,7 @@ int rrtmg_lw_hip_kdata_is_standin(void) { return G.init ? (G.H.standin ? 1 : 0) 
 
 void rrtmg_lw_hip_finalize(void)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (!G.init) return;
     (void)hipDeviceSynchronize();
     if (G.ws_base) (void)hipFree(G.ws_base);
@@ -812,7 +830,7 @@ int rrtmg_lw_hip_set_batch(int ncol_batch)
 
 int rrtmg_lw_hip_set_overlap(int on)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     G.split_sweep = on != 0;       // the second scratch set is allocated by the next call that needs it
     return 0;
 }
@@ -822,7 +840,7 @@ int rrtmg_lw_hip_num_chunks(void) { return NQUAD; }
 
 void rrtmg_lw_hip_profile_begin(void)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     for (auto &r : G.prof) { G.evpool.push_back(r.a); G.evpool.push_back(r.b); }
     G.prof.clear();
     G.profile = true;
@@ -832,7 +850,7 @@ void rrtmg_lw_hip_profile_begin(void)
 // "<name> <launches> <total_ms>\n".  Returns the number of bytes written (truncated to len-1).
 int rrtmg_lw_hip_profile_end(char *buf, int len)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     G.profile = false;
     (void)hipDeviceSynchronize();
     std::vector<std::string> names;
@@ -867,7 +885,7 @@ int rrtmg_lw_hip_profile_end(char *buf, int len)
 
 int rrtmg_lw_hip_check(void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
     return read_physics_error((hipStream_t)stream);
 }
@@ -883,7 +901,7 @@ int rrtmg_lw_hip_run_nomcica_device(
     double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
     double *duflx_dt, double *duflxc_dt, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.nomcica.f90:456
@@ -908,7 +926,7 @@ int rrtmg_lw_hip_run_nomcica(
     double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
     double *duflx_dt, double *duflxc_dt)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
@@ -954,7 +972,7 @@ int rrtmg_lw_hip_run_columns(
     double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
     double *dtotuflux_dt, double *dtotuclfl_dt)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlayers)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
@@ -1004,7 +1022,7 @@ int rrtmg_lw_hip_run_columns_mcica(
     double *totuclfl, double *totdclfl, double *fnetc, double *htrc,
     double *dtotuflux_dt, double *dtotuclfl_dt)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlayers)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
@@ -1048,7 +1066,7 @@ int rrtmg_lw_hip_run_columns_mcica(
 // of the host-pointer entries then run as asynchronous DMA at PCIe rate instead of through the runtime's pageable staging.
 int rrtmg_lw_hip_host_register(void *ptr, long long bytes)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
     if (!ptr || bytes <= 0) return fail(RRTMG_LW_HIP_EARG, "bad host range");
     HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
@@ -1057,7 +1075,7 @@ int rrtmg_lw_hip_host_register(void *ptr, long long bytes)
 
 int rrtmg_lw_hip_host_unregister(void *ptr)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (!ptr) return fail(RRTMG_LW_HIP_EARG, "null pointer");
     HIP_TRY(hipHostUnregister(ptr));
     return 0;
@@ -1066,7 +1084,7 @@ int rrtmg_lw_hip_host_unregister(void *ptr)
 // Streams `bytes` from one device buffer into another with 16 B per lane (k_calibrate): known traffic for PMC calibration.
 int rrtmg_lw_hip_calibrate_stream(long long bytes)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
     if (bytes < 16) return fail(RRTMG_LW_HIP_EARG, "bytes must be >= 16");
     const size_t n = (size_t)bytes / 16;
@@ -1099,7 +1117,7 @@ int rrtmg_lw_hip_run_mcica_device(
     const double *cldfmcl, const double *taucmcl, const double *ciwpmcl, const double *clwpmcl,
     const double *reicmcl, const double *relqmcl, const double *tauaer, OUT_PARAMS, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.f90:469
@@ -1119,7 +1137,7 @@ int rrtmg_lw_hip_run_mcica(
     const double *cldfmcl, const double *taucmcl, const double *ciwpmcl, const double *clwpmcl,
     const double *reicmcl, const double *relqmcl, const double *tauaer, OUT_PARAMS)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
@@ -1161,7 +1179,7 @@ int rrtmg_lw_hip_run_mcica(
 int rrtmg_lw_hip_get_alpha(int ncol, int nlay, int icld, int idcor, double decorr_con, const double *dz, const double *lat,
                            int juldat, const double *cldfrac, double *alpha)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!(icld == 4 || icld == 5)) return 0;                      // alpha is only defined for the exponential overlaps
@@ -1183,7 +1201,7 @@ int rrtmg_lw_hip_mcica_subcol_device(
     const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
     double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
     if (icld == 0) return 0;                                      // src/mcica_subcol_gen_lw.f90:265
     hipStream_t s = (hipStream_t)stream;
@@ -1201,7 +1219,7 @@ int rrtmg_lw_hip_mcica_subcol(
     const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
     double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (icld == 0) return 0;
@@ -1250,7 +1268,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
     const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS, void *stream)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
@@ -1278,7 +1296,7 @@ int rrtmg_lw_hip_run_mcica_subcol(
     const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
     const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    ENTRY_LOCK;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace

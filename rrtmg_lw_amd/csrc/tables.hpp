@@ -50,6 +50,7 @@ class Blob {
         std::memcpy(&ver, &buf_[8], 4);
         std::memcpy(&n, &buf_[12], 4);
         if (ver != 1) { err = path + ": unsupported blob version"; return false; }
+        if (16 + 96 * (uint64_t)n > (uint64_t)sz) { err = path + ": entry table runs past the end of the file"; return false; }
         for (uint32_t i = 0; i < n; i++) {
             const unsigned char *p = &buf_[16 + 96 * (size_t)i];
             char name[49];
@@ -63,7 +64,7 @@ class Blob {
             std::memcpy(e.dims, p + 56, 24);
             std::memcpy(&off, p + 80, 8);
             std::memcpy(&nb, p + 88, 8);
-            if (off + nb > (uint64_t)sz || nd > 6) { err = path + ": corrupt entry table"; return false; }
+            if (off > (uint64_t)sz || nb > (uint64_t)sz - off || nd > 6) { err = path + ": corrupt entry table"; return false; }   // (no wrap-around of off + nb)
             e.dtype = (int)dt; e.ndim = (int)nd; e.data = &buf_[off]; e.nbytes = (size_t)nb;
             entries_[name] = e;
         }

@@ -3,8 +3,9 @@
 !  intents and assumed-shape dummies, so a host model's
 !      use rrtmg_lw_rad, only: rrtmg_lw
 !      call rrtmg_lw(ncol, nlay, icld, idrv, play, plev, ..., uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt)
-!  (with the sub-column arrays produced by mcica_subcol_lw) compiles unchanged.  The body forwards to rrtmg_lw_hip_run_mcica (include/rrtmg_lw_hip.h); assumed-shape
-!  actuals that are not contiguous are packed by the compiler at the call of the assumed-size C interface.
+!  (with the sub-column arrays produced by mcica_subcol_lw) compiles unchanged.  The body forwards to
+!  rrtmg_lw_hip_run_mcica (include/rrtmg_lw_hip.h) the sections (1:ncol, 1:nlay[+1]) of its arguments - what the
+!  reference's loops touch - so oversized (pcols > ncol) and strided actuals behave as with the reference.
       module rrtmg_lw_rad
 
       use iso_c_binding
@@ -82,10 +83,24 @@
          p1 = c_loc(d1)
          p2 = c_loc(d2)
       endif
+      ! sections (1:ncol, 1:nlay[+1]) as the reference's loops touch them (src/rrtmg_lw_rad.f90:785-924): oversized
+      ! (pcols > ncol) or strided actuals are packed / unpacked by the compiler, exactly-sized ones are passed in place
+      call check_extent('play', size(play,1), size(play,2), ncol, nlay)
+      call check_extent('plev', size(plev,1), size(plev,2), ncol, nlay+1)
+      call check_extent('tauaer', size(tauaer,1), size(tauaer,2), ncol, nlay)
+      call check_extent('cldfmcl', size(cldfmcl,2), size(cldfmcl,3), ncol, nlay)
+      call check_extent('uflx', size(uflx,1), size(uflx,2), ncol, nlay+1)
+      call check_extent('hr', size(hr,1), size(hr,2), ncol, nlay)
       rc = rrtmg_lw_hip_run_mcica(int(ncol, c_int), int(nlay, c_int), icld_c, int(idrv, c_int), &
-            play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, &
-            cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, int(inflglw, c_int), int(iceflglw, c_int), int(liqflglw, c_int), &
-            cldfmcl, taucmcl, ciwpmcl, clwpmcl, reicmcl, relqmcl, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, p1, p2)
+            play(1:ncol,1:nlay), plev(1:ncol,1:nlay+1), tlay(1:ncol,1:nlay), tlev(1:ncol,1:nlay+1), tsfc(1:ncol), &
+            h2ovmr(1:ncol,1:nlay), o3vmr(1:ncol,1:nlay), co2vmr(1:ncol,1:nlay), ch4vmr(1:ncol,1:nlay), &
+            n2ovmr(1:ncol,1:nlay), o2vmr(1:ncol,1:nlay), cfc11vmr(1:ncol,1:nlay), cfc12vmr(1:ncol,1:nlay), &
+            cfc22vmr(1:ncol,1:nlay), ccl4vmr(1:ncol,1:nlay), emis(1:ncol,1:16), &
+            int(inflglw, c_int), int(iceflglw, c_int), int(liqflglw, c_int), &
+            cldfmcl(1:140,1:ncol,1:nlay), taucmcl(1:140,1:ncol,1:nlay), ciwpmcl(1:140,1:ncol,1:nlay), &
+            clwpmcl(1:140,1:ncol,1:nlay), reicmcl(1:ncol,1:nlay), relqmcl(1:ncol,1:nlay), tauaer(1:ncol,1:nlay,1:16), &
+            uflx(1:ncol,1:nlay+1), dflx(1:ncol,1:nlay+1), hr(1:ncol,1:nlay), &
+            uflxc(1:ncol,1:nlay+1), dflxc(1:ncol,1:nlay+1), hrc(1:ncol,1:nlay), p1, p2)
       if (rc /= 0) call rrtmg_lw_hip_abort('rrtmg_lw')
       icld = int(icld_c, im)
       if (idrv == 1) then
@@ -94,5 +109,16 @@
       endif
 
       end subroutine rrtmg_lw
+
+      subroutine check_extent(name, n1, n2, ncol, nl)
+      character(len=*), intent(in) :: name
+      integer, intent(in) :: n1, n2
+      integer(kind=im), intent(in) :: ncol, nl
+      if (n1 < ncol .or. n2 < nl) then
+         write(*,'(a,a,a,i0,a,i0,a,i0,a,i0,a)') 'rrtmg_lw: ', name, ' has extents (', n1, ',', n2, &
+               '), smaller than (', ncol, ',', nl, ')'
+         error stop 1
+      endif
+      end subroutine check_extent
 
       end module rrtmg_lw_rad

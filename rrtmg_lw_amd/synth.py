@@ -203,3 +203,41 @@ def make_gcm_inputs(ncol, nlay, config="clear", col0=0, backend="numpy", device=
     out.update(ncol=ncol, nlay=nlay, inflglw=2, iceflglw=3, liqflglw=1,
                icld=2 if perturbed else 0, idrv=1 if config == "aer_idrv" else 0)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Stress variants: inputs that reach the branches the benchmark columns never take (numpy only; deterministic).
+#   "highgas"   CO2 x {2, 4, 8} and N2O x {2, 2.5, 3} by column: the `ratx > thr` adjustment of the minor-gas amounts
+#               (reference src/rrtmg_lw_taumol.f90:547-554, 1352-1359, 1478-1487, 1718-1725, 2494-2501)
+#   "cold"      every temperature 70 K lower: Planck-table index and jt / indself / indminor clamps at the cold end
+#   "hot"       every temperature 70 K higher: the clamps at the warm end (reference src/rrtmg_lw_setcoef.f90:174-178, 294-305)
+#   "allupper"  the whole column above 95.6 hPa (laytrop = 0), pressures down to 0.006 hPa (jp clamps at 58)
+#   "alllower"  the whole column below that level (laytrop = nlay)
+# ------------------------------------------------------------------------------------------------------------------
+STRESS_KINDS = ("highgas", "cold", "hot", "allupper", "alllower")
+
+
+def make_stress_inputs(kind, ncol, nlay, config="cloudy", col0=0):
+    d = make_gcm_inputs(ncol, nlay, config, col0=col0)
+    c = np.arange(ncol)
+    if kind == "highgas":
+        fco2 = np.array([2.0, 4.0, 8.0, 1.0])[c % 4][:, None]
+        fn2o = np.array([1.0, 2.0, 2.5, 3.0])[(c // 2) % 4][:, None]
+        d["co2vmr"] = np.asfortranarray(np.array(d["co2vmr"]) * fco2)
+        d["n2ovmr"] = np.asfortranarray(np.array(d["n2ovmr"]) * fn2o)
+    elif kind in ("cold", "hot"):
+        dt = -70.0 if kind == "cold" else 70.0
+        for k in ("tlay", "tlev", "tsfc"):
+            d[k] = np.asfortranarray(np.array(d[k]) + dt)
+    elif kind in ("allupper", "alllower"):
+        # ln p of every level mapped linearly onto [ln 1013, ln 110] (all lower) or [ln 90, ln 0.006] (all upper)
+        lo, hi = (np.log(1013.0), np.log(110.0)) if kind == "alllower" else (np.log(90.0), np.log(0.006))
+        s0, s1 = np.log(1013.0), np.log(0.067)
+        for k in ("play", "plev"):
+            p = np.array(d[k])
+            f = p / base_profile(nlay)[k][None, :]            # the per-column surface-pressure factor of the base set
+            x = (np.log(base_profile(nlay)[k]) - s0) / (s1 - s0)
+            d[k] = np.asfortranarray(np.exp(lo + x * (hi - lo))[None, :] * f)
+    else:
+        raise ValueError(kind)
+    return d

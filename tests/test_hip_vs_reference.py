@@ -1,0 +1,111 @@
+"""GPU tests: the HIP path (through the C ABI) compared DIRECTLY with numbers the reference itself produced.
+
+ * tests/golden/ref_gcm_*.npz, ref_stress_*.npz, ref_col_*.npz - outputs of the reference's own Fortran
+   (tools/gen_ref_fixtures.py; flang build of /root/reference by oracle/Makefile, stand-in k tables) on seeded inputs:
+   the GCM entry (src/rrtmg_lw_rad.nomcica.f90:99-588) and the prepared-column sequence of the column driver
+   (src/rrtmg_lw.1col.f90:497-580), the latter including BASELINE.json configs[0] = input_rrtm_MLS-clr, 51 layers,
+   total and all 16 per-band blocks;
+ * the k-independent numbers of the reference's checked-in OUTPUT_RRTM files: upward flux at the surface per band
+   (src/rrtmg_lw_rtrn.f90:476-489,549-562).
+No oracle in between (tests/test_hip_parity.py covers HIP vs oracle on larger inputs).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from rrtmg_lw_amd.io_rrtm import read_input_rrtm, read_output_rrtm
+from rrtmg_lw_amd.synth import make_gcm_inputs, make_stress_inputs
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+FLUX_TOL, HR_TOL = 0.01, 0.001        # BASELINE.json north_star
+TIGHT = 5e-5                          # regression bar (a last-bit difference can move a 1e-4-quantised table index)
+
+
+def _check(got, f, idrv, tag):
+    keys = ("uflx", "dflx", "uflxc", "dflxc")
+    dflux = max(np.abs(got[k] - f[k]).max() for k in keys)
+    dhr = max(np.abs(got[k] - f[k]).max() for k in ("hr", "hrc"))
+    ddt = max(np.abs(got[k] - f[k]).max() for k in ("duflx_dt", "duflxc_dt")) if idrv else 0.0
+    print(f"{tag}: HIP vs reference fixture max|dflux|={dflux:.3e} max|dhr|={dhr:.3e} max|d(dF/dT)|={ddt:.3e}")
+    assert dflux <= FLUX_TOL and dhr <= HR_TOL and ddt <= FLUX_TOL
+    assert dflux <= TIGHT and dhr <= TIGHT and ddt <= TIGHT
+    assert got["icld"] == int(f["icld_out"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_gcm_*.npz"))), ids=os.path.basename)
+def test_gcm_entry_matches_reference_fixture(hip, path):
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
+    got = hip.rrtmg_lw_from_dict(d, icld=icld)
+    _check(got, f, d["idrv"], os.path.basename(path))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_stress_*.npz"))), ids=os.path.basename)
+def test_stress_inputs_match_reference_fixture(hip, path):
+    """2x-8x CO2 / 2x-3x N2O (the `ratx > thr` adjustment, src/rrtmg_lw_taumol.f90:547-554 and its four sibling sites),
+    temperatures outside 160-339 K (Planck-index and jt clamps, src/rrtmg_lw_setcoef.f90:174-178,294-305), laytrop = 0 and
+    laytrop = nlay."""
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_stress_inputs(str(f["kind"]), ncol, nlay, col0=int(f["col0"]))
+    got = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=0)
+    _check(got, f, 0, os.path.basename(path))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_col_*.npz"))), ids=os.path.basename)
+def test_prepared_columns_match_reference_fixture(hip, path):
+    """Prepared-column entry vs the reference's column-driver sequence; ref_col_MLS-clr.npz is BASELINE configs[0]
+    (single MLS clear-sky column, 51 layers) with the total and every one of the 16 per-band blocks."""
+    f = np.load(path)
+    j = lambda n: os.path.join(G, n) if n else None
+    col = read_input_rrtm(j(str(f["inp"])), j(str(f["cld"])), j(str(f["aer"])))
+    if col["imca"] == 1:
+        col["imca"] = 0
+    got = hip.run_columns([col], 1, 16)
+    worst = 0.0
+    for k in ("totuflux", "totdflux", "fnet", "totuclfl", "totdclfl", "fnetc", "htr", "htrc", "dtotuflux_dt", "dtotuclfl_dt"):
+        if k.startswith("dtot") and col["idrv"] != 1:
+            continue
+        dv = np.abs(got[k][0] - f[k]).max()
+        worst = max(worst, dv)
+        assert dv <= (HR_TOL if k.startswith("htr") else FLUX_TOL), k
+        assert dv <= TIGHT, k
+    nb = 0
+    for key in f.files:
+        if key.startswith("b") and key.endswith("_up"):
+            b = int(key[1:-3])
+            gb = hip.run_columns([col], b, b)
+            for kk, gk in (("up", "totuflux"), ("dn", "totdflux"), ("htr", "htr")):
+                dv = np.abs(gb[gk][0] - f[f"b{b}_{kk}"]).max()
+                worst = max(worst, dv)
+                assert dv <= TIGHT, (b, kk)
+            nb += 1
+    print(f"{os.path.basename(path)}: total + {nb} band blocks, worst |d| = {worst:.3e}")
+    if str(f["inp"]) == "input_rrtm_MLS-clr":
+        assert nb == 16 and int(col["nlayers"]) == 51
+
+
+CLR = [("MLS-clr", None), ("MLS-clr-aer12", "in_aer_rrtm-aer12"), ("MLW-clr", None), ("SAW-clr", None), ("TROP-clr", None)]
+
+
+@pytest.mark.parametrize("name,aer", CLR, ids=[c[0] for c in CLR])
+def test_surface_emission_matches_golden_output(hip, name, aer):
+    """The one part of the reference's checked-in OUTPUT_RRTM files that does not depend on the (missing) absorption
+    coefficients: the upward flux at level 0, total and per band, = pi 1e4 delwave B_band(tbound) sum_g fracs(1,g) with
+    emissivity 1 (src/rrtmg_lw_rtrn.f90:476-489,549-562,580-583; real and stand-in fractions both sum to 1 per band).
+    Pins Planck tables, the surface Planck interpolation incl. the band-16 istart = 16 variant, delwave and fluxfac of the
+    HIP path against the reference's own printed results (4 decimals)."""
+    col = read_input_rrtm(os.path.join(G, f"input_rrtm_{name}"), None, os.path.join(G, aer) if aer else None)
+    blocks = read_output_rrtm(os.path.join(G, f"output_rrtm_{name}"))
+    tot = hip.run_columns([col], 1, 16)
+    assert abs(tot["totuflux"][0][0] - blocks[0]["uflx"][0]) < 2e-3
+    assert tot["totdflux"][0][-1] == 0.0 and blocks[0]["dflx"][-1] == 0.0
+    if len(blocks) == 17:
+        for b in range(1, 17):
+            gb = hip.run_columns([col], b, b)
+            assert abs(gb["totuflux"][0][0] - blocks[b]["uflx"][0]) < 2e-3 * max(1.0, blocks[b]["uflx"][0] / 50), b

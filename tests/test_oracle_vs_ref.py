@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from rrtmg_lw_amd.io_rrtm import read_input_rrtm
-from rrtmg_lw_amd.synth import make_gcm_inputs
+from rrtmg_lw_amd.synth import make_gcm_inputs, make_stress_inputs
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 # same compiler-independent arithmetic on both sides: agreement is at rounding level, except where a last-bit
@@ -30,6 +30,28 @@ def test_gcm_fixture(oracle, path):
     keys = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if d["idrv"] else ())
     for k in keys:
         assert np.abs(o[k] - f[k]).max() <= TOL, k
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_stress_*.npz"))), ids=os.path.basename)
+def test_stress_fixture(oracle, path):
+    """High CO2 / N2O (minor-gas adjustment branch), temperatures beyond the table ends, laytrop = 0 and = nlay."""
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_stress_inputs(str(f["kind"]), ncol, nlay, col0=int(f["col0"]))
+    o = oracle.rrtmg_lw(ncol, nlay, icld, 0, d)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.abs(o[k] - f[k]).max() <= TOL, k
+    # the inputs do reach the branches they are meant for
+    kind = str(f["kind"])
+    lnp = np.log(np.array(d["play"]))
+    if kind == "allupper":
+        assert (lnp <= 4.56).all()
+    if kind == "alllower":
+        assert (lnp > 4.56).all()
+    if kind == "cold":
+        assert np.array(d["tlay"]).min() < 160.0
+    if kind == "hot":
+        assert np.array(d["tlay"]).max() > 339.0 and np.array(d["tsfc"]).max() > 339.0
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_col_*.npz"))), ids=os.path.basename)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle.bindings import Reference  # noqa: E402
 from rrtmg_lw_amd.io_rrtm import read_input_rrtm  # noqa: E402
-from rrtmg_lw_amd.synth import make_gcm_inputs  # noqa: E402
+from rrtmg_lw_amd.synth import STRESS_KINDS, make_gcm_inputs, make_stress_inputs  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 OUT_KEYS = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")
@@ -25,6 +25,7 @@ GCM_CASES = [  # name, config, ncol, nlay, icld
     ("cloudy72_rnd", "cloudy", 24, 72, 1), ("aer137", "aer_idrv", 8, 137, 2), ("aer40_rnd", "aer_idrv", 8, 40, 1),
     ("cloudy72_icld9", "cloudy", 6, 72, 9),
 ]
+STRESS_CASES = [(k, 12, 72, icld) for k in STRESS_KINDS for icld in (0, 2)]      # name, ncol, nlay, icld (synth.make_stress_inputs)
 MCICA_CASES = [  # name, config, ncol, nlay, icld, irng, ims (permuteseed = ims * 140), idcor, juldat
     ("mr_kiss", "cloudy", 6, 40, 2, 0, 1, 0, 0), ("rnd_kiss", "cloudy", 5, 72, 1, 0, 2, 0, 0), ("max_kiss", "cloudy", 5, 51, 3, 0, 1, 0, 0),
     ("exp_kiss", "cloudy", 6, 40, 4, 0, 1, 1, 150), ("exprnd_kiss", "aer_idrv", 6, 40, 5, 0, 3, 1, 300),
@@ -46,6 +47,12 @@ def main():
         o = ref.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
         np.savez_compressed(os.path.join(G, f"ref_gcm_{name}.npz"), config=cfg, ncol=ncol, nlay=nlay, icld=icld, col0=4242,
                             icld_out=o["icld"], **{k: o[k] for k in OUT_KEYS})
+    for kind, ncol, nlay, icld in STRESS_CASES:
+        d = make_stress_inputs(kind, ncol, nlay, col0=31)
+        o = ref.rrtmg_lw(ncol, nlay, icld, 0, d)
+        assert all(np.isfinite(o[k]).all() for k in OUT_KEYS)
+        np.savez_compressed(os.path.join(G, f"ref_stress_{kind}_icld{icld}.npz"), kind=kind, ncol=ncol, nlay=nlay, icld=icld, col0=31,
+                            icld_out=o["icld"], **{k: o[k] for k in OUT_KEYS})
     for name, inp, cld, aer in COL_CASES:
         col = read_input_rrtm(os.path.join(G, inp), os.path.join(G, cld) if cld else None, os.path.join(G, aer) if aer else None)
         if col["imca"] == 1:
@@ -53,7 +60,7 @@ def main():
         o = ref.column(col)
         bands = {}
         if col["iout"] == 99:       # per-band blocks as the column driver produces them (istart = iend = band, iout = 99)
-            for b in (1, 3, 6, 8, 13, 16):
+            for b in range(1, 17):
                 ob = ref.column(col, b, b, 99)
                 bands[f"b{b}_up"] = ob["totuflux"]
                 bands[f"b{b}_dn"] = ob["totdflux"]
