@@ -339,11 +339,11 @@ __global__ __launch_bounds__(256) void k_cloudlay(DevTables T, Workspace W, GcmI
             else if (inflag == 2) {
                 int ki = icb_map(ib, iceind);
                 const int kl = icb_map(ib, liqind);
-                // iceflag = 1 (Ebert-Curry) has five ice bands.  When another layer of the column made cldprop carry 16 bands (liqflag = 1) and
-                // this layer is ice only, the reference promotes iceind to 2 and reads abscoice(6:16) left over from an earlier layer or call
-                // (src/rrtmg_lw_cldprop.f90:219-231,252-258: ill-defined upstream).  Here such a layer uses the Ebert-Curry band of the
-                // spectral band (the 5-band map) instead of reading past the table.
-                if (icemode == 1) ki = icb_map(ib, 1);
+                // iceflag = 1 (Ebert-Curry) has five ice bands.  When another layer of the column made cldprop carry 16 bands (liqflag = 1
+                // with liquid water) and this layer is ice only, the reference promotes iceind to 2 and reads abscoice(6:16), values left over
+                // from an earlier layer or call (src/rrtmg_lw_cldprop.f90:215-222,252-258,283-286: ill-defined upstream).  Bands 1-5 are the
+                // reference's; bands 6-16 of such a layer use the fifth Ebert-Curry band here instead of reading past the 5 x 2 table.
+                if (icemode == 1 && ki > 5) ki = 5;
                 double ai, al;
                 if (icemode == 0) ai = ice_single;
                 else if (icemode == 1) ai = absice1[2 * (ki - 1)] + absice1[2 * (ki - 1) + 1] / radice;

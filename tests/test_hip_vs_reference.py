@@ -23,6 +23,8 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 FLUX_TOL, HR_TOL = 0.01, 0.001        # BASELINE.json north_star
 TIGHT = 5e-5                          # regression bar (a last-bit difference can move a 1e-4-quantised table index)
+TIGHT_REL = 2.5e-7                    # ... relative to the largest flux where that is larger (stress inputs reach 930 W m-2): the
+                                      # sweep's transmittance / tfn values are float32 (north_star: expf-class transmittance)
 
 
 def _check(got, f, idrv, tag):
@@ -32,7 +34,8 @@ def _check(got, f, idrv, tag):
     ddt = max(np.abs(got[k] - f[k]).max() for k in ("duflx_dt", "duflxc_dt")) if idrv else 0.0
     print(f"{tag}: HIP vs reference fixture max|dflux|={dflux:.3e} max|dhr|={dhr:.3e} max|d(dF/dT)|={ddt:.3e}")
     assert dflux <= FLUX_TOL and dhr <= HR_TOL and ddt <= FLUX_TOL
-    assert dflux <= TIGHT and dhr <= TIGHT and ddt <= TIGHT
+    tight = max(TIGHT, TIGHT_REL * max(np.abs(f[k]).max() for k in keys))
+    assert dflux <= tight and dhr <= TIGHT and ddt <= tight
     assert got["icld"] == int(f["icld_out"])
 
 
