@@ -282,8 +282,7 @@ def main():
             pach = bpc * ncol * args.steps / (ktot * 1e-3) / 1e9
             path = dict(kernels_ms_per_step=round(ktot / args.steps, 3), achieved=round(pach, 3), unit="GB/s",
                         frac=round(pach / HBM_PEAK_GBS, 5), bytes_per_column=bpc,
-                        top=[dict(kernel=k, ms_per_step=round(v[1] / args.steps, 3)) for k, v in
-                             sorted(kern.items(), key=lambda kv: -kv[1][1])[:6]],
+                        kernels={k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                         families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
                                   for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweep", "k_flux", "k_rates")})
             # PMC-derived HBM traffic of the dominant kernel, if a summary has been committed under profiles/

@@ -35,7 +35,7 @@ struct State {
     bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *ltop; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by k_sweep exists twice as well: k_sweep/k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -170,6 +170,16 @@ int sweep_attr_one()
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M, true)));
     return 0;
 }
+template <int Q>
+int sweepc_attr_one()
+{
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
+    return 0;
+}
 template <int M>
 int sweep_attr_mode()
 {
@@ -181,7 +191,10 @@ int sweep_attr_mode()
 int ensure_sweep_attrs()
 {
     if (G.sweep_attrs) return 0;
-    if (int rc = sweep_attr_mode<0>()) return rc;
+    if (int rc = sweepc_attr_one<1>()) return rc;
+    if (int rc = sweepc_attr_one<2>()) return rc;
+    if (int rc = sweepc_attr_one<3>()) return rc;
+    if (int rc = sweepc_attr_one<4>()) return rc;
     if (int rc = sweep_attr_mode<1>()) return rc;
     if (int rc = sweep_attr_mode<2>()) return rc;
     if (int rc = sweep_attr_mode<3>()) return rc;
@@ -222,7 +235,9 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         items.push_back({(void **)&ps.laytrop, n * 4});
         items.push_back({(void **)&ps.ncbands, n * 4});
         items.push_back({(void **)&ps.cflag, (L + 2) * n * 4});
+        items.push_back({(void **)&ps.ltop, 256});
     }
+    if (cloud) items.push_back({(void **)&W.hand, (size_t)5 * NQUAD * 4 * n * 8});
     if (cloud) {
         for (auto &ps : G.prep) {
             items.push_back({(void **)&ps.odcld, 16 * L * n * 8});
@@ -246,7 +261,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     {   // G.W itself carries prep set 0 and scratch set 0
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
-        W.odcld = ps.odcld; W.efcl = ps.efcl;
+        W.odcld = ps.odcld; W.efcl = ps.efcl; W.ltop = ps.ltop;
     }
     G.ws_bytes = total;
     G.ws_nlay = nlay;
@@ -274,7 +289,7 @@ Workspace ws_for(int k)
     Workspace w = G.W;
     const State::PrepSet &ps = G.prep[k];
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
-    w.odcld = ps.odcld; w.efcl = ps.efcl;
+    w.odcld = ps.odcld; w.efcl = ps.efcl; w.ltop = ps.ltop;
     const State::ScrSet &ss = G.scrset[G.ws_two_scr ? k : 0];
     for (int a = 0; a < NSCR; a++) w.scr[a] = ss.scr[a];
     w.fw = ss.fw;
@@ -372,31 +387,54 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     sa.cldfrac = GCM ? g.cldfr : c.cldfrac;
     sa.tlay = GCM ? g.tlay : c.tavel;
     sa.tlev = GCM ? g.tlev : c.tz;
-    // one sweep launch per class of bands with the same number of quads (workgroup = 64 columns x that many waves)
-    for (int nq = 4; nq >= 1; nq--) {
-        unsigned long long list = 0ull;
-        int nb_bands = 0;
+    // Per class of bands with the same number of quads: a cloud-free call (mode 0) is one k_sweepc<., 0> launch; the cloudy modes run
+    // k_sweepc<., 1> (layers above the batch's highest cloud, downward), k_sweep<mode> (layers 1 .. ltop down, surface, up) and
+    // k_sweepc<., 2> (layers above, upward).  The classes are independent of each other: with `fan` each class has its own stream;
+    // on one stream the launches go phase by phase (all downward ones, then the cloud zone, then the upward ones) so that consecutive
+    // launches never wait for each other's last workgroups.
+    unsigned long long lists[5] = {0, 0, 0, 0, 0};
+    int nbs[5] = {0, 0, 0, 0, 0};
+    for (int nq = 1; nq <= 4; nq++)
         for (int B = 1; B <= NBND; B++)
-            if (band_nquad(B) == nq && B >= istart && B <= iend) list |= (unsigned long long)(B - 1) << (4 * nb_bands++);
-        if (nb_bands == 0) continue;
-        sa.bands = list;
-        const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;     // (shadows the function's stream for the launch macros below)
+            if (band_nquad(B) == nq && B >= istart && B <= iend) lists[nq] |= (unsigned long long)(B - 1) << (4 * nbs[nq]++);
+#define SWEEPC_I(Q, PH, I)                                                                                           \
+    do {                                                                                                             \
+        const int ns = sweepc_ns(Q, PH, I);                                                                          \
+        sa.ncb = (nb + 64 * ns - 1) / (64 * ns);                                                                     \
+        const dim3 sgrid((unsigned)(((sa.ncb + 7) / 8) * 8 * sa.nbands)), sblock(64, 1, ns);                         \
+        LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I>), sgrid, sblock, SWEEPC_LDS_BYTES, s, G.D, Wk, sa); \
+    } while (0)
+#define SWEEPC(Q, PH) do { if (idrv == 1 && PH != 1) SWEEPC_I(Q, PH, true); else SWEEPC_I(Q, PH, false); } while (0)
+#define SWEEPC_Q(PH) do { if (nq == 4) SWEEPC(4, PH); else if (nq == 3) SWEEPC(3, PH); else if (nq == 2) SWEEPC(2, PH); else SWEEPC(1, PH); } while (0)
 #define SWEEP_I(M, Q, I)                                                                                             \
     do {                                                                                                             \
         const int ns = sweep_ns(Q, M, I);                                                                            \
         sa.ncb = (nb + 64 * ns - 1) / (64 * ns);                                                                     \
-        sa.nbands = nb_bands;                                                                                        \
-        const dim3 sgrid((unsigned)(((sa.ncb + 7) / 8) * 8 * nb_bands)), sblock(64, Q, ns);                          \
+        const dim3 sgrid((unsigned)(((sa.ncb + 7) / 8) * 8 * sa.nbands)), sblock(64, sweep_t(Q, M, I), ns);          \
         LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, I>), sgrid, sblock, sweep_lds_bytes(Q, M, I), s, G.D, Wk, sa); \
     } while (0)
 #define SWEEP(M, Q) do { if (idrv == 1) SWEEP_I(M, Q, true); else SWEEP_I(M, Q, false); } while (0)
-#define SWEEP_MODE(Q)                                                          \
-        if (mode == 0) SWEEP(0, Q); else if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q);
-        if (nq == 4) { SWEEP_MODE(4) } else if (nq == 3) { SWEEP_MODE(3) } else if (nq == 2) { SWEEP_MODE(2) } else { SWEEP_MODE(1) }
+#define SWEEP_MODE(Q) do { if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q); } while (0)
+#define SWEEP_Q() do { if (nq == 4) SWEEP_MODE(4); else if (nq == 3) SWEEP_MODE(3); else if (nq == 2) SWEEP_MODE(2); else SWEEP_MODE(1); } while (0)
+    for (int phase = 0; phase < 3; phase++) {
+        for (int nq = 4; nq >= 1; nq--) {
+            if (nbs[nq] == 0) continue;
+            sa.bands = lists[nq];
+            sa.nbands = nbs[nq];
+            const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;     // (shadows the function's stream for the launch macros)
+            if (mode == 0) { if (phase == 0) SWEEPC_Q(0); }
+            else if (phase == 0) SWEEPC_Q(1);
+            else if (phase == 1) SWEEP_Q();
+            else SWEEPC_Q(2);
+        }
+    }
+#undef SWEEP_Q
 #undef SWEEP_MODE
 #undef SWEEP
 #undef SWEEP_I
-    }
+#undef SWEEPC_Q
+#undef SWEEPC
+#undef SWEEPC_I
     if (fan) {
         for (int k = 0; k < 3; k++) {
             HIP_TRY(hipEventRecord(G.ev_swq_done[k], G.swq[k]));

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 
 #include "tables.hpp"
@@ -73,6 +74,9 @@ struct Workspace {
     double *odcld;      // [16][nlay][ncolb]   secdiff(ib) * taucloud
     double *efcl;       // [16][nlay][ncolb]   rtrn: (1 - exp(-odcld)) * cldfrac
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcld, bit2 istcldd; cflag[0] bit3 = column has cloud
+    int *ltop;          // [1] highest layer of the batch that holds cloud in any column (0: none): above it every sweep is the clear-sky one
+    double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at level ltop: 0 downward (k_sweepc<.,1> -> k_sweep), 1 / 2 upward
+                        // total / clear (k_sweep -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
     unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
     Part2 *pdn, *pup;   // [16 bands][nlay+1][ncolb]
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
     }
     W.ncbands[col] = 1;
     W.cflag[col] = 0;
+    if (col == 0) *W.ltop = 0;          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
     const int nlay = W.nlay;
     const double *cldfr = GCM ? g.cldfr : c.cldfrac;
     const double *ciwp_ = GCM ? g.cicewp : c.ciwp, *clwp_ = GCM ? g.cliqwp : c.clwp;
-    int ncbands = 1, anycloud = 0;
+    int ncbands = 1, anycloud = 0, top = 0;
     for (int lay = 1; lay <= nlay; lay++) {
         const size_t gi = gc + (size_t)nct * (lay - 1);
         const double cf = cldfr[gi], ciwp = ciwp_[gi], clwp = clwp_[gi];
@@ -260,8 +265,10 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
         }
         const int cloudy = cf >= 1.e-6;
         anycloud |= cloudy;
+        if (cloudy) top = lay;
         W.cflag[(size_t)lay * W.ncolb + col] = cloudy | (ncbands << 8);
     }
+    if (top > *reinterpret_cast<volatile int *>(W.ltop)) atomicMax(W.ltop, top);      // (few columns get past the test once the first waves have reported)
     W.ncbands[col] = ncbands;
     W.cflag[col] = anycloud ? 8 : 0;
     W.cflag[(size_t)(nlay + 1) * W.ncolb + col] = 0;
@@ -1461,6 +1468,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
     }
     W.cflag[(size_t)lay * ncb + col] = any;
     if (any) atomicOr(&W.cflag[col], 8);
+    if (any && lay > *reinterpret_cast<volatile int *>(W.ltop)) atomicMax(W.ltop, lay);
     if (lay == 1) W.cflag[(size_t)(nlay + 1) * ncb + col] = 0;
     if (err) atomicCAS(W.err, 0, err);
 }
@@ -1715,8 +1723,33 @@ __host__ __device__ constexpr int sweep_pf(int MODE, bool IDRV) { return MODE ==
 #ifndef RRLW_SWEEP_WAVES_MCMASK
 #define RRLW_SWEEP_WAVES_MCMASK 4 // MODE 4 (125-127 VGPRs; 130.3 vs 143.2 ms per 1e6 McICA columns at 3)
 #endif
-__host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV)
+// quads of a band one thread carries through the sweep (G); a band of NQ quads then takes T = NQ / G threads per column, and only
+// T > 1 needs the reduction of the quad partials through LDS.  More quads per thread spread the per-level work that does not depend
+// on the g-point (Planck functions of the level, fraction rows, layer flags, loads of temperatures, loop control: ~40 % of a clear
+// level's instructions at G = 1) over more g-points and give the wave more independent recurrences to overlap; they cost registers
+// (2 per g-point for the clear-sky sweep, 8-10 in the cloudy ones).
+#ifndef RRLW_SWEEP_G_CLEAR
+#define RRLW_SWEEP_G_CLEAR 0      // MODE 0: 0 = all quads of the band in one thread (32 state registers for 16 g-points)
+#endif
+#ifndef RRLW_SWEEP_G_CLOUD
+#define RRLW_SWEEP_G_CLOUD 1      // cloudy modes: quads per thread where it divides NQ
+#endif
+__host__ __device__ constexpr int sweep_g(int NQ, int MODE, bool IDRV)
 {
+    const int want = MODE == 0 ? (RRLW_SWEEP_G_CLEAR == 0 ? NQ : RRLW_SWEEP_G_CLEAR) : RRLW_SWEEP_G_CLOUD;
+    (void)IDRV;
+    return (want >= 1 && want <= NQ && NQ % want == 0) ? want : 1;
+}
+__host__ __device__ constexpr int sweep_t(int NQ, int MODE, bool IDRV) { return NQ / sweep_g(NQ, MODE, IDRV); }
+#ifndef RRLW_SWEEP_WAVES_CLEAR_G
+#define RRLW_SWEEP_WAVES_CLEAR_G 4   // MODE 0 with more than one quad per thread
+#endif
+#ifndef RRLW_SWEEP_WAVES_CLOUD_G
+#define RRLW_SWEEP_WAVES_CLOUD_G 2   // cloudy modes with more than one quad per thread
+#endif
+__host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV, int G = 1)
+{
+    if (G > 1) return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR_G : RRLW_SWEEP_WAVES_CLOUD_G;
     if (IDRV) return MODE == 0 ? 4 : 2;       // the d(flux)/dT instantiations carry 32 more registers (clear sky 100-106; rtrnmr spills 170 dwords at 168)
     return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
            MODE == 3 ? RRLW_SWEEP_WAVES_MCARR : RRLW_SWEEP_WAVES_MCMASK;
@@ -1725,14 +1758,16 @@ __host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV)
 // 4 x sweep_waves wave slots the kernel is compiled for
 __host__ __device__ constexpr int sweep_ns(int NQ, int MODE, bool IDRV)
 {
-    const int waves = 4 * sweep_waves(MODE, IDRV);         // per workgroup = per CU
-    return NQ == 3 ? (waves / 3 > 1 ? waves / 3 : 1) : waves / NQ;     // (3-quad bands: 12 of 12, 15 of 16 or 6 of 8 wave slots)
+    const int waves = 4 * sweep_waves(MODE, IDRV, sweep_g(NQ, MODE, IDRV));         // per workgroup = per CU
+    const int T = sweep_t(NQ, MODE, IDRV);
+    return T == 3 ? (waves / 3 > 1 ? waves / 3 : 1) : waves / T;     // (3 threads per band: 12 of 12, 15 of 16 or 6 of 8 wave slots)
 }
 // dynamic LDS of k_sweep<., NQ>: transmittance table (float pairs), Planck rows, fraction rows, reduction buffer
 constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8, SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
 __host__ __device__ constexpr int sweep_lds_bytes(int NQ, int MODE, bool IDRV)
 {
-    return SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES + (NQ > 1 ? sweep_ns(NQ, MODE, IDRV) * NQ * SWEEP_LV * 64 * 16 : 0);
+    const int T = sweep_t(NQ, MODE, IDRV);
+    return SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES + (T > 1 ? sweep_ns(NQ, MODE, IDRV) * T * SWEEP_LV * 64 * 16 : 0);
 }
 
 // Loads of k_sweep: wave-uniform base pointer in a buffer descriptor (scalar registers), per-lane 32-bit byte offset that does not
@@ -1833,12 +1868,49 @@ __device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool 
     return OvlFac{clr1, cld1, cmb1, cmb2, clr2, cld2, r1, r2};
 }
 
-struct SweepLev { scr4 c, ct; double tl, tz, cf, cfn; unsigned w; };     // one level's prefetched inputs
+// LDS tables of a sweep workgroup (one band): the transmittance table as float pairs {1 - exp, tfn}, the band's row of totplnk (and band
+// 16's, for the istart = 16 variant of setcoef :233-246), its Planck-fraction rows (0-8 fracrefa, 9-13 fracrefb, 14-15 zeros).  Ends
+// with a barrier.
+__device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned char *smem, int B, bool alt16, bool lo_bin, bool up_bin, int tid, int nth)
+{
+    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);
+    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);
+    const double2 *src = reinterpret_cast<const double2 *>(T.stat + T.sl.lutf);
+    double2 *dst = reinterpret_cast<double2 *>(smem);
+    // (loads first, then the LDS writes, eight at a time: a plain copy loop waits for every load before it issues the next)
+    constexpr int NLUT = SWEEP_LUT_BYTES / 16;
+    for (int i0 = tid; i0 < NLUT; i0 += 8 * nth) {
+        double2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[min(i0 + k * nth, NLUT - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (i0 + k * nth < NLUT) dst[i0 + k * nth] = v[k];
+    }
+    const double *tp = alt16 ? T.stat + T.sl.totplk16 : T.stat + T.sl.totplnk + 181 * (B - 1);
+    const double *tq = T.stat + T.sl.totplnk + 181 * 15;
+    for (int i = tid; i < 181; i += nth) { s_pl[0][i] = tp[i]; s_pl[1][i] = tq[i]; }
+    const int ng = T.band[B - 1].ng, fa = T.band[B - 1].fracrefa, fb = T.band[B - 1].fracrefb;
+    const int na = lo_bin ? 9 : 1, nb = up_bin ? 5 : 1;
+    for (int i = tid; i < 16 * 16; i += nth) {
+        const int r = i >> 4, g = i & 15;
+        double v = 0.0;
+        if (g < ng) {
+            if (r < 9) { if (r < na) v = T.ktab[fa + r * ng + g]; }
+            else if (r < 14 && fb >= 0 && r - 9 < nb) v = T.ktab[fb + (r - 9) * ng + g];
+        }
+        s_fr[r][g] = v;
+    }
+    __syncthreads();
+}
+
+template <int G> struct SweepLev { scr4 c[G], ct[G]; double tl, tz, cf, cfn; unsigned w; };     // one level's prefetched inputs (G quads of codes)
 
 template <int MODE, int NQ, bool IDRV>
-__global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MODE, IDRV)) void k_sweep(DevTables T, Workspace W, SweepArgs a)
+__global__ __launch_bounds__(64 * sweep_t(NQ, MODE, IDRV) * sweep_ns(NQ, MODE, IDRV), sweep_waves(MODE, IDRV, sweep_g(NQ, MODE, IDRV)))
+void k_sweep(DevTables T, Workspace W, SweepArgs a)
 {
-    constexpr int NGC = 4;
+    constexpr int G = sweep_g(NQ, MODE, IDRV), NT = sweep_t(NQ, MODE, IDRV);      // quads per thread, threads (waves) per band and column block
+    constexpr int NGC = 4 * G;
     constexpr int LV = SWEEP_LV, PF = sweep_pf(MODE, IDRV);
     static_assert(LV % PF == 0, "prefetch slots");
     constexpr int NS = sweep_ns(NQ, MODE, IDRV);
@@ -1860,7 +1932,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);              // [0] this band's Planck integrals, [1] band 16's (istart = 16 quirk)
     double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);   // Planck fractions: rows 0-8 fracrefa, 9-13 fracrefb, 14-15 zeros
     const int tx = threadIdx.x, slot = threadIdx.y, sub = threadIdx.z;
-    Part2 *red = reinterpret_cast<Part2 *>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES) + (size_t)sub * NQ * LV * 64;   // [slot][level-in-round][column]
+    Part2 *red = reinterpret_cast<Part2 *>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES) + (size_t)sub * NT * LV * 64;   // [slot][level-in-round][column]
     // Workgroup -> (column block, band).  Consecutive workgroup ids go round the 8 XCDs (each with its own L2), and the bands of one
     // column block read the same temperatures, flags and cloud fractions: ids that share an XCD (same id % 8) walk the bands of one
     // column block before they move to the next block, so those re-reads hit that XCD's L2 instead of HBM.
@@ -1872,7 +1944,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     if (B < a.istart || B > a.iend) return;         // uniform over the workgroup
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;      // lanes past the end shadow the last column
-    const int quad = band_qstart(B) + slot;
+    const int quad = band_qstart(B) + slot * G;        // first of this thread's G quads
     const size_t gc = (size_t)a.col0 + colc;
     const int nlay = W.nlay, nct = a.nct;
     const size_t ncb = W.ncolb;
@@ -1882,39 +1954,12 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
     const bool any_bin = lo_bin || up_bin;
     const int base_up = ((UP_ZERO >> (B - 1)) & 1u) ? 14 : (((UP_FROM_A >> (B - 1)) & 1u) ? 0 : 9);     // first fracs row of the upper atmosphere
-    {   // stage the tables
-        const int tid = (sub * NQ + slot) * 64 + tx, nth = 64 * NQ * NS;
-        const double2 *src = reinterpret_cast<const double2 *>(T.stat + T.sl.lutf);
-        double2 *dst = reinterpret_cast<double2 *>(smem);
-        // (loads first, then the LDS writes, eight at a time: a plain copy loop waits for every load before it issues the next)
-        constexpr int NLUT = SWEEP_LUT_BYTES / 16;
-        for (int i0 = tid; i0 < NLUT; i0 += 8 * nth) {
-            double2 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = src[min(i0 + k * nth, NLUT - 1)];
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (i0 + k * nth < NLUT) dst[i0 + k * nth] = v[k];
-        }
-        const double *tp = alt16 ? T.stat + T.sl.totplk16 : T.stat + T.sl.totplnk + 181 * (B - 1);
-        const double *tq = T.stat + T.sl.totplnk + 181 * 15;
-        for (int i = tid; i < 181; i += nth) { s_pl[0][i] = tp[i]; s_pl[1][i] = tq[i]; }
-        const int ng = T.band[B - 1].ng, fa = T.band[B - 1].fracrefa, fb = T.band[B - 1].fracrefb;
-        const int na = lo_bin ? 9 : 1, nb = up_bin ? 5 : 1;
-        for (int i = tid; i < 16 * 16; i += nth) {
-            const int r = i >> 4, g = i & 15;
-            double v = 0.0;
-            if (g < ng) {
-                if (r < 9) { if (r < na) v = T.ktab[fa + r * ng + g]; }
-                else if (r < 14 && fb >= 0 && r - 9 < nb) v = T.ktab[fb + (r - 9) * ng + g];
-            }
-            s_fr[r][g] = v;
-        }
-        __syncthreads();
-    }
+    sweep_stage_tables(T, smem, B, alt16, lo_bin, up_bin, (sub * NT + slot) * 64 + tx, 64 * NT * NS);
     // wave-uniform bases (the quad index is uniform over a wave: one wave = 64 columns of one quad) and per-lane byte offsets
     const int uquad = __builtin_amdgcn_readfirstlane(quad);
-    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)uquad * nlay * ncb;
-    const scr4 *__restrict__ sCt = reinterpret_cast<const scr4 *>(W.scr[S_CODET]) + (size_t)uquad * nlay * ncb;
+    const size_t qstride = (size_t)nlay * ncb;            // scr4 cells between consecutive quads
+    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)uquad * qstride;
+    const scr4 *__restrict__ sCt = reinterpret_cast<const scr4 *>(W.scr[S_CODET]) + (size_t)uquad * qstride;
     const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
     const int *__restrict__ sFlag = W.cflag;
     const double *__restrict__ tlay = a.tlay + a.col0;
@@ -1926,27 +1971,33 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
     const int laytrop = W.laytrop[colc];
     const double *tp0 = s_pl[0], *tp1 = s_pl[1];
+    // The cloudy modes sweep only the layers 1 .. ltop, ltop = the highest layer of the batch that holds cloud in any column: above it
+    // k_sweepc<., 1> (downward) and k_sweepc<., 2> (upward) run the clear-sky recurrences with all g-points of a band in one thread, and
+    // the radiances at level ltop are handed over through W.hand.
+    const int ltop = MODE == 0 ? nlay : __builtin_amdgcn_readfirstlane(*W.ltop);
+    // W.hand as double2: [stream][quad][column][2]
+    auto hand_ptr = [&]() -> double2 * { return reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2; };
 
     // adds the round's partials of the band's quads in quad order; wave `slot` finishes levels lev0 + dir * (slot, slot + NQ, ..)
     auto reduce_store = [&](const Part2 (&acc)[LV], Part2 *__restrict__ dst, int lev0, int dir) {
-        if constexpr (NQ == 1) {
+        if constexpr (NT == 1) {
 #pragma unroll
             for (int i = 0; i < LV; i++) {
                 const int lv = lev0 + dir * i;
-                if (incol && lv >= 0 && lv <= nlay) dst[(size_t)lv * ncb] = acc[i];
+                if (incol && lv >= 0 && lv <= ltop) dst[(size_t)lv * ncb] = acc[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < LV; i++) red[(slot * LV + i) * 64 + tx] = acc[i];
             __syncthreads();
 #pragma unroll
-            for (int i0 = 0; i0 < LV; i0 += NQ) {
+            for (int i0 = 0; i0 < LV; i0 += NT) {
                 const int i = i0 + slot;
                 const int lv = lev0 + dir * i;
-                if (i < LV && incol && lv >= 0 && lv <= nlay) {
+                if (i < LV && incol && lv >= 0 && lv <= ltop) {
                     Part2 sum = red[i * 64 + tx];
 #pragma unroll
-                    for (int q = 1; q < NQ; q++) {
+                    for (int q = 1; q < NT; q++) {
                         const Part2 v = red[(q * LV + i) * 64 + tx];
                         sum.a = sum.a + v.a;
                         sum.b = sum.b + v.b;
@@ -1960,20 +2011,20 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 
     // a level's partial goes straight to the reduction buffer (or, for a one-quad band, to memory): nothing is held across the round
     auto put_part = [&](int i, int lv, const Part2 &v, Part2 *__restrict__ dst) {
-        if constexpr (NQ == 1) { if (incol) dst[(size_t)lv * ncb] = v; }
+        if constexpr (NT == 1) { if (incol) dst[(size_t)lv * ncb] = v; }
         else red[(slot * LV + i) * 64 + tx] = v;
     };
     auto reduce_round = [&](Part2 *__restrict__ dst, int lev0, int dir) {
-        if constexpr (NQ > 1) {
+        if constexpr (NT > 1) {
             __syncthreads();
 #pragma unroll
-            for (int i0 = 0; i0 < LV; i0 += NQ) {
+            for (int i0 = 0; i0 < LV; i0 += NT) {
                 const int i = i0 + slot;
                 const int lv = lev0 + dir * i;
-                if (i < LV && incol && lv >= 0 && lv <= nlay) {
+                if (i < LV && incol && lv >= 0 && lv <= ltop) {
                     Part2 sum = red[i * 64 + tx];
 #pragma unroll
-                    for (int q = 1; q < NQ; q++) {
+                    for (int q = 1; q < NT; q++) {
                         const Part2 v = red[(q * LV + i) * 64 + tx];
                         sum.a = sum.a + v.a;
                         sum.b = sum.b + v.b;
@@ -1985,13 +2036,13 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
         }
     };
 
-    // MODE 4: the four sub-column mask bits of this thread's quad in layer `lev` (bits of padding g-points cleared)
+    // MODE 4: the sub-column mask bits of this thread's NGC g-points in layer `lev` (bits of padding g-points cleared)
     auto quad_bits = [&](int lev) -> unsigned {
-        const int ig0 = band_g0(B) + 4 * slot, w0 = ig0 >> 5;
-        const int nvalid = min(4, band_ng(B) - 4 * slot);
+        const int ig0 = band_g0(B) + NGC * slot, w0 = ig0 >> 5;
+        const int nvalid = max(0, min(NGC, band_ng(B) - NGC * slot));
         const size_t mo = (size_t)(lev - 1) * W.mask_stride + W.mask_col0 + gc;
         const unsigned long long lo = W.mask[(size_t)w0 * nlay * W.mask_stride + mo];
-        const unsigned long long hi = (w0 < 4 && (ig0 & 31) > 28) ? W.mask[(size_t)(w0 + 1) * nlay * W.mask_stride + mo] : 0u;
+        const unsigned long long hi = (w0 < 4 && (ig0 & 31) + NGC > 32) ? W.mask[(size_t)(w0 + 1) * nlay * W.mask_stride + mo] : 0u;
         return (unsigned)(((lo | (hi << 32)) >> (ig0 & 31)) & ((1u << nvalid) - 1u));
     };
 
@@ -2003,11 +2054,11 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
             const unsigned w = (lower ? lo_bin : up_bin) ? fwv : 0x10000000u;
             const int r0 = clampi((lower ? 0 : base_up) + (int)(w >> 28) - 1, 0, 14);
             const double fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
-            const double *row = &s_fr[r0][4 * slot];
+            const double *row = &s_fr[r0][NGC * slot];
 #pragma unroll
             for (int j = 0; j < NGC; j++) fr[j] = row[j] + fpl * (row[16 + j] - row[j]);
         } else {
-            const double *row = &s_fr[lower ? 0 : base_up][4 * slot];
+            const double *row = &s_fr[lower ? 0 : base_up][NGC * slot];
 #pragma unroll
             for (int j = 0; j < NGC; j++) fr[j] = row[j];
         }
@@ -2023,20 +2074,24 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     // direction; cloudy = the level's flag (known a round earlier) selects the extra loads of a cloudy level
     // part 1: what a level consumes first (codes, temperatures, fraction word), part 2: what only a cloudy level's recurrence needs;
     // 3 = both.  A slot's first part is refilled as soon as the level has decoded it, half a level before the second.
-    auto fill = [&](int lev, int zlev, int nlev, unsigned flagword, SweepLev &q, int part) {
+    auto fill = [&](int lev, int zlev, int nlev, unsigned flagword, SweepLev<G> &q, int part) {
         const bool cloudy = (flagword & 1u) != 0u;
         if (part & 1) q.w = 0u;
         if (lev >= 1 && lev <= nlay) {                         // uniform
             const size_t so = (size_t)(lev - 1) * ncb;
             if (part & 1) {
-                if (!CODES2) q.c = bload_scr4_nt(sC + so, off16);
+                if (!CODES2) {
+#pragma unroll
+                    for (int k = 0; k < G; k++) q.c[k] = bload_scr4_nt(sC + k * qstride + so, off16);
+                }
                 q.tl = bload_f64(tlay + (size_t)nct * (lev - 1), off8);
                 q.tz = bload_f64(tlev + (size_t)nct * zlev, off8);
                 if (any_bin) q.w = bload_u32(sFw + so, off4);
             }
             if constexpr (MODE != 0) {
                 if ((part & 2) && cloudy) {
-                    q.ct = bload_scr4_nt(sCt + so, off16);
+#pragma unroll
+                    for (int k = 0; k < G; k++) q.ct[k] = bload_scr4_nt(sCt + k * qstride + so, off16);
                     if constexpr (MODE == 1 || MODE == 2) q.cf = bload_f64(cldf + (size_t)nct * (lev - 1), off8);
                     if constexpr (MODE == 2) q.cfn = (nlev >= 1 && nlev <= nlay) ? bload_f64(cldf + (size_t)nct * (nlev - 1), off8) : 0.0;
                 }
@@ -2051,35 +2106,52 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
     for (int j = 0; j < NGC; j++) { radld[j] = 0.0; radclrd[j] = 0.0; cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
     bool iclddn = false;
-    if (slot == 0 && incol) {   // downward flux at the top level is zero
-        Part2 z{0.0, 0.0};
-        pdn[(size_t)nlay * ncb] = z;
+    if constexpr (MODE == 0) {
+        if (slot == 0 && incol) {   // downward flux at the top level is zero
+            Part2 z{0.0, 0.0};
+            pdn[(size_t)nlay * ncb] = z;
+        }
+    } else {                        // downward radiances at level ltop from k_sweepc<., 1> (zeros when ltop = nlay); clear = total up there
+        const double2 *hand = hand_ptr();
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const double2 h0 = hand[(size_t)k * ncb * 2], h1 = hand[(size_t)k * ncb * 2 + 1];
+            radld[4 * k] = h0.x; radld[4 * k + 1] = h0.y; radld[4 * k + 2] = h1.x; radld[4 * k + 3] = h1.y;
+        }
+#pragma unroll
+        for (int j = 0; j < NGC; j++) radclrd[j] = radld[j];
     }
 
     // ------------------------------------------------------------------ downward sweep, SWEEP_LV levels per round
     // Rolling prefetch: the loads of a level are issued SWEEP_LV levels before it is processed (into the slot of the level just
     // consumed), its cloud flag 2 x SWEEP_LV levels before, so that the conditional loads of a cloudy level are part of the prefetch.
-    SweepLev p[PF];
-    scr4 cq[2];                          // CODES2: gas codes of the next two levels
-    auto ldcodes = [&](int lev) -> scr4 {
-        scr4 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
-        return (lev >= 1 && lev <= nlay) ? bload_scr4_nt(sC + (size_t)(lev - 1) * ncb, off16) : z;
+    SweepLev<G> p[PF];
+    struct CodesG { scr4 q[G]; };
+    CodesG cq[2];                        // CODES2: gas codes of the next two levels
+    auto ldcodes = [&](int lev) -> CodesG {
+        CodesG r;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            scr4 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
+            r.q[k] = (lev >= 1 && lev <= nlay) ? bload_scr4_nt(sC + k * qstride + (size_t)(lev - 1) * ncb, off16) : z;
+        }
+        return r;
     };
     unsigned fl[2][PF];
 #pragma unroll
-    for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(nlay - i); fl[1][i] = ldflag(nlay - PF - i); }
+    for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(ltop - i); fl[1][i] = ldflag(ltop - PF - i); }
 #pragma unroll
-    for (int i = 0; i < PF; i++) fill(nlay - i, nlay - i - 1, nlay - i - 1, fl[0][i], p[i], 3);
-    if constexpr (CODES2) { cq[0] = ldcodes(nlay); cq[1] = ldcodes(nlay - 1); }
+    for (int i = 0; i < PF; i++) fill(ltop - i, ltop - i - 1, ltop - i - 1, fl[0][i], p[i], 3);
+    if constexpr (CODES2) { cq[0] = ldcodes(ltop); cq[1] = ldcodes(ltop - 1); }
     bool prevcld = false;                // the previous level of the sweep was cloudy (istcldd(lev) == 0)
     double cfprev = 0.0;
     bool rat1 = false, rat2 = false;
-    for (int top = nlay; top >= 1; top -= LV) {
+    for (int top = ltop; top >= 1; top -= LV) {
 #pragma unroll
         for (int i = 0; i < LV; i++) {
             const int lev = top - i;
             const int s = i % PF;
-            const SweepLev &cur = p[s];
+            const SweepLev<G> &cur = p[s];
             const bool cloudy = (fl[0][s] & 1u) != 0u;
             // the slot is refilled (level lev - PF) once this level has consumed it
             auto advance_early = [&]() { if constexpr (EARLY) fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[1][s], p[s], 1); };
@@ -2096,7 +2168,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
                 double tfn;
-                const scr_t cj = CODES2 ? cq[i & 1].v[j] : cur.c.v[j];
+                const scr_t cj = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
                 decode(cj, s_lut[code_index(cj)], atr[j], tfn);
                 bbd[j] = fr[j] * (blay + tfn * dplankdn);
             }
@@ -2130,12 +2202,17 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                         prevcld = true;
                         cfprev = cf;
                     }
-                    double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
+                    double cfj[NGC], efj[NGC];
+#pragma unroll
+                    for (int j = 0; j < NGC; j++) { cfj[j] = cf; efj[j] = efcl; }
                     if constexpr (MODE == 3) {          // rtrnmc: cloud fraction and effective emissivity per g-point
-                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + colc) * 8);
-                        const float4 c4 = pc[0], e4 = pc[1];
-                        cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
-                        efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
+#pragma unroll
+                        for (int k = 0; k < G; k++) {
+                            const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)(quad + k) * nlay + (lev - 1)) * ncb + colc) * 8);
+                            const float4 c4 = pc[0], e4 = pc[1];
+                            cfj[4 * k] = c4.x; cfj[4 * k + 1] = c4.y; cfj[4 * k + 2] = c4.z; cfj[4 * k + 3] = c4.w;
+                            efj[4 * k] = e4.x; efj[4 * k + 1] = e4.y; efj[4 * k + 2] = e4.z; efj[4 * k + 3] = e4.w;
+                        }
                     }
                     if constexpr (MODE == 4) {
                         const unsigned bits = quad_bits(lev);
@@ -2146,7 +2223,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
                         double atot, tftot;
-                        decode(cur.ct.v[j], s_lut[code_index(cur.ct.v[j])], atot, tftot);
+                        decode(cur.ct[j / 4].v[j % 4], s_lut[code_index(cur.ct[j / 4].v[j % 4])], atot, tftot);
                         const double bbdtot = fr[j] * (blay + tftot * dplankdn);
                         const double gassrc = bbd[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
@@ -2218,14 +2295,14 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
     for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i], 3);
     if constexpr (CODES2) { cq[0] = ldcodes(0); cq[1] = ldcodes(1); }
     prevcld = false; cfprev = 0.0; rat1 = false; rat2 = false;
-    for (int base = 0; base <= nlay; base += LV) {
+    for (int base = 0; base <= ltop; base += LV) {
         Part2 accd[idrv ? LV : 1];
 #pragma unroll
         for (int i = 0; i < LV; i++) {
             const int lev = base + i;
             if constexpr (idrv) accd[i] = Part2{0.0, 0.0};
             const int s = i % PF;
-            const SweepLev &cur = p[s];
+            const SweepLev<G> &cur = p[s];
             const bool cloudy = (fl[0][s] & 1u) != 0u;
             auto advance_early = [&]() { if constexpr (EARLY) fill(lev + PF, lev + PF, lev + PF + 1, fl[1][s], p[s], 1); };
             auto advance = [&]() {
@@ -2233,7 +2310,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                 fill(lev + PF, lev + PF, lev + PF + 1, fl[0][s], p[s], EARLY ? 2 : 3);
                 fl[1][s] = ldflag(lev + 2 * PF);
             };
-            if (lev > nlay) { advance_early(); advance(); continue; }                            // uniform
+            if (lev > ltop) { advance_early(); advance(); continue; }                            // uniform
             if (lev == 0) {                                                     // uniform
                 put_part(i, 0, surf, pup);
                 if constexpr (idrv) accd[i] = dsurf;
@@ -2249,7 +2326,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
                 double tfn;
-                const scr_t cj = CODES2 ? cq[i & 1].v[j] : cur.c.v[j];
+                const scr_t cj = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
                 decode(cj, s_lut[code_index(cj)], atr[j], tfn);
                 bbu[j] = fr[j] * (blay + tfn * dplankup);
             }
@@ -2284,12 +2361,17 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
                         prevcld = true;
                         cfprev = cf;
                     }
-                    double cfj[NGC] = {cf, cf, cf, cf}, efj[NGC] = {efcl, efcl, efcl, efcl};
+                    double cfj[NGC], efj[NGC];
+#pragma unroll
+                    for (int j = 0; j < NGC; j++) { cfj[j] = cf; efj[j] = efcl; }
                     if constexpr (MODE == 3) {
-                        const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)quad * nlay + (lev - 1)) * ncb + colc) * 8);
-                        const float4 c4 = pc[0], e4 = pc[1];
-                        cfj[0] = c4.x; cfj[1] = c4.y; cfj[2] = c4.z; cfj[3] = c4.w;
-                        efj[0] = e4.x; efj[1] = e4.y; efj[2] = e4.z; efj[3] = e4.w;
+#pragma unroll
+                        for (int k = 0; k < G; k++) {
+                            const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)(quad + k) * nlay + (lev - 1)) * ncb + colc) * 8);
+                            const float4 c4 = pc[0], e4 = pc[1];
+                            cfj[4 * k] = c4.x; cfj[4 * k + 1] = c4.y; cfj[4 * k + 2] = c4.z; cfj[4 * k + 3] = c4.w;
+                            efj[4 * k] = e4.x; efj[4 * k + 1] = e4.y; efj[4 * k + 2] = e4.z; efj[4 * k + 3] = e4.w;
+                        }
                     }
                     if constexpr (MODE == 4) {
                         const unsigned bits = quad_bits(lev);
@@ -2300,7 +2382,7 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
                         double atot, tftot;
-                        decode(cur.ct.v[j], s_lut[code_index(cur.ct.v[j])], atot, tftot);
+                        decode(cur.ct[j / 4].v[j % 4], s_lut[code_index(cur.ct[j / 4].v[j % 4])], atot, tftot);
                         const double bbutot = fr[j] * (blay + tftot * dplankup);
                         const double gassrc = bbu[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
@@ -2341,6 +2423,275 @@ __global__ __launch_bounds__(64 * NQ * sweep_ns(NQ, MODE, IDRV), sweep_waves(MOD
         }
         reduce_round(pup, base, +1);
         if constexpr (idrv) reduce_store(accd, dbase, base, +1);
+    }
+    if constexpr (MODE != 0) {          // upward radiances at level ltop for k_sweepc<., 2>
+        if (incol) {
+            double2 *hand = hand_ptr();
+            const size_t hstream = (size_t)NQUAD * ncb * 2;
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                double2 *h = hand + (size_t)k * ncb * 2;
+                h[hstream] = make_double2(radlu[4 * k], radlu[4 * k + 1]);          h[hstream + 1] = make_double2(radlu[4 * k + 2], radlu[4 * k + 3]);
+                h[2 * hstream] = make_double2(radclru[4 * k], radclru[4 * k + 1]);  h[2 * hstream + 1] = make_double2(radclru[4 * k + 2], radclru[4 * k + 3]);
+                if constexpr (idrv) {
+                    h[3 * hstream] = make_double2(drad[4 * k], drad[4 * k + 1]);    h[3 * hstream + 1] = make_double2(drad[4 * k + 2], drad[4 * k + 3]);
+                    h[4 * hstream] = make_double2(dradc[4 * k], dradc[4 * k + 1]);  h[4 * hstream + 1] = make_double2(dradc[4 * k + 2], dradc[4 * k + 3]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sweepc : the clear-sky recurrences (src/rrtmg_lw_rtrn.f90:437-466 downward, :497-540 upward; identical in rtrnmr / rtrnmc) with
+//            ALL g-points of a band in one thread: one thread = (column, band), no reduction across threads.  The work of a level that
+//            does not depend on the g-point (two Planck interpolations, fraction-row selection, the loads of temperatures and codes,
+//            loop control) is done once for up to 16 g-points instead of once per quad, and the wave has up to 16 independent
+//            recurrences in flight.
+//   PHASE 0  the whole column of a cloud-free call (icld = 0): downward, surface (rtrn :476-495), upward
+//   PHASE 1  layers ltop+1 .. nlay downward, for the cloudy modes: above the highest cloud of the batch (W.ltop) every column is clear and
+//            the clear-sky stream equals the total one; the radiances at level ltop go to k_sweep<1..4> through W.hand
+//   PHASE 2  layers ltop+1 .. nlay upward, total and clear-sky streams, starting from the radiances k_sweep<1..4> left in W.hand
+// ------------------------------------------------------------------------------------------------
+// waves per SIMD each instantiation is compiled for = what its registers allow without spilling (a spilled register is reloaded with a
+// scratch load, which counts as a vector-memory operation: its wait drains every prefetch in flight), at most 4 (one workgroup of
+// <= 1024 threads per CU: the transmittance table takes half of the LDS).  Register needs, unconstrained, by quads per thread 4 / 3 / 2 / 1:
+//   phase 1                       160 124  96  70
+//   phase 0                       198 154 116  76
+//   phase 2, phase 0 with d/dT    232 190 144  94
+//   phase 2 with d/dT             256 256 208 124
+#ifndef RRLW_SWEEPC_WAVES_CAP
+#define RRLW_SWEEPC_WAVES_CAP 4
+#endif
+__host__ __device__ constexpr int sweepc_waves(int NQ, int PHASE, bool IDRV)
+{
+    const int row = PHASE == 1 ? 0 : (PHASE == 0 && !IDRV) ? 1 : (PHASE == 2 && IDRV) ? 3 : 2;
+    const int tab[4][4] = {{7, 5, 4, 3}, {6, 4, 3, 2}, {5, 3, 2, 2}, {4, 2, 1, 1}};      // [row][NQ - 1]
+    const int w = tab[row][NQ - 1];
+    return w < RRLW_SWEEPC_WAVES_CAP ? w : RRLW_SWEEPC_WAVES_CAP;
+}
+__host__ __device__ constexpr int sweepc_ns(int NQ, int PHASE, bool IDRV) { return 4 * sweepc_waves(NQ, PHASE, IDRV); }      // waves (64-column blocks) per workgroup = per CU
+constexpr int SWEEPC_LDS_BYTES = SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES;
+#ifndef RRLW_SWEEPC_QUAD_BARRIER
+#define RRLW_SWEEPC_QUAD_BARRIER 0   // 1: keep the quads of a level apart in the instruction schedule (fewer registers, less overlap; measured slower)
+#endif
+#ifndef RRLW_SWEEPC_CODES
+#define RRLW_SWEEPC_CODES 2       // code slots: levels of cell codes in flight (the codes are the one HBM stream of the sweep; 4 registers per quad and slot)
+#endif
+
+// One slot of the rolling prefetch.  Every load is issued on every path (rows clamped to 1 .. nlay instead of skipped): the compiler can
+// then count the loads in flight behind the one it needs and wait with vmcnt(N) instead of vmcnt(0) - vector-memory operations complete
+// in order, so a wait for everything would stall the wave on the codes it has just requested for the next level.
+template <int G> struct SweepcLev { double tl, tz; unsigned w; };
+
+template <int NQ, int PHASE, bool IDRV>
+__global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, PHASE, IDRV)) void k_sweepc(DevTables T, Workspace W, SweepArgs a)
+{
+    constexpr int G = NQ, NG = 4 * G, NS = sweepc_ns(NQ, PHASE, IDRV), NC = RRLW_SWEEPC_CODES;
+    constexpr bool DOWN = PHASE != 2, UP = PHASE != 1, TWO = PHASE == 2;       // TWO: total and clear-sky streams differ
+    extern __shared__ __align__(16) unsigned char smem[];
+    const float2 *s_lut = reinterpret_cast<const float2 *>(smem);
+    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);
+    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);
+    const int tx = threadIdx.x, sub = threadIdx.z;
+    const int wq = blockIdx.x >> 3;                                            // (workgroup -> (column block, band) as in k_sweep: XCD-aware)
+    const int cblock = (wq / a.nbands) * 8 + (blockIdx.x & 7);
+    if (cblock >= a.ncb) return;
+    const int col = (cblock * NS + sub) * 64 + tx;
+    const int B = (int)((a.bands >> (4 * (wq % a.nbands))) & 15ull) + 1;
+    if (B < a.istart || B > a.iend) return;
+    const bool incol = col < a.ncol;
+    const int colc = incol ? col : a.ncol - 1;
+    const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B));
+    const size_t gc = (size_t)a.col0 + colc;
+    const int nlay = W.nlay, nct = a.nct;
+    const size_t ncb = W.ncolb;
+    const double wtdelw = T.delwave[B - 1];
+    const bool alt16 = (B == 16 && a.istart == 16);
+    const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
+    const bool any_bin = lo_bin || up_bin;
+    const int base_up = ((UP_ZERO >> (B - 1)) & 1u) ? 14 : (((UP_FROM_A >> (B - 1)) & 1u) ? 0 : 9);
+    sweep_stage_tables(T, smem, B, alt16, lo_bin, up_bin, sub * 64 + tx, 64 * NS);
+    const int lo = PHASE == 0 ? 1 : __builtin_amdgcn_readfirstlane(*W.ltop) + 1;       // layers lo .. nlay
+    const size_t qstride = (size_t)nlay * ncb;
+    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)quad * qstride;
+    const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
+    const double *__restrict__ tlay = a.tlay + a.col0;
+    const double *__restrict__ tlev = a.tlev + a.col0;
+    const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
+    Part2 *__restrict__ pdn = W.pdn + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    Part2 *__restrict__ pup = W.pup + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    const int laytrop = W.laytrop[colc];
+    const double *tp0 = s_pl[0], *tp1 = s_pl[1];
+    double2 *hand = reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2;      // [stream][quad][column][2]
+    const size_t hstream = (size_t)NQUAD * ncb * 2;
+
+    // loads of layer `lev` (any integer: rows outside 1 .. nlay are clamped, their values never used); zoff selects the interface whose
+    // temperature the sweep direction needs: 0 = level lev - 1 (below the layer, downward sweep), 1 = level lev (above, upward sweep)
+    auto fill_t = [&](auto bin_tag, int lev, int zoff, SweepcLev<G> &q) {
+        const int l = min(max(lev, 1), nlay);
+        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8);
+        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8);
+        if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
+    };
+    auto ld_c = [&](int lev, int k) -> scr4 {
+        const int l = min(max(lev, 1), nlay);
+        return bload_scr4_nt(sC + k * qstride + (size_t)(l - 1) * ncb, off16);
+    };
+    // fraction rows of layer `lev`: first row and interpolation weight (taumol :556-561, :692-693)
+    auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
+        const bool lower = lev <= laytrop;
+        if (any_bin) {          // uniform
+            const unsigned w = (lower ? lo_bin : up_bin) ? fwv : 0x10000000u;
+            const int r0 = clampi((lower ? 0 : base_up) + (int)(w >> 28) - 1, 0, 14);
+            fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
+            return &s_fr[r0][0];
+        }
+        fpl = 0.0;
+        return &s_fr[lower ? 0 : base_up][0];
+    };
+
+    double rad[NG], radc[TWO ? NG : 1], drad[IDRV ? NG : 1], dradc[(IDRV && TWO) ? NG : 1];
+#pragma unroll
+    for (int j = 0; j < NG; j++) rad[j] = 0.0;
+
+    // One level: layer `lev`, its temperatures in `cur`, its codes in cc[.][lev % NC]; dir = -1 downward (Planck difference towards the
+    // interface below, partial of level lev - 1), +1 upward.  BIN: the band's Planck fractions are interpolated between two rows.
+    // The slot pieces are re-issued for level lev + NC * dir (codes) / lev + dir (temperatures) as soon as they have been consumed.
+    SweepcLev<G> cur;
+    cur.w = 0u;
+    scr4 cc[G][NC];
+    auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) {
+        constexpr bool BIN = decltype(bin_tag)::value, DN = decltype(dn_tag)::value;
+        constexpr int dir = DN ? -1 : 1;
+        double fpl;
+        const double *row = frac_row(lev, cur.w, fpl);
+        const double blay = planck_at(tp0, tp0, cur.tl);
+        const double dpl = planck_at(tp0, (DN && alt16 && lev == 1) ? tp1 : tp0, cur.tz) - blay;
+        fill_t(bin_tag, lev + dir, DN ? 0 : 1, cur);
+        double sum = 0.0, sumc = 0.0, dsum = 0.0, dsumc = 0.0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            float2 e[4];
+            scr4 ck;
+#pragma unroll
+            for (int c = 0; c < NC; c++) if (c == slot) ck = cc[k][c];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) e[jj] = s_lut[code_index(ck.v[jj])];
+            {
+                const scr4 nx = ld_c(lev + NC * dir, k);
+#pragma unroll
+                for (int c = 0; c < NC; c++) if (c == slot) cc[k][c] = nx;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * k + jj;
+                double atr, tfn;
+                decode(ck.v[jj], e[jj], atr, tfn);
+                double fr = row[j];
+                if constexpr (BIN) fr = fr + fpl * (row[16 + j] - fr);
+                const double bb = fr * (blay + tfn * dpl);
+                rad[j] = rad[j] + (bb - rad[j]) * atr;
+                sum = sum + rad[j];
+                if constexpr (TWO && !DN) { radc[j] = radc[j] + (bb - radc[j]) * atr; sumc = sumc + radc[j]; }
+                if constexpr (IDRV && !DN) {
+                    drad[j] = drad[j] * (1.0 - atr); dsum = dsum + drad[j];
+                    if constexpr (TWO) { dradc[j] = dradc[j] * (1.0 - atr); dsumc = dsumc + dradc[j]; }
+                }
+            }
+            if (RRLW_SWEEPC_QUAD_BARRIER) __builtin_amdgcn_sched_barrier(0);
+        }
+        const double v = (sum * 0.5) * wtdelw, vc = (TWO && !DN) ? (sumc * 0.5) * wtdelw : v;
+        if (incol) {
+            if constexpr (DN) pdn[(size_t)(lev - 1) * ncb] = Part2{v, vc};
+            else {
+                pup[(size_t)lev * ncb] = Part2{v, vc};
+                if constexpr (IDRV) {
+                    const double dv = ((dsum * 0.5) * wtdelw) * T.fluxfac, dvc = TWO ? ((dsumc * 0.5) * wtdelw) * T.fluxfac : dv;
+                    dbase[(size_t)lev * ncb] = Part2{dv, dvc};
+                }
+            }
+        }
+    };
+    auto sweep = [&](auto bin_tag, auto dn_tag) {
+        constexpr bool DN = decltype(dn_tag)::value;
+        constexpr int dir = DN ? -1 : 1;
+        const int first = DN ? nlay : lo, count = nlay - lo + 1;
+        // (issued in the order the steady state has them in flight at the top of a level - codes of the slots that are older than the
+        // level's temperatures, the temperatures, the youngest slot - so that the waits of the loop header can be counted ones)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (c == NC - 1) fill_t(bin_tag, first, DN ? 0 : 1, cur);
+#pragma unroll
+            for (int k = 0; k < G; k++) cc[k][c] = ld_c(first + c * dir, k);
+        }
+        int n = 0;
+        for (; n + NC <= count; n += NC) {          // whole groups of NC levels: a straight-line body (a skipped level inside the loop makes
+#pragma unroll                                      // the compiler rotate the slot registers through copies, which wait for every load)
+            for (int c = 0; c < NC; c++) level(bin_tag, dn_tag, first + (n + c) * dir, c);
+        }
+#pragma unroll
+        for (int c = 0; c < NC - 1; c++) {
+            if (n + c < count) level(bin_tag, dn_tag, first + (n + c) * dir, c);       // uniform
+        }
+    };
+    using std::true_type;
+    using std::false_type;
+
+    if constexpr (DOWN) {
+        // ------------------------------------------------------------------ downward: layers nlay .. lo
+        if (incol) pdn[(size_t)nlay * ncb] = Part2{0.0, 0.0};
+        if (any_bin) sweep(true_type{}, true_type{}); else sweep(false_type{}, true_type{});
+    }
+    if constexpr (PHASE == 1) {                     // downward radiances at level ltop for k_sweep<1..4>
+        if (incol) {
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                hand[(size_t)k * ncb * 2] = make_double2(rad[4 * k], rad[4 * k + 1]);
+                hand[(size_t)k * ncb * 2 + 1] = make_double2(rad[4 * k + 2], rad[4 * k + 3]);
+            }
+        }
+        return;
+    }
+
+    if constexpr (PHASE == 0) {
+        // ------------------------------------------------------------------ surface: rtrn :476-495
+        const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
+        const double pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + colc];
+        const double dpb = IDRV ? W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + colc] : 0.0;
+        double fpl;
+        const double *row = frac_row(1, any_bin ? bload_u32(sFw, off4) : 0u, fpl);        // the surface emits with the lowest layer's Planck fractions
+        double usum = 0.0, dusum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            const double fr = any_bin ? row[j] + fpl * (row[16 + j] - row[j]) : row[j];
+            rad[j] = fr * pb + reflect * rad[j];
+            usum = usum + rad[j];
+            if constexpr (IDRV) { drad[j] = fr * dpb; dusum = dusum + drad[j]; }
+        }
+        const double v = (usum * 0.5) * wtdelw, dv = ((dusum * 0.5) * wtdelw) * T.fluxfac;
+        if (incol) {
+            pup[0] = Part2{v, v};
+            if constexpr (IDRV) dbase[0] = Part2{dv, dv};
+        }
+    } else {                                        // upward radiances at level ltop from k_sweep<1..4>
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const double2 *h = hand + (size_t)k * ncb * 2;
+            const double2 a0 = h[hstream], a1 = h[hstream + 1], c0 = h[2 * hstream], c1 = h[2 * hstream + 1];
+            rad[4 * k] = a0.x; rad[4 * k + 1] = a0.y; rad[4 * k + 2] = a1.x; rad[4 * k + 3] = a1.y;
+            if constexpr (TWO) { radc[4 * k] = c0.x; radc[4 * k + 1] = c0.y; radc[4 * k + 2] = c1.x; radc[4 * k + 3] = c1.y; }
+            if constexpr (IDRV) {
+                const double2 d0 = h[3 * hstream], d1 = h[3 * hstream + 1], e0 = h[4 * hstream], e1 = h[4 * hstream + 1];
+                drad[4 * k] = d0.x; drad[4 * k + 1] = d0.y; drad[4 * k + 2] = d1.x; drad[4 * k + 3] = d1.y;
+                if constexpr (TWO) { dradc[4 * k] = e0.x; dradc[4 * k + 1] = e0.y; dradc[4 * k + 2] = e1.x; dradc[4 * k + 3] = e1.y; }
+            }
+        }
+    }
+    if constexpr (UP) {
+        // ------------------------------------------------------------------ upward: layers lo .. nlay
+        if (any_bin) sweep(true_type{}, false_type{}); else sweep(false_type{}, false_type{});
     }
 }
 
