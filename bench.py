@@ -9,10 +9,15 @@ all-gather of the packed flux/heating-rate block that reassembles the outputs on
 One JSON line is printed by rank 0.
 
 Extra objects in the line:
-  roofline      for the dominant kernel (largest total time among the kernels of the timed region), timed live with
-                HIP events on the launch stream; algorithmic bytes = 33.0 KB per column apportioned to a
-                band-chunk kernel by its share of the 140 g-points.
-  path          the same accounting for the whole step (all kernels).
+  roofline      HBM roofline of the PATH: algorithmic bytes of a step (33.0 KB per 72-layer column, SURVEY.md 8d, x columns per rank)
+                / the summed kernel time of the step, measured live with HIP events on the launch stream.  The dominant kernel
+                (largest total time) is reported inside it with ITS time share of those bytes - the whole column's bytes are not
+                attributed to one kernel - and the PMC-measured HBM traffic per launch where a summary is committed under profiles/.
+  compute       the instruction side ("so that the low HBM fraction is explained rather than hidden"): vector
+                lane-instructions per second of the step against the chip's issue peak, LDS bytes per second against the
+                ~150 TB/s the LDS arrays deliver; instruction and LDS counts per column come from the committed PMC pass
+                (profiles/pmc_compute.json), times from this run.
+  path          per-kernel milliseconds of a step.
   cpu_baseline  the reference's own Fortran (oracle/_ref, "reference") or the C port ("port") on the host cores,
                 measured before the GPU is touched, rank 0 at N=1 only.
 """
@@ -28,6 +33,8 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_COL_72 = 33.0e3      # 29.5 KB in + 3.5 KB out per 72-layer column (non-McICA API)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+VALU_PEAK_LANE_INSTR = 256 * 4 * 32 * 2.4e9      # 78.6e12: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (f32-class; f64 issues at half of it)
+LDS_PEAK_BYTES = 150e12             # MI355X_MICROARCH.md, LDS: ~150 TB/s aggregate for ds_read_b64 / b128
 
 
 def algo_bytes_per_col(nlay, idrv):
@@ -90,7 +97,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    api.rrtmg_lw_ini(1004.0, device=local_rank)
+    # (explicit choice of the coefficient file: the line's config.kdata says which one ran)
+    api.rrtmg_lw_ini(1004.0, kdata=api.REAL_KDATA if os.path.exists(api.REAL_KDATA) else api.STANDIN_KDATA, device=local_rank)
     if args.batch:
         api.set_batch(args.batch)
     if args.no_overlap:
@@ -98,9 +106,12 @@ def main():
     if args.overlap:
         api.set_overlap(True)
 
-    # contiguous column block of this rank
+    # contiguous column block of this rank.  Every rank works on exactly `per` = ceil(ncol / world) columns (the synthetic generator is
+    # keyed by the global column index, so the last rank simply continues past --ncol when it does not divide): equal blocks for the
+    # all-gather, no rank-dependent path anywhere.  `value` counts --ncol columns only.
     from rrtmg_lw_amd.shard import column_block, output_rows, output_views
-    col0, ncol, per = column_block(args.ncol, world, rank)
+    per = (args.ncol + world - 1) // world
+    col0, ncol = rank * per, per
     nlay = args.nlay
     # inputs straight into HBM, generated in slabs to bound the temporaries
     slab = 131072
@@ -119,19 +130,17 @@ def main():
     del parts
     idrv = d["idrv"]
 
-    # packed output block: rows = uflx, dflx, uflxc, dflxc, duflx_dt, duflxc_dt (nlay+1 each), hr, hrc (nlay each)
-    rows = output_rows(nlay)
+    # packed output block: rows = uflx, dflx, uflxc, dflxc [, duflx_dt, duflxc_dt with idrv = 1] (nlay+1 each), hr, hrc (nlay each)
+    rows = output_rows(nlay, idrv)
     # two output blocks: the all-gather of step k (RCCL's own stream) overlaps the kernels of step k+1
     outbufs = [torch.zeros((rows, ncol), dtype=torch.float64, device=dev) for _ in range(2)]
-    outs = [output_views(b, nlay) for b in outbufs]
+    outs = [output_views(b, nlay, idrv) for b in outbufs]
     outbuf, out = outbufs[0], outs[0]
     gathered = [None, None]
     pending = [None, None]
     do_gather = use_dist and not args.no_gather
     if do_gather:
         gathered = [torch.empty((world * rows, per), dtype=torch.float64, device=dev) for _ in range(2)]   # rank-major concatenation
-        if ncol != per:
-            raise SystemExit("--ncol must be divisible by --gpus for the all-gather")
 
     stream = torch.cuda.current_stream().cuda_stream
     alpha = None
@@ -173,7 +182,7 @@ def main():
         api.check(stream)
         n = min(256, ncol)
         dn = make_gcm_inputs(n, nlay, args.config, col0=col0)
-        orc = Oracle(kdata=api.default_kdata())
+        orc = Oracle(kdata=api.REAL_KDATA if os.path.exists(api.REAL_KDATA) else api.STANDIN_KDATA)
         if args.mcica:
             al = np.asfortranarray(alpha[:n].cpu().numpy())
             sub = orc.mcica_subcol(n, nlay, args.mcica, 1, 0, dn["play"], dn["cldfr"], dn["cicewp"], dn["cliqwp"], dn["reice"],
@@ -264,7 +273,10 @@ def main():
         bpc = algo_bytes_per_col(nlay, idrv) + (8.0 * nlay if args.mcica else 0.0)     # + alpha
         roof = None
         path = None
+        compute = None
         if kern:
+            ktot = sum(v[1] for v in kern.values())                 # summed kernel milliseconds of the timed steps (this rank)
+            pach = bpc * ncol * args.steps / (ktot * 1e-3) / 1e9
             # dominant kernel of the critical path: k_colprep / k_cloudscan / k_cloudlay run on the auxiliary stream underneath the previous
             # batch's k_layer / k_sweep (driver.hip: run_pipelined) and are left out of the choice
             crit = {k: v for k, v in kern.items() if not (k.startswith("k_colprep") or k in ("k_cloudscan", "k_cloudlay"))} or kern
@@ -272,30 +284,47 @@ def main():
             cnt, tot = kern[dom]
             avg_ms = tot / cnt
             cols_per_launch = ncol * args.steps / cnt      # every kernel is launched once per column batch
-            share = 1.0
-            ach = bpc * share * cols_per_launch / (avg_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=round(avg_ms, 4),
-                        launches=cnt, columns_per_launch=cols_per_launch,
-                        algorithmic_bytes_per_launch=bpc * share * cols_per_launch)
-            ktot = sum(v[1] for v in kern.values())
-            pach = bpc * ncol * args.steps / (ktot * 1e-3) / 1e9
-            path = dict(kernels_ms_per_step=round(ktot / args.steps, 3), achieved=round(pach, 3), unit="GB/s",
-                        frac=round(pach / HBM_PEAK_GBS, 5), bytes_per_column=bpc,
-                        kernels={k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
-                        families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
-                                  for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweep", "k_flux", "k_rates")})
-            # PMC-derived HBM traffic of the dominant kernel, if a summary has been committed under profiles/
+            dom_d = dict(kernel=dom, avg_launch_ms=round(avg_ms, 4), launches=cnt, columns_per_launch=cols_per_launch,
+                         time_share=round(tot / ktot, 4),
+                         # the contract's per-kernel figure (whole-column algorithmic bytes / this kernel's time) overstates a kernel that is
+                         # a fraction of the path; kept for continuity with round 1, next to the share-weighted one
+                         whole_column_bytes_over_kernel_time_GBps=round(bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9, 3),
+                         traffic=None)
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    roof["traffic"] = json.load(open(pmc)).get(dom)
+                    dom_d["traffic"] = json.load(open(pmc)).get(dom)
+                except Exception:
+                    pass
+            roof = dict(bound="hbm", scope="path: all kernels of a step (sweep family = %.0f %% of it)" %
+                        (100.0 * sum(v[1] for k, v in kern.items() if k.startswith("k_sweep")) / ktot),
+                        achieved=round(pach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pach / HBM_PEAK_GBS, 5),
+                        algorithmic_bytes_per_column=bpc, kernels_ms_per_step=round(ktot / args.steps, 3),
+                        traffic=dom_d["traffic"], dominant=dom_d)
+            path = dict(kernels_ms_per_step=round(ktot / args.steps, 3),
+                        kernels={k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
+                        families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
+                                  for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweepc", "k_sweep<", "k_flux", "k_rates")})
+            # instruction side: counts per column from the committed PMC pass of the same configuration, times from this run
+            pc = os.path.join(ROOT, "profiles", "pmc_compute.json")
+            key = f"{args.config}_L{nlay}" + (f"_mcica{args.mcica}" if args.mcica else "")
+            if os.path.exists(pc):
+                try:
+                    ent = json.load(open(pc)).get(key)
+                    if ent:
+                        valu = ent["valu_wave_instr_per_column"] * 64.0 * ncol * args.steps / (ktot * 1e-3)
+                        ldsb = ent["lds_bytes_per_column"] * ncol * args.steps / (ktot * 1e-3)
+                        compute = dict(valu_lane_instr_per_s=round(valu, 1), valu_peak=VALU_PEAK_LANE_INSTR, valu_frac=round(valu / VALU_PEAK_LANE_INSTR, 4),
+                                       valu_frac_of_f64_rate=round(valu / (VALU_PEAK_LANE_INSTR / 2), 4),
+                                       lds_bytes_per_s=round(ldsb, 1), lds_peak=LDS_PEAK_BYTES, lds_frac=round(ldsb / LDS_PEAK_BYTES, 4),
+                                       valu_wave_instr_per_column=ent["valu_wave_instr_per_column"], lds_bytes_per_column=ent["lds_bytes_per_column"],
+                                       source=ent.get("source", "profiles/pmc_compute.json"))
                 except Exception:
                     pass
         res = dict(metric="columns/sec, 72-layer profiles" if nlay == 72 else f"columns/sec, {nlay}-layer profiles",
                    value=round(value, 1), unit="columns/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
-                   dtype="f64", data="synthetic",
+                   dtype="f64 (transmittance / tfn codes and their LDS table f32)", data="synthetic",
                    config=dict(workload=f"{args.ncol} synthetic {nlay}-layer columns, config '{args.config}' "
                                         + (f"(McICA: kissvec sub-column generator icld={args.mcica} + cldprmc + rtrnmc, idrv={idrv}), " if args.mcica else
                                            f"(icld={d['icld']}: {'rtrnmr max-random overlap' if d['icld'] == 2 else 'clear'}, idrv={idrv}), ") +
@@ -303,7 +332,7 @@ def main():
                                ncol_total=args.ncol, nlay=nlay, columns_per_gpu=per, parallelism=f"columns/{world}",
                                gather="rccl all_gather_into_tensor of the packed outputs, overlapped with the next step's kernels" if do_gather else "none",
                                kdata="stand-in (real k-data absent from the reference mount)" if api.kdata_is_standin() else "real"),
-                   roofline=roof, path=path, cpu_baseline=cpu, end_to_end=e2e)
+                   roofline=roof, compute=compute, path=path, cpu_baseline=cpu, end_to_end=e2e)
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -18,8 +18,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _pin(slot):
+    """Pin this worker to one CPU of the affinity mask (one process per core, pinned).  Returns the CPU, or -1
+    when the mask cannot be narrowed (some containers refuse it)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        cpu = cpus[slot % len(cpus)]
+        os.sched_setaffinity(0, {cpu})
+        return cpu
+    except OSError:
+        return -1
+
+
 def _worker(args):
-    ncol, nlay, config, col0, kind = args
+    ncol, nlay, config, col0, kind, slot = args
+    pinned = _pin(slot)
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     from oracle.bindings import Oracle, Reference
@@ -29,7 +42,7 @@ def _worker(args):
     eng.rrtmg_lw(min(ncol, 8), nlay, d["icld"], d["idrv"], make_gcm_inputs(min(ncol, 8), nlay, config))   # warm-up
     t0 = time.perf_counter()
     eng.rrtmg_lw(ncol, nlay, d["icld"], d["idrv"], d)
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, pinned
 
 
 def _sample_worker(args):
@@ -62,17 +75,23 @@ def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None, sample_col
     kind = "reference" if Reference.available("nomcica") else "port"
     if cores is None:
         cores = usable_cores()
-    jobs = [(cols_per_core, nlay, config, i * cols_per_core, kind) for i in range(cores)]
+    # spread the pins over the mask (a 16-CPU quota on a 256-thread box: every 16th hardware thread, distinct physical cores)
+    stride = max(1, len(os.sched_getaffinity(0)) // cores)
+    jobs = [(cols_per_core, nlay, config, i * cols_per_core, kind, i * stride) for i in range(cores)]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
-        times = list(ex.map(_worker, jobs))
+        res = list(ex.map(_worker, jobs))
+        times = [r[0] for r in res]
+        npinned = sum(1 for r in res if r[1] >= 0)
         wall = time.perf_counter() - t0
         # the baseline's own results for the first `sample_cols` columns of the workload: bench.py compares the GPU's with them
         sample = ex.submit(_sample_worker, (sample_cols, nlay, config, kind)).result() if sample_cols > 0 else None
     total = cols_per_core * cores
     tmax = max(times)
     return dict(value=total / tmax, unit="columns/s", cores=cores, kind=kind,
+                pinned=npinned == cores,
                 sample=f"{total} synthetic {nlay}-layer '{config}' columns ({cols_per_core} per process, one process per core, "
+                       f"{'each pinned to its own CPU' if npinned == cores else 'unpinned'}, "
                        f"slowest process {tmax:.2f} s, {sum(times):.1f} core-seconds; single-core rate {cols_per_core / (sum(times) / cores):.0f} columns/s)",
                 wall_s=wall, sample_outputs=sample)
 

@@ -158,7 +158,8 @@ def rrtmg_lw_device(d, out, icld=None, idrv=None, stream=None):
     args += [ptr(d[k]) for k in _GCM_ORDER]
     args += [C.c_int(int(d["inflglw"])), C.c_int(int(d["iceflglw"])), C.c_int(int(d["liqflglw"]))]
     args += [ptr(d[k]) for k in _CLD_ORDER]
-    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")]
+    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")]
+    args += [ptr(out[k]) if out.get(k) is not None else C.c_void_p(0) for k in ("duflx_dt", "duflxc_dt")]      # needed only with idrv = 1
     args.append(C.c_void_p(stream or 0))
     _check(lib().rrtmg_lw_hip_run_nomcica_device(*args))
     return icld_c.value
@@ -188,7 +189,8 @@ def rrtmg_lw_mcica_device(d, sub, out, icld=None, idrv=None, stream=None):
     args += [ptr(d[k]) for k in _GCM_ORDER]
     args += [C.c_int(int(d["inflglw"])), C.c_int(int(d["iceflglw"])), C.c_int(int(d["liqflglw"]))]
     args += [ptr(sub[k]) for k in ("cldfmcl", "taucmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl")] + [ptr(d["tauaer"])]
-    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")]
+    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")]
+    args += [ptr(out[k]) if out.get(k) is not None else C.c_void_p(0) for k in ("duflx_dt", "duflxc_dt")]      # needed only with idrv = 1
     args.append(C.c_void_p(stream or 0))
     _check(lib().rrtmg_lw_hip_run_mcica_device(*args))
     return icld_c.value
@@ -339,7 +341,8 @@ def rrtmg_lw_mcica_subcol_device(d, out, permuteseed, irng, alpha=None, icld=Non
     args += [C.c_int(int(d["inflglw"])), C.c_int(int(d["iceflglw"])), C.c_int(int(d["liqflglw"]))]
     args += [ptr(d[k]) for k in ("cldfr", "taucld", "cicewp", "cliqwp", "reice", "reliq")]
     args += [ptr(alpha) if alpha is not None else C.c_void_p(0), ptr(d["tauaer"])]
-    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")]
+    args += [ptr(out[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")]
+    args += [ptr(out[k]) if out.get(k) is not None else C.c_void_p(0) for k in ("duflx_dt", "duflxc_dt")]      # needed only with idrv = 1
     args.append(C.c_void_p(stream or 0))
     _check(lib().rrtmg_lw_hip_run_mcica_subcol_device(*args))
     return icld_c.value

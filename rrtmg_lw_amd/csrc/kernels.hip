@@ -2456,17 +2456,17 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 // waves per SIMD each instantiation is compiled for = what its registers allow without spilling (a spilled register is reloaded with a
 // scratch load, which counts as a vector-memory operation: its wait drains every prefetch in flight), at most 4 (one workgroup of
 // <= 1024 threads per CU: the transmittance table takes half of the LDS).  Register needs, unconstrained, by quads per thread 4 / 3 / 2 / 1:
-//   phase 1                       160 124  96  70
-//   phase 0                       198 154 116  76
-//   phase 2, phase 0 with d/dT    232 190 144  94
-//   phase 2 with d/dT             256 256 208 124
+//   phase 1                       132 112  96  70
+//   phase 0                       218 154 124  78
+//   phase 2, phase 0 with d/dT    256+ 232 164  96
+//   phase 2 with d/dT             256+ 256+ 238 126
 #ifndef RRLW_SWEEPC_WAVES_CAP
 #define RRLW_SWEEPC_WAVES_CAP 4
 #endif
 __host__ __device__ constexpr int sweepc_waves(int NQ, int PHASE, bool IDRV)
 {
     const int row = PHASE == 1 ? 0 : (PHASE == 0 && !IDRV) ? 1 : (PHASE == 2 && IDRV) ? 3 : 2;
-    const int tab[4][4] = {{7, 5, 4, 3}, {6, 4, 3, 2}, {5, 3, 2, 2}, {4, 2, 1, 1}};      // [row][NQ - 1]
+    const int tab[4][4] = {{7, 5, 4, 3}, {6, 4, 3, 2}, {5, 3, 2, 1}, {4, 2, 1, 1}};      // [row][NQ - 1]
     const int w = tab[row][NQ - 1];
     return w < RRLW_SWEEPC_WAVES_CAP ? w : RRLW_SWEEPC_WAVES_CAP;
 }
@@ -2570,7 +2570,9 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
         const double blay = planck_at(tp0, tp0, cur.tl);
         const double dpl = planck_at(tp0, (DN && alt16 && lev == 1) ? tp1 : tp0, cur.tz) - blay;
         fill_t(bin_tag, lev + dir, DN ? 0 : 1, cur);
-        double sum = 0.0, sumc = 0.0, dsum = 0.0, dsumc = 0.0;
+        // (sums as a tree - pairs inside a quad, then the quads: a running sum over 16 g-points is a chain of 16 dependent additions, and a
+        // wave issues in order, so each of them would hold the wave for the latency of the one before)
+        double qs[G], qsc[G], qd[G], qdc[G];
 #pragma unroll
         for (int k = 0; k < G; k++) {
             float2 e[4];
@@ -2593,15 +2595,30 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
                 if constexpr (BIN) fr = fr + fpl * (row[16 + j] - fr);
                 const double bb = fr * (blay + tfn * dpl);
                 rad[j] = rad[j] + (bb - rad[j]) * atr;
-                sum = sum + rad[j];
-                if constexpr (TWO && !DN) { radc[j] = radc[j] + (bb - radc[j]) * atr; sumc = sumc + radc[j]; }
+                if constexpr (TWO && !DN) radc[j] = radc[j] + (bb - radc[j]) * atr;
                 if constexpr (IDRV && !DN) {
-                    drad[j] = drad[j] * (1.0 - atr); dsum = dsum + drad[j];
-                    if constexpr (TWO) { dradc[j] = dradc[j] * (1.0 - atr); dsumc = dsumc + dradc[j]; }
+                    drad[j] = drad[j] * (1.0 - atr);
+                    if constexpr (TWO) dradc[j] = dradc[j] * (1.0 - atr);
                 }
+            }
+            qs[k] = (rad[4 * k] + rad[4 * k + 1]) + (rad[4 * k + 2] + rad[4 * k + 3]);
+            if constexpr (TWO && !DN) qsc[k] = (radc[4 * k] + radc[4 * k + 1]) + (radc[4 * k + 2] + radc[4 * k + 3]);
+            if constexpr (IDRV && !DN) {
+                qd[k] = (drad[4 * k] + drad[4 * k + 1]) + (drad[4 * k + 2] + drad[4 * k + 3]);
+                if constexpr (TWO) qdc[k] = (dradc[4 * k] + dradc[4 * k + 1]) + (dradc[4 * k + 2] + dradc[4 * k + 3]);
             }
             if (RRLW_SWEEPC_QUAD_BARRIER) __builtin_amdgcn_sched_barrier(0);
         }
+        auto tree = [&](const double (&q)[G]) -> double {
+            if constexpr (G == 1) return q[0];
+            else if constexpr (G == 2) return q[0] + q[1];
+            else if constexpr (G == 3) return (q[0] + q[1]) + q[2];
+            else return (q[0] + q[1]) + (q[2] + q[3]);
+        };
+        const double sum = tree(qs);
+        double sumc = 0.0, dsum = 0.0, dsumc = 0.0;
+        if constexpr (TWO && !DN) sumc = tree(qsc);
+        if constexpr (IDRV && !DN) { dsum = tree(qd); if constexpr (TWO) dsumc = tree(qdc); }
         const double v = (sum * 0.5) * wtdelw, vc = (TWO && !DN) ? (sumc * 0.5) * wtdelw : v;
         if (incol) {
             if constexpr (DN) pdn[(size_t)(lev - 1) * ncb] = Part2{v, vc};

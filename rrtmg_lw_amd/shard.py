@@ -7,8 +7,13 @@ buffer so that a single all_gather_into_tensor moves everything.
 """
 from __future__ import annotations
 
-FLUX_NAMES = ("uflx", "dflx", "uflxc", "dflxc", "duflx_dt", "duflxc_dt")
+FLUX_NAMES = ("uflx", "dflx", "uflxc", "dflxc")
+DERIV_NAMES = ("duflx_dt", "duflxc_dt")          # part of the block only when idrv = 1 (a third of the rows otherwise dead weight in the gather)
 RATE_NAMES = ("hr", "hrc")
+
+
+def flux_names(idrv=1):
+    return FLUX_NAMES + (DERIV_NAMES if idrv else ())
 
 
 def column_block(ncol, world, rank):
@@ -18,14 +23,15 @@ def column_block(ncol, world, rank):
     return col0, max(0, min(per, ncol - col0)), per
 
 
-def output_rows(nlay):
-    return len(FLUX_NAMES) * (nlay + 1) + len(RATE_NAMES) * nlay
+def output_rows(nlay, idrv=1):
+    """Rows of the packed block: 4 (idrv = 0) or 6 (idrv = 1) flux arrays of nlay + 1 levels, 2 heating-rate arrays of nlay layers."""
+    return len(flux_names(idrv)) * (nlay + 1) + len(RATE_NAMES) * nlay
 
 
-def output_views(buf, nlay):
-    """Slice a (rows, ncol) buffer (torch tensor or numpy array) into the eight named output arrays."""
+def output_views(buf, nlay, idrv=1):
+    """Slice a (rows, ncol) buffer (torch tensor or numpy array) into the named output arrays (six without dF/dT, eight with)."""
     out, r = {}, 0
-    for nm in FLUX_NAMES:
+    for nm in flux_names(idrv):
         out[nm] = buf[r:r + nlay + 1]
         r += nlay + 1
     for nm in RATE_NAMES:
@@ -34,12 +40,14 @@ def output_views(buf, nlay):
     return out
 
 
-def unpack_gathered(gathered, nlay, ncol):
-    """gathered: (world, rows, per) -> dict of (ncol, nlay[+1]) arrays in global column order."""
+def unpack_gathered(gathered, nlay, ncol, idrv=1):
+    """gathered: (world, rows, per) -> dict of (ncol, nlay[+1]) arrays in global column order (columns past ncol - the padding of
+    the last ranks when ncol is not a multiple of the world size - are dropped)."""
     world, rows, per = gathered.shape
+    assert rows == output_rows(nlay, idrv)
     out = {}
-    views = [output_views(gathered[r], nlay) for r in range(world)]
-    for nm in FLUX_NAMES + RATE_NAMES:
+    views = [output_views(gathered[r], nlay, idrv) for r in range(world)]
+    for nm in flux_names(idrv) + RATE_NAMES:
         parts = [v[nm].T for v in views]                  # (per, nlev) each
         if hasattr(parts[0], "numpy") and not hasattr(parts[0], "__array_interface__"):
             import torch

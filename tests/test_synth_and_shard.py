@@ -8,7 +8,7 @@ import socket
 import numpy as np
 import pytest
 
-from rrtmg_lw_amd.shard import column_block, output_rows, output_views, unpack_gathered
+from rrtmg_lw_amd.shard import column_block, flux_names, output_rows, output_views, unpack_gathered
 from rrtmg_lw_amd.synth import base_profile, make_gcm_inputs
 
 
@@ -59,42 +59,57 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, ncol, nlay, q):
+def _rank_main(rank, world, port, ncol, nlay, config, q):
+    """One rank of the sharded step as bench.py runs it: `per` = ceil(ncol / world) columns on every rank (the last rank continues
+    past ncol), the packed block sized by idrv, one all_gather_into_tensor."""
     import torch
     import torch.distributed as dist
     from oracle.bindings import Oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    col0, n, per = column_block(ncol, world, rank)
-    d = make_gcm_inputs(n, nlay, "cloudy", col0=col0)
-    o = Oracle().rrtmg_lw(n, nlay, d["icld"], d["idrv"], d)
-    buf = torch.zeros((output_rows(nlay), per), dtype=torch.float64)
-    views = output_views(buf, nlay)
-    for k in ("uflx", "dflx", "uflxc", "dflxc", "hr", "hrc"):
-        views[k][:, :n] = torch.from_numpy(np.ascontiguousarray(o[k].T))
-    gathered = torch.empty((world * output_rows(nlay), per), dtype=torch.float64)
+    per = (ncol + world - 1) // world
+    d = make_gcm_inputs(per, nlay, config, col0=rank * per)
+    idrv = d["idrv"]
+    o = Oracle().rrtmg_lw(per, nlay, d["icld"], idrv, d)
+    rows = output_rows(nlay, idrv)
+    buf = torch.zeros((rows, per), dtype=torch.float64)
+    views = output_views(buf, nlay, idrv)
+    assert set(views) == set(flux_names(idrv)) | {"hr", "hrc"}
+    for k in views:
+        views[k][:, :] = torch.from_numpy(np.ascontiguousarray(o[k].T))
+    gathered = torch.empty((world * rows, per), dtype=torch.float64)
     dist.all_gather_into_tensor(gathered, buf)
     if rank == 0:
-        res = unpack_gathered(gathered.view(world, output_rows(nlay), per), nlay, ncol)
+        res = unpack_gathered(gathered.view(world, rows, per), nlay, ncol, idrv)
         q.put({k: v.numpy() for k, v in res.items()})
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_allgather_matches_single_process(oracle):
+@pytest.mark.parametrize("ncol,nlay,config", [(22, 30, "cloudy"), (23, 30, "cloudy"), (21, 20, "aer_idrv")])
+def test_two_rank_gloo_allgather_matches_single_process(oracle, ncol, nlay, config):
+    """Even split, a column count the world size does not divide, and idrv = 1 (the block then carries duflx_dt / duflxc_dt)."""
     import torch.multiprocessing as mp
-    ncol, nlay, world = 22, 30, 2
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, ncol, nlay, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, ncol, nlay, config, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=0)
+    d = make_gcm_inputs(ncol, nlay, config, col0=0)
     ref = oracle.rrtmg_lw(ncol, nlay, d["icld"], d["idrv"], d)
-    for k in ("uflx", "dflx", "uflxc", "dflxc", "hr", "hrc"):
+    keys = ("uflx", "dflx", "uflxc", "dflxc", "hr", "hrc") + (("duflx_dt", "duflxc_dt") if d["idrv"] else ())
+    assert set(got) == set(keys)
+    for k in keys:
+        assert got[k].shape == ref[k].shape
         assert np.array_equal(got[k], ref[k]), k
+
+
+def test_packed_block_drops_derivative_rows_without_idrv():
+    assert output_rows(72, 0) == 4 * 73 + 2 * 72 == 436          # SURVEY.md 8e: 436 rows per column at 72 layers
+    assert output_rows(72, 1) == 6 * 73 + 2 * 72 == 582
