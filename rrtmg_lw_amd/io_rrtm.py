@@ -1,4 +1,4 @@
-"""Reader for the column driver's text files: INPUT_RRTM, IN_CLD_RRTM, IN_AER_RRTM, OUTPUT_RRTM.
+"""Reader and writer for the column driver's text files: INPUT_RRTM, IN_CLD_RRTM, IN_AER_RRTM in, OUTPUT_RRTM in and out.
 
 Follows the record formats of the reference's standalone driver (``readprof`` src/rrtmg_lw.1col.f90:755-1149,
 ``readcld`` :1152-1208, ``readaer`` :1211-1293, ``xsident`` :1296-1363; output formats :737-746) so that
@@ -245,3 +245,62 @@ def read_output_rrtm(path):
         out.append(dict(wn1=b["wn1"], wn2=b["wn2"], level=r[:, 0].astype(int), pz=r[:, 1],
                         uflx=r[:, 2], dflx=r[:, 3], fnet=r[:, 4], htr=r[:, 5]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OUTPUT_RRTM writer: the column driver's output records, src/rrtmg_lw.1col.f90:615-639 (write statements) and
+# :737-746 (formats 9952-9958, 9899-9901, 9903).
+# ---------------------------------------------------------------------------------------------------------------------
+WAVENUM1 = (10., 350., 500., 630., 700., 820., 980., 1080., 1180., 1390., 1480., 1800., 2080., 2250., 2380., 2600.)    # src/rrtmg_lw_init.f90:215-220
+WAVENUM2 = (350., 500., 630., 700., 820., 980., 1080., 1180., 1390., 1480., 1800., 2080., 2250., 2380., 2600., 3250.)
+
+
+def _ffmt(x, w, d):
+    """Fortran Fw.d edit descriptor as the reference's compiler prints it: right-justified; the optional zero before the decimal
+    point is dropped when the field has no room for it (f6.5 of 0.067 -> '.06700'); asterisks on overflow."""
+    t = f"{x:.{d}f}"
+    if len(t) > w and t.startswith("0."):
+        t = t[1:]
+    elif len(t) > w and t.startswith("-0."):
+        t = "-" + t[2:]
+    return t.rjust(w) if len(t) <= w else "*" * w
+
+
+def format_output_row(i, pz, up, dn, net, htr):
+    """One level record: formats 9952-9958, chosen by the pressure (src/rrtmg_lw.1col.f90:623-637)."""
+    if pz < 1.e-2:
+        pre = " " * 9 + _ffmt(pz, 7, 6) + " " * 3          # 9952
+    elif pz < 1.e-1:
+        pre = " " * 9 + _ffmt(pz, 6, 5) + " " * 4          # 9953
+    elif pz < 1.:
+        pre = " " * 8 + _ffmt(pz, 6, 4) + " " * 5          # 9954
+    elif pz < 10.:
+        pre = " " * 7 + _ffmt(pz, 6, 3) + " " * 6          # 9955
+    elif pz < 100.:
+        pre = " " * 6 + _ffmt(pz, 6, 2) + " " * 7          # 9956
+    else:
+        pre = " " * 5 + _ffmt(pz, 6, 1) + " " * 8          # 9957, 9958
+    return " " + f"{int(i):3d}" + pre + _ffmt(up, 8, 4) + " " * 6 + _ffmt(dn, 8, 4) + " " * 6 + _ffmt(net, 12, 7) + " " * 10 + _ffmt(htr, 9, 5)
+
+
+def format_output_block(istart, iend, pz, up, dn, net, htr, iplon=1):
+    """Header (9899-9901), the level records from the top level down to 0, and the page-feed record (9903)."""
+    lines = [f" Wavenumbers: {_ffmt(WAVENUM1[istart - 1], 6, 1)} - {_ffmt(WAVENUM2[iend - 1], 6, 1)} cm-1, ATM {int(iplon):6d}",
+             " LEVEL    PRESSURE   UPWARD FLUX   DOWNWARD FLUX    NET FLUX       HEATING RATE",
+             "             mb          W/m2          W/m2           W/m2          degree/day"]
+    for i in range(len(pz) - 1, -1, -1):
+        lines.append(format_output_row(i, pz[i], up[i], dn[i], net[i], htr[i]))
+    lines.append("\f")
+    return lines
+
+
+def write_output_rrtm(path, blocks, footer=None):
+    """blocks: list of dict(istart, iend, pz, uflx, dflx, fnet, htr[, iplon]) in the order the driver writes them (the total, then
+    the bands when iout = 99).  `footer` replaces the reference's list of module versions (format 9910)."""
+    out = []
+    for b in blocks:
+        out += format_output_block(b["istart"], b["iend"], b["pz"], b["uflx"], b["dflx"], b["fnet"], b["htr"], b.get("iplon", 1))
+    out += footer if footer is not None else ["  Modules and versions used in this calculation:", "",
+                                               "     rrtmg_lw_amd (MI355X-native RRTMG_LW hot path): librrtmg_lw_hip.so over the prepared-column entry"]
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
