@@ -49,7 +49,7 @@ struct State {
     // McICA sub-column masks of all columns of the current call
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
-    int batch = 131072;     // columns per internal batch: ~0.2 MB of workspace per column at 72 layers (27 GB); measured per 1e6 cloudy columns: 32768: 117.9 ms, 65536: 112.6 ms, 131072: 108.4 ms, 262144: 106.8 ms
+    int batch = 262144;     // columns per internal batch: ~0.2 MB of workspace per column at 72 layers (54 GB of the 288); measured per 1e6 cloudy columns (round 2): 131072: 80.6 ms, 262144: 78.4 ms, 524288: 78.2 ms
     bool split_sweep = false;    // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: k_sweep
                                  // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -1 %)
     bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device

@@ -1006,7 +1006,17 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     for (int q = 0; q < NQ; q++) {
         scr4 c;
 #pragma unroll
-        for (int k = 0; k < 4; k++) c.v[k] = cell_code(od[4 * q + k], od[4 * q + k] <= 0.06, bpade);
+        for (int k = 0; k < 4; k++) {
+            // the table index costs a float64 division (~16 instructions per cell, a third of k_layer's arithmetic); the 64 columns of a
+            // wave sit in the same layer, so thin g-points (upper atmosphere, band wings) are thin in all of them: a wave whose cells
+            // all take the series branch skips the division (wave-uniform test; same values either way)
+            const bool series = od[4 * q + k] <= 0.06;
+#ifdef RRLW_SERIES_SKIP          // (measured: k_layer 26.0 -> 27.3 ms per 1e6 cloudy columns - 140 wave-uniform branches per thread cost more than the skipped divisions)
+            if (__builtin_amdgcn_ballot_w64(!series) == 0ull) c.v[k] = (scr_t)od[4 * q + k];
+            else
+#endif
+                c.v[k] = cell_code(od[4 * q + k], series, bpade);
+        }
         if (incol) scr_store(W.scr[S_CODE], so0 + q * qstride, c);
     }
     if (CLOUD && cloudy) {

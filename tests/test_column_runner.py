@@ -63,10 +63,10 @@ CASES = [("input_rrtm_MLS-clr", None, None), ("input_rrtm_MLS-clr-aer12", None, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("inp,cld,aer", CASES, ids=[c[0] for c in CASES])
-def test_runner_matches_oracle(tmp_path, oracle, inp, cld, aer):
+def test_runner_matches_oracle(tmp_path, hip, oracle, inp, cld, aer):
     """The runner end to end (file in, OUTPUT_RRTM out, stand-in coefficients) against the oracle taken through the same driver steps:
     block sequence of IOUT, DTBOUND adjustment with IDRV = 1; agreement to the printed precision."""
-    from rrtmg_lw_amd import api
+    api = hip          # (the session fixture loads torch's HIP runtime before the library: one runtime per process, tests/conftest.py)
     from rrtmg_lw_amd.column import main
     j = lambda n: os.path.join(G, n) if n else None
     out = str(tmp_path / "OUTPUT_RRTM")
