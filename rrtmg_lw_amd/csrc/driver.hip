@@ -53,6 +53,7 @@ struct State {
     bool split_sweep = false;    // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: k_sweep
                                  // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -1 %)
     bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device
+    bool n1 = false;             // RRTMG_LW_N1=1: cloud-free calls take the north-star-mapping prototype k_n1 (measurement only)
     bool ws_two_scr = false;     // the workspace holds the second scratch set that split_sweep needs
     // host-entry staging
     void *stage_base = nullptr;
@@ -381,6 +382,19 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         for (int k = 0; k < 3; k++) HIP_TRY(hipStreamWaitEvent(G.swq[k], G.ev_swq_go, 0));
     }
     const hipStream_t s_main = s;
+    if (G.n1 && mode == 0 && GCM && istart == 1 && iend == 16 && idrv == 0 && n1_lds_bytes(nlay) <= 160 * 1024) {
+        // prototype of the north-star mapping (one column per wavefront): replaces the sweeps, k_flux and k_rates of a cloud-free call
+        SweepArgs sa{};
+        sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = 0; sa.istart = 1; sa.iend = 16;
+        sa.emis = g.emis; sa.cldfrac = nullptr; sa.tlay = g.tlay; sa.tlev = g.tlev;
+        static bool attr = false;
+        if (!attr) { HIP_TRY(hipFuncSetAttribute((const void *)k_n1<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        const dim3 ngrid((nb + N1_WAVES - 1) / N1_WAVES), nblock(64 * N1_WAVES);
+        LAUNCH_LDS("k_n1", (k_n1<false>), ngrid, nblock, n1_lds_bytes(nlay), s, G.D, Wk, sa, out, g.plev);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     SweepArgs sa;
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
     sa.emis = GCM ? g.emis : c.semiss;
@@ -821,6 +835,10 @@ int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, do
     D.heatfac = G.H.heatfac; D.fluxfac = G.H.fluxfac; D.oneminus = G.H.oneminus; D.bpade = G.H.bpade;
     if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; G.ws_mc = false; }
     G.device = device;
+    {
+        const char *e = std::getenv("RRTMG_LW_N1");
+        G.n1 = e && e[0] == '1';
+    }
     G.init = true;
     G.err.clear();
     return 0;

@@ -1773,7 +1773,12 @@ __host__ __device__ constexpr int sweep_ns(int NQ, int MODE, bool IDRV)
     return T == 3 ? (waves / 3 > 1 ? waves / 3 : 1) : waves / T;     // (3 threads per band: 12 of 12, 15 of 16 or 6 of 8 wave slots)
 }
 // dynamic LDS of k_sweep<., NQ>: transmittance table (float pairs), Planck rows, fraction rows, reduction buffer
-constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8, SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
+#ifdef RRLW_SWEEP_EXPF
+constexpr int SWEEP_LUT_BYTES = 16;                   // no table in LDS
+#else
+constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8;
+#endif
+constexpr int SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
 __host__ __device__ constexpr int sweep_lds_bytes(int NQ, int MODE, bool IDRV)
 {
     const int T = sweep_t(NQ, MODE, IDRV);
@@ -1826,6 +1831,28 @@ __device__ __forceinline__ void decode(scr_t c, const float2 &e, double &atr, do
     tfn = (double)(e.y + 0.166667f * od);
 #endif
 }
+// RRLW_SWEEP_EXPF (measurement variant, north_star "__builtin_amdgcn_expf for transmittance"): the table entry of index i evaluated
+// instead of looked up - the same closed forms rrtmg_lw_ini tabulates (src/rrtmg_lw_init.f90:125-142: t = i / 1e4,
+// tau = bpade t / (1 - t), 1 - exp(-tau), tfn = tau / 6 below 0.06 else 1 - 2 (1 / tau - exp / (1 - exp))) in float32 with the hardware
+// exp2 / rcp.  The INDEX is still the reference's (formed in float64 by k_layer).  Frees the table's 80 KB of LDS; costs ~12 more
+// instructions per cell (4 of them transcendental) and float32 cancellation in 1 - exp and in tfn.  Measured: profiles/round2_expf.md.
+__device__ __forceinline__ float2 lut_entry_expf(unsigned idx, float bpade)
+{
+    const float t = (float)idx * 1.0e-4f;
+    const float tau = bpade * t * __builtin_amdgcn_rcpf(1.0f - t);                    // idx = 10000 -> +inf -> exp = 0, entry {1, 1}
+    const float ex = __builtin_amdgcn_exp2f(-1.44269504088896f * tau);
+    const float atr = 1.0f - ex;
+    float tfn = tau < 0.06f ? tau * (1.0f / 6.0f) : 1.0f - 2.0f * (__builtin_amdgcn_rcpf(tau) - ex * __builtin_amdgcn_rcpf(atr));
+    if (idx == 0u) tfn = 0.0f;                                                         // entry 0 = {0, 0} (series cells)
+    if (idx >= 10000u) tfn = 1.0f;
+    return make_float2(idx == 0u ? 0.0f : atr, tfn);
+}
+#ifdef RRLW_SWEEP_EXPF
+#define RRLW_LUT_ENTRY(lut, idx) lut_entry_expf((idx), 3.5971223f)
+#else
+#define RRLW_LUT_ENTRY(lut, idx) (lut)[(idx)]
+#endif
+
 // integrated Planck function at temperature t from one band's row of totplnk: setcoef :173-269
 __device__ __forceinline__ double planck_at(const double *tp, const double *tq, double t)
 {
@@ -1888,7 +1915,11 @@ __device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned 
     const double2 *src = reinterpret_cast<const double2 *>(T.stat + T.sl.lutf);
     double2 *dst = reinterpret_cast<double2 *>(smem);
     // (loads first, then the LDS writes, eight at a time: a plain copy loop waits for every load before it issues the next)
+#ifdef RRLW_SWEEP_EXPF
+    constexpr int NLUT = 0;
+#else
     constexpr int NLUT = SWEEP_LUT_BYTES / 16;
+#endif
     for (int i0 = tid; i0 < NLUT; i0 += 8 * nth) {
         double2 v[8];
 #pragma unroll
@@ -2179,7 +2210,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
             for (int j = 0; j < NGC; j++) {
                 double tfn;
                 const scr_t cj = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
-                decode(cj, s_lut[code_index(cj)], atr[j], tfn);
+                decode(cj, RRLW_LUT_ENTRY(s_lut, code_index(cj)), atr[j], tfn);
                 bbd[j] = fr[j] * (blay + tfn * dplankdn);
             }
             if constexpr (CODES2) cq[i & 1] = ldcodes(lev - 2);
@@ -2233,7 +2264,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
                         double atot, tftot;
-                        decode(cur.ct[j / 4].v[j % 4], s_lut[code_index(cur.ct[j / 4].v[j % 4])], atot, tftot);
+                        decode(cur.ct[j / 4].v[j % 4], RRLW_LUT_ENTRY(s_lut, code_index(cur.ct[j / 4].v[j % 4])), atot, tftot);
                         const double bbdtot = fr[j] * (blay + tftot * dplankdn);
                         const double gassrc = bbd[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
@@ -2337,7 +2368,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
             for (int j = 0; j < NGC; j++) {
                 double tfn;
                 const scr_t cj = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
-                decode(cj, s_lut[code_index(cj)], atr[j], tfn);
+                decode(cj, RRLW_LUT_ENTRY(s_lut, code_index(cj)), atr[j], tfn);
                 bbu[j] = fr[j] * (blay + tfn * dplankup);
             }
             if constexpr (CODES2) cq[i & 1] = ldcodes(lev + 2);
@@ -2392,7 +2423,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
                         double atot, tftot;
-                        decode(cur.ct[j / 4].v[j % 4], s_lut[code_index(cur.ct[j / 4].v[j % 4])], atot, tftot);
+                        decode(cur.ct[j / 4].v[j % 4], RRLW_LUT_ENTRY(s_lut, code_index(cur.ct[j / 4].v[j % 4])), atot, tftot);
                         const double bbutot = fr[j] * (blay + tftot * dplankup);
                         const double gassrc = bbu[j] * atr[j];
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
@@ -2590,7 +2621,7 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
 #pragma unroll
             for (int c = 0; c < NC; c++) if (c == slot) ck = cc[k][c];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) e[jj] = s_lut[code_index(ck.v[jj])];
+            for (int jj = 0; jj < 4; jj++) e[jj] = RRLW_LUT_ENTRY(s_lut, code_index(ck.v[jj]));
             {
                 const scr4 nx = ld_c(lev + NC * dir, k);
 #pragma unroll
@@ -2719,6 +2750,171 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
     if constexpr (UP) {
         // ------------------------------------------------------------------ upward: layers lo .. nlay
         if (any_bin) sweep(true_type{}, false_type{}); else sweep(false_type{}, false_type{});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_n1 : PROTOTYPE of the mapping BASELINE.json's north_star names, for cloud-free calls (icld = 0), kept to put a number beside the
+//        production mapping ("north-star mapping"): ONE COLUMN PER WAVEFRONT, G-POINTS ACROSS LANES (three passes over the
+//        152 padded g-slots), Planck / fraction tables in LDS, the transmittance either from the table in LDS or (EXPF) from
+//        __builtin_amdgcn_exp2f, WAVE-REDUCE of the g-point radiances: the reduction covers all 16 bands at once, so the wave writes
+//        the column's FINAL fluxes and heating rates - no per-band partial slabs, no k_flux / k_rates.  It reads k_layer's codes.
+//        Per level the wave does what k_sweepc does once per 64 columns: 16 Planck pairs (one lane per band), the fraction rows, and a
+//        64-lane reduction - which is why it loses (measured: profiles/round2_n1.md).
+// ------------------------------------------------------------------------------------------------
+constexpr int N1_WAVES = 8;                                   // columns per workgroup
+constexpr int N1_PL_BYTES = 16 * 184 * 8, N1_FR_BYTES = 16 * 16 * 16 * 8;
+constexpr int N1_WAVE_BYTES = 16 * 32 + 2 * 608;              // per wave: {blay, dpl, fpl, row} per band; up / down flux per level (<= 603 layers: see n1_max_nlay)
+__host__ __device__ constexpr int n1_lds_bytes(int nlay) { return SWEEP_LUT_BYTES + N1_PL_BYTES + N1_FR_BYTES + N1_WAVES * (16 * 32 + 2 * 8 * (nlay + 1)); }
+
+template <bool IDRV_UNUSED>
+__global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, SweepArgs a, FluxOut out, const double *pz)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const float2 *s_lut = reinterpret_cast<const float2 *>(smem);
+    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);                          // [band][181]
+    double (*s_fr)[16][16] = reinterpret_cast<double (*)[16][16]>(smem + SWEEP_LUT_BYTES + N1_PL_BYTES);    // [band][row][g]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nlay = W.nlay, nct = a.nct;
+    const size_t ncb = W.ncolb;
+    unsigned char *wbase = smem + SWEEP_LUT_BYTES + N1_PL_BYTES + N1_FR_BYTES + (size_t)wv * (16 * 32 + 2 * 8 * (nlay + 1));
+    double *s_pk = reinterpret_cast<double *>(wbase);                    // [band][4]: blay, dpl, fpl, (row index as double)
+    double *s_dn = reinterpret_cast<double *>(wbase + 16 * 32), *s_up = s_dn + (nlay + 1);
+    {   // stage: transmittance table, every band's Planck row and fraction rows
+        const int tid = threadIdx.x, nth = 64 * N1_WAVES;
+#ifndef RRLW_SWEEP_EXPF
+        const double2 *src = reinterpret_cast<const double2 *>(T.stat + T.sl.lutf);
+        double2 *dst = reinterpret_cast<double2 *>(smem);
+        for (int i = tid; i < SWEEP_LUT_BYTES / 16; i += nth) dst[i] = src[i];
+#endif
+        for (int i = tid; i < 16 * 181; i += nth) s_pl[i / 181][i % 181] = T.stat[T.sl.totplnk + i];
+        for (int i = tid; i < 16 * 16 * 16; i += nth) {
+            const int b = i >> 8, r = (i >> 4) & 15, g = i & 15;
+            const bool lo_bin = (LO_BINARY >> b) & 1u, up_bin = (UP_BINARY >> b) & 1u;
+            const int ng = T.band[b].ng, fa = T.band[b].fracrefa, fb = T.band[b].fracrefb;
+            const int na = lo_bin ? 9 : 1, nb = up_bin ? 5 : 1;
+            double v = 0.0;
+            if (g < ng) {
+                if (r < 9) { if (r < na) v = T.ktab[fa + r * ng + g]; }
+                else if (r < 14 && fb >= 0 && r - 9 < nb) v = T.ktab[fb + (r - 9) * ng + g];
+            }
+            s_fr[b][r][g] = v;
+        }
+        __syncthreads();
+    }
+    const int col = blockIdx.x * N1_WAVES + wv;
+    if (col >= a.ncol) return;                      // (whole wave; no barrier follows)
+    const size_t gc = (size_t)a.col0 + col;
+    const int laytrop = W.laytrop[col];
+    // lane -> g-slot of each pass: slot = 64 p + lane of the 152 padded slots (38 quads x 4)
+    int bnd[3], gi[3];
+    double wt[3];
+    size_t coff[3];
+    bool ok[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        const int slot = 64 * p + lane, q = slot >> 2;
+        int b = 0;
+#pragma unroll
+        for (int B = 1; B <= NBND; B++) if (q >= band_qstart(B)) b = B - 1;
+        bnd[p] = b;
+        gi[p] = 4 * (q - band_qstart(b + 1)) + (slot & 3);
+        ok[p] = slot < 4 * NQUAD && gi[p] < T.band[b].ng;
+        gi[p] = min(gi[p], 15);
+        wt[p] = ok[p] ? 0.5 * T.delwave[b] : 0.0;
+        coff[p] = ((size_t)min(q, NQUAD - 1) * nlay * ncb + col) * 4 + (slot & 3);        // + (lev - 1) * ncb * 4
+    }
+    const scr_t *codes = W.scr[S_CODE];
+    // per level: lanes 0..15 (band = lane & 15) publish the band's Planck terms and fraction row
+    const int mb = lane & 15;
+    const bool m_lo_bin = (LO_BINARY >> mb) & 1u, m_up_bin = (UP_BINARY >> mb) & 1u;
+    const int m_base_up = ((UP_ZERO >> mb) & 1u) ? 14 : (((UP_FROM_A >> mb) & 1u) ? 0 : 9);
+    const int m_fwslot = fw_slot(mb + 1);
+    auto publish = [&](int lev, int zlev, bool alt) {
+        const double tl = a.tlay[gc + (size_t)nct * (lev - 1)], tz = a.tlev[gc + (size_t)nct * zlev];
+        const bool lower = lev <= laytrop;
+        unsigned w = 0x10000000u;
+        if (lower ? m_lo_bin : m_up_bin) w = W.fw[((size_t)m_fwslot * nlay + (lev - 1)) * ncb + col];
+        const int r0 = clampi((lower ? 0 : m_base_up) + (int)(w >> 28) - 1, 0, 14);
+        const double fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
+        const double *tp = s_pl[mb];
+        const double blay = planck_at(tp, tp, tl);
+        const double *tq = (alt && mb == 15) ? T.stat + T.sl.totplk16 : tp;        // (istart = 16 is not routed here; kept for symmetry)
+        const double dpl = planck_at(tp, tq, tz) - blay;
+        __builtin_amdgcn_wave_barrier();          // (the level before has read its entries)
+        if (lane < 16) { s_pk[4 * mb] = blay; s_pk[4 * mb + 1] = dpl; s_pk[4 * mb + 2] = fpl; s_pk[4 * mb + 3] = (double)r0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto wave_sum = [&](double v) -> double {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    double rad[3] = {0.0, 0.0, 0.0};
+    auto level = [&](int lev) -> double {
+        double part = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const scr_t cj = ok[p] ? codes[coff[p] + (size_t)(lev - 1) * ncb * 4] : (scr_t)0;
+            double atr, tfn;
+            decode(cj, RRLW_LUT_ENTRY(s_lut, code_index(cj)), atr, tfn);
+            const int b = bnd[p];
+            const double blay = s_pk[4 * b], dpl = s_pk[4 * b + 1], fpl = s_pk[4 * b + 2];
+            const int r0 = (int)s_pk[4 * b + 3];
+            const double f0 = s_fr[b][r0][gi[p]], f1 = s_fr[b][r0 + 1][gi[p]];
+            const double fr = f0 + fpl * (f1 - f0);
+            const double bb = fr * (blay + tfn * dpl);
+            rad[p] = rad[p] + (bb - rad[p]) * atr;
+            part += wt[p] * rad[p];
+        }
+        return wave_sum(part);
+    };
+    // ---- downward
+    if (lane == 0) s_dn[nlay] = 0.0;
+    for (int lev = nlay; lev >= 1; lev--) {
+        publish(lev, lev - 1, false);
+        const double f = level(lev);
+        if (lane == 0) s_dn[lev - 1] = f * T.fluxfac;
+    }
+    // ---- surface
+    {
+        publish(1, 0, false);          // fraction row of layer 1
+        double part = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int b = bnd[p];
+            const double fpl = s_pk[4 * b + 2];
+            const int r0 = (int)s_pk[4 * b + 3];
+            const double f0 = s_fr[b][r0][gi[p]], f1 = s_fr[b][r0 + 1][gi[p]];
+            const double fr = f0 + fpl * (f1 - f0);
+            const double reflect = 1. - a.emis[gc + (size_t)nct * b];
+            const double pb = W.percol[(size_t)(PC_PLANKBND + b) * ncb + col];
+            rad[p] = fr * pb + reflect * rad[p];
+            part += wt[p] * rad[p];
+        }
+        const double f = wave_sum(part);
+        if (lane == 0) s_up[0] = f * T.fluxfac;
+    }
+    // ---- upward
+    for (int lev = 1; lev <= nlay; lev++) {
+        publish(lev, lev, false);
+        const double f = level(lev);
+        if (lane == 0) s_up[lev] = f * T.fluxfac;
+    }
+    // ---- outputs: lanes = levels
+    for (int l0 = 0; l0 <= nlay; l0 += 64) {
+        const int lev = l0 + lane;
+        if (lev <= nlay) {
+            const size_t o = gc + (size_t)nct * lev;
+            const double u = s_up[lev], d = s_dn[lev];
+            out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = u; out.dflxc[o] = d;
+            if (out.fnet) { out.fnet[o] = u - d; out.fnetc[o] = u - d; }
+            if (lev < nlay) {
+                const double h = T.heatfac * ((u - d) - (s_up[lev + 1] - s_dn[lev + 1])) / (pz[o] - pz[o + nct]);
+                out.hr[o] = h; out.hrc[o] = h;
+            }
+        }
     }
 }
 
