@@ -32,6 +32,12 @@ def short_name(k):
     m = re.match(r"(k_colprep|k_cloudscan|k_cloudlay|k_cloud)<\w+>", k)
     if m:
         return m.group(1)
+    m = re.match(r"k_sweepc<(\d+), (\d+), (\w+)>", k)      # (quads per thread, phase); the d(flux)/dT instantiation shares the bench's kernel name
+    if m:
+        return "k_sweepc<%s,%s>" % (m.group(1), m.group(2))
+    m = re.match(r"k_n1<\w+>", k)
+    if m:
+        return "k_n1"
     m = re.match(r"k_sweep<(\d+), (\d+), (\w+)>", k)       # the d(flux)/dT instantiation shares the bench's kernel name
     if m:
         return "k_sweep<%s,%s>" % (m.group(1), m.group(2))
