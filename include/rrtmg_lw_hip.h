@@ -196,7 +196,28 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     double *duflx_dt, double *duflxc_dt, void *stream);
 
 /* Tuning / introspection ------------------------------------------------------------------------- */
-/* Columns processed per internal batch (bounds the device workspace); default 131072 (about 0.2 MB of device workspace per column at 72 layers). */
+/* Aggregation of small calls.  A host model that calls rrtmg_lw per chunk of a few dozen columns (the reference is called that way:
+ * `do iplon = 1, ncol` inside, pcols-sized chunks outside, src/rrtmg_lw_rad.nomcica.f90:472) pays ~0.5 ms of launch latency per call on
+ * the GPU whatever the chunk size.  queue_begin fixes what the chunks share (layer count, flags); queue_add takes one chunk with
+ * exactly the argument list of rrtmg_lw_hip_run_nomcica - it only records the pointers, the arrays must stay valid and unchanged until
+ * the flush; queue_flush packs all queued chunks column-wise into one pinned staging set, runs ONE pass over all their columns and
+ * writes every chunk's outputs (and its icld, reset as rrtmg_lw resets it) back.  Errors of the pass are reported by the flush. */
+int rrtmg_lw_hip_queue_begin(int nlay, int icld, int idrv, int inflglw, int iceflglw, int liqflglw);
+int rrtmg_lw_hip_queue_add(
+    int ncol, int *icld,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt);
+int rrtmg_lw_hip_queue_flush(void);
+/* columns queued since the last flush */
+int rrtmg_lw_hip_queue_columns(void);
+
+/* Columns processed per internal batch (bounds the device workspace); default 262144 (about 0.2 MB of device workspace per column at 72 layers). */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
 /* on = 1: device-pointer entries run k_sweep/k_flux of column batch i on a second stream while k_layer of batch i+1 runs on the
  * caller's stream (second scratch set, +0.1 MB of workspace per column).  Default 0: k_sweep owns a CU (transmittance table in

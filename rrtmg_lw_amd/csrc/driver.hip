@@ -71,6 +71,17 @@ struct State {
 State G;
 std::mutex g_mu;
 
+// aggregation of small calls (rrtmg_lw_hip_queue_*): recorded chunks and the pinned staging set they are packed into
+struct QueuedChunk { int ncol; int *icld; const double *in[23]; double *out[8]; };
+struct ChunkQueue {
+    bool open = false;
+    int nlay = 0, icld = 0, idrv = 0, inflg = 0, iceflg = 0, liqflg = 0;
+    long long ncol = 0;
+    std::vector<QueuedChunk> chunks;
+    double *pinned = nullptr;
+    size_t pinned_doubles = 0;
+} Q;
+
 // The HIP current device is per host thread: an entry called from another thread (an OpenMP host model, a Python worker) must
 // select the device the workspace lives on, and leaves the caller's device selection as it found it.
 struct DeviceGuard {
@@ -853,6 +864,8 @@ void rrtmg_lw_hip_finalize(void)
     (void)hipDeviceSynchronize();
     if (G.ws_base) (void)hipFree(G.ws_base);
     if (G.stage_base) (void)hipFree(G.stage_base);
+    if (Q.pinned) { (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
+    Q.chunks.clear(); Q.ncol = 0; Q.open = false;
     if (G.mask) (void)hipFree(G.mask);
     if (G.d_ktab) (void)hipFree(G.d_ktab);
     if (G.d_stat) (void)hipFree(G.d_stat);
@@ -1156,6 +1169,138 @@ int rrtmg_lw_hip_calibrate_stream(long long bytes)
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "calibration kernel failed: %s", hipGetErrorString(e));
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Aggregation of small calls (include/rrtmg_lw_hip.h): chunks are recorded, packed column-wise into one pinned staging set and
+// solved in one pass through the host-pointer entry.
+// ---------------------------------------------------------------------------------------------------
+}   // extern "C"
+
+namespace {
+// inner extent and number of rows of the 23 inputs ([rows][ncol][inner], run_nomcica's order with tauaer last) and 8 outputs
+void queue_shapes(int nlay, size_t (&in_inner)[23], size_t (&in_rows)[23], size_t (&out_rows)[8])
+{
+    const size_t L = (size_t)nlay;
+    const size_t rows[23] = {L, L + 1, L, L + 1, 1, L, L, L, L, L, L, L, L, L, L, 16, L, L, L, L, L, L, 16 * L};
+    for (int k = 0; k < 23; k++) { in_inner[k] = 1; in_rows[k] = rows[k]; }
+    in_inner[17] = NBND;                      // taucld (16, ncol, nlay)
+    const size_t orows[8] = {L + 1, L + 1, L, L + 1, L + 1, L, L + 1, L + 1};
+    for (int k = 0; k < 8; k++) out_rows[k] = orows[k];
+}
+}   // namespace
+
+extern "C" {
+
+int rrtmg_lw_hip_queue_begin(int nlay, int icld, int idrv, int inflglw, int iceflglw, int liqflglw)
+{
+    ENTRY_LOCK;
+    if (int rc = check_common(1, nlay)) return rc;
+    Q.chunks.clear();
+    Q.ncol = 0;
+    Q.nlay = nlay; Q.icld = icld; Q.idrv = idrv; Q.inflg = inflglw; Q.iceflg = iceflglw; Q.liqflg = liqflglw;
+    Q.open = true;
+    return 0;
+}
+
+int rrtmg_lw_hip_queue_columns(void) { return (int)Q.ncol; }
+
+int rrtmg_lw_hip_queue_add(
+    int ncol, int *icld,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt)
+{
+    ENTRY_LOCK;
+    if (!Q.open) return fail(RRTMG_LW_HIP_EARG, "rrtmg_lw_hip_queue_begin has not been called");
+    if (ncol < 1) return fail(RRTMG_LW_HIP_EARG, "bad chunk size %d", ncol);
+    if (icld && *icld != Q.icld) return fail(RRTMG_LW_HIP_EARG, "chunk icld %d differs from the queue's %d", *icld, Q.icld);
+    QueuedChunk c{ncol, icld,
+                  {play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
+                   cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer},
+                  {uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt}};
+    const int icld_eff = (Q.icld < 0 || Q.icld > 3) ? 2 : Q.icld;
+    for (int k = 0; k < 23; k++) {
+        const bool cloud_arr = k >= 16 && k <= 21;              // inatm reads the cloud arrays only when icld >= 1
+        if (!c.in[k] && !(cloud_arr && icld_eff == 0)) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", k);
+    }
+    for (int k = 0; k < 6; k++) if (!c.out[k]) return fail(RRTMG_LW_HIP_EARG, "null output array");
+    if (Q.idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    if (Q.ncol + ncol > 0x7fffffffLL) return fail(RRTMG_LW_HIP_EARG, "too many queued columns");
+    Q.chunks.push_back(c);
+    Q.ncol += ncol;
+    return 0;
+}
+
+}   // extern "C" (the flush calls rrtmg_lw_hip_run_nomcica, which takes the entry lock itself)
+
+extern "C" int rrtmg_lw_hip_queue_flush(void)
+{
+    size_t in_inner[23], in_rows[23], out_rows[8];
+    double *in_p[23], *out_p[8];
+    long long N;
+    {
+        ENTRY_LOCK;
+        if (!Q.open) return fail(RRTMG_LW_HIP_EARG, "rrtmg_lw_hip_queue_begin has not been called");
+        N = Q.ncol;
+        if (N == 0) return 0;
+        queue_shapes(Q.nlay, in_inner, in_rows, out_rows);
+        size_t tot = 0;
+        for (int k = 0; k < 23; k++) tot += in_inner[k] * in_rows[k] * (size_t)N;
+        for (int k = 0; k < 8; k++) tot += out_rows[k] * (size_t)N;
+        if (Q.pinned_doubles < tot) {
+            if (Q.pinned) { (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
+            HIP_TRY(hipHostMalloc((void **)&Q.pinned, tot * sizeof(double), hipHostMallocDefault));
+            Q.pinned_doubles = tot;
+        }
+        double *p = Q.pinned;
+        for (int k = 0; k < 23; k++) { in_p[k] = p; p += in_inner[k] * in_rows[k] * (size_t)N; }
+        for (int k = 0; k < 8; k++) { out_p[k] = p; p += out_rows[k] * (size_t)N; }
+        // pack: every array is [rows][columns][inner] - row r of a chunk goes to row r of the packed array at the chunk's column offset
+        const bool cloud = !(Q.icld == 0);
+        size_t off = 0;
+        for (const QueuedChunk &c : Q.chunks) {
+            for (int k = 0; k < 23; k++) {
+                const bool cloud_arr = k >= 16 && k <= 21;
+                if (cloud_arr && !cloud) continue;
+                const size_t w = in_inner[k] * (size_t)c.ncol;
+                for (size_t r = 0; r < in_rows[k]; r++)
+                    memcpy(in_p[k] + (r * (size_t)N + off) * in_inner[k], c.in[k] + r * w, w * sizeof(double));
+            }
+            off += (size_t)c.ncol;
+        }
+    }
+    int icld = Q.icld;
+    const bool cloud = !(Q.icld == 0);
+    const int rc = rrtmg_lw_hip_run_nomcica((int)N, Q.nlay, &icld, Q.idrv, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
+                                            in_p[8], in_p[9], in_p[10], in_p[11], in_p[12], in_p[13], in_p[14], in_p[15], Q.inflg, Q.iceflg, Q.liqflg,
+                                            cloud ? in_p[16] : nullptr, cloud ? in_p[17] : nullptr, cloud ? in_p[18] : nullptr, cloud ? in_p[19] : nullptr,
+                                            cloud ? in_p[20] : nullptr, cloud ? in_p[21] : nullptr, in_p[22],
+                                            out_p[0], out_p[1], out_p[2], out_p[3], out_p[4], out_p[5],
+                                            Q.idrv == 1 ? out_p[6] : nullptr, Q.idrv == 1 ? out_p[7] : nullptr);
+    ENTRY_LOCK;
+    if (rc == 0) {
+        size_t off = 0;
+        for (const QueuedChunk &c : Q.chunks) {
+            for (int k = 0; k < 8; k++) {
+                if (!c.out[k] || (k >= 6 && Q.idrv != 1)) continue;
+                for (size_t r = 0; r < out_rows[k]; r++)
+                    memcpy(c.out[k] + r * (size_t)c.ncol, out_p[k] + r * (size_t)N + off, (size_t)c.ncol * sizeof(double));
+            }
+            if (c.icld) *c.icld = icld;
+            off += (size_t)c.ncol;
+        }
+    }
+    Q.chunks.clear();
+    Q.ncol = 0;
+    return rc;
+}
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------------------------
 // McICA flavour

@@ -286,3 +286,29 @@ def test_orography_spread_of_pressure_levels(hip, oracle, icld, lo):
     _compare(got, ref, d["idrv"], f"orography icld={icld}")
     jp = np.floor(36.0 - 5.0 * (np.log(np.array(d["play"])) + 0.04)).astype(int)
     assert (jp.max(axis=0) - jp.min(axis=0)).max() >= 3        # the spread the staging window cannot hold
+
+
+def test_chunk_queue_equals_one_call(hip, oracle):
+    """A host model that hands over ragged chunks of a few dozen columns (rrtmg_lw_hip_queue_*): one aggregated pass gives every chunk
+    exactly what a single call over all columns gives, for rtrnmr with aerosol and dF/dT and for a cloud-free call."""
+    for config, icld in (("aer_idrv", 2), ("cloudy", 0)):
+        ncol, nlay = 333, 40
+        d = make_gcm_inputs(ncol, nlay, config, col0=123)
+        whole = hip.rrtmg_lw_from_dict(d, icld=icld)
+        q = hip.ChunkQueue(nlay, icld, d["idrv"], d["inflglw"], d["iceflglw"], d["liqflglw"])
+        bounds = [0, 1, 17, 64, 65, 200, 333]
+        outs = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            c = {k: (np.asfortranarray(v[:, a:b, :]) if k == "taucld" else np.asfortranarray(v[a:b])) if isinstance(v, np.ndarray) else v
+                 for k, v in d.items()}
+            c["ncol"] = b - a
+            outs.append(q.add(c))
+        assert q.columns() == ncol
+        q.flush()
+        assert q.columns() == 0
+        keys = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if d["idrv"] else ())
+        for (a, b), o in zip(zip(bounds[:-1], bounds[1:]), outs):
+            for k in keys:
+                assert np.array_equal(o[k], whole[k][a:b]), (config, a, k)
+    ref = oracle.rrtmg_lw(ncol, nlay, 0, 0, d)
+    assert np.abs(whole["uflx"] - ref["uflx"]).max() <= TIGHT_FLUX
