@@ -18,12 +18,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _pin(slot):
-    """Pin this worker to one CPU of the affinity mask (one process per core, pinned).  Returns the CPU, or -1
-    when the mask cannot be narrowed (some containers refuse it)."""
+def physical_cpus():
+    """One hardware thread per physical core of the affinity mask (SMT siblings from sysfs; all CPUs when sysfs does not say)."""
+    cpus = sorted(os.sched_getaffinity(0))
+    seen, out = set(), []
+    for c in cpus:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out or cpus
+
+
+def _pin(cpu):
+    """Pin this worker to one CPU (one process per core, pinned).  Returns the CPU, or -1 when the mask cannot be
+    narrowed (some containers refuse it)."""
     try:
-        cpus = sorted(os.sched_getaffinity(0))
-        cpu = cpus[slot % len(cpus)]
         os.sched_setaffinity(0, {cpu})
         return cpu
     except OSError:
@@ -75,9 +88,10 @@ def measure(nlay=72, config="cloudy", cols_per_core=6000, cores=None, sample_col
     kind = "reference" if Reference.available("nomcica") else "port"
     if cores is None:
         cores = usable_cores()
-    # spread the pins over the mask (a 16-CPU quota on a 256-thread box: every 16th hardware thread, distinct physical cores)
-    stride = max(1, len(os.sched_getaffinity(0)) // cores)
-    jobs = [(cols_per_core, nlay, config, i * cols_per_core, kind, i * stride) for i in range(cores)]
+    # one process per PHYSICAL core, spread evenly over the cores of the mask (a 16-CPU quota on a 2 x 64-core box: every 8th core)
+    phys = physical_cpus()
+    stride = max(1, len(phys) // cores)
+    jobs = [(cols_per_core, nlay, config, i * cols_per_core, kind, phys[(i * stride) % len(phys)]) for i in range(cores)]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
         res = list(ex.map(_worker, jobs))
