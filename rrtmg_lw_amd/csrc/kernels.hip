@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 
 // ------------------------------------------------------------------------------------------------
 // k_sweep : the vertical recurrences.  One thread owns NGC consecutive g-points of one band for one column.
-//   MODE 0 clear column set (icld = 0): rtrn/rtrnmr clear branch   src/rrtmg_lw_rtrn.f90:437-466,:497-540
+//   (cloud-free calls, icld = 0, and the layers above the batch's highest cloud are k_sweepc's, below)
 //   MODE 1 rtrn   (random overlap)                                 src/rrtmg_lw_rtrn.f90:361-540
 //   MODE 2 rtrnmr (maximum-random overlap)                         src/rrtmg_lw_rtrnmr.f90:347-738
 //   MODE 3 rtrnmc (McICA: cloud terms per g-point, k_cloudmc)      src/rrtmg_lw_rtrnmc.f90:331-520
@@ -1718,9 +1718,6 @@ constexpr int SWEEP_LV = 4;       // levels per reduction round
 #define RRLW_SWEEP_PF_RTRNMR 1
 #endif
 __host__ __device__ constexpr int sweep_pf(int MODE, bool IDRV) { return MODE == 2 && !IDRV ? RRLW_SWEEP_PF_RTRNMR : RRLW_SWEEP_PF; }
-#ifndef RRLW_SWEEP_WAVES_CLEAR
-#define RRLW_SWEEP_WAVES_CLEAR 4  // waves per SIMD the clear-sky sweep (MODE 0) is compiled for (<= 128 VGPRs: it needs 82-94)
-#endif
 #ifndef RRLW_SWEEP_WAVES_RTRN
 #define RRLW_SWEEP_WAVES_RTRN 4   // MODE 1 (121-123 VGPRs)
 #endif
@@ -1738,30 +1735,24 @@ __host__ __device__ constexpr int sweep_pf(int MODE, bool IDRV) { return MODE ==
 // on the g-point (Planck functions of the level, fraction rows, layer flags, loads of temperatures, loop control: ~40 % of a clear
 // level's instructions at G = 1) over more g-points and give the wave more independent recurrences to overlap; they cost registers
 // (2 per g-point for the clear-sky sweep, 8-10 in the cloudy ones).
-#ifndef RRLW_SWEEP_G_CLEAR
-#define RRLW_SWEEP_G_CLEAR 0      // MODE 0: 0 = all quads of the band in one thread (32 state registers for 16 g-points)
-#endif
 #ifndef RRLW_SWEEP_G_CLOUD
 #define RRLW_SWEEP_G_CLOUD 1      // cloudy modes: quads per thread where it divides NQ
 #endif
 __host__ __device__ constexpr int sweep_g(int NQ, int MODE, bool IDRV)
 {
-    const int want = MODE == 0 ? (RRLW_SWEEP_G_CLEAR == 0 ? NQ : RRLW_SWEEP_G_CLEAR) : RRLW_SWEEP_G_CLOUD;
-    (void)IDRV;
+    const int want = RRLW_SWEEP_G_CLOUD;
+    (void)IDRV; (void)MODE;
     return (want >= 1 && want <= NQ && NQ % want == 0) ? want : 1;
 }
 __host__ __device__ constexpr int sweep_t(int NQ, int MODE, bool IDRV) { return NQ / sweep_g(NQ, MODE, IDRV); }
-#ifndef RRLW_SWEEP_WAVES_CLEAR_G
-#define RRLW_SWEEP_WAVES_CLEAR_G 4   // MODE 0 with more than one quad per thread
-#endif
 #ifndef RRLW_SWEEP_WAVES_CLOUD_G
 #define RRLW_SWEEP_WAVES_CLOUD_G 2   // cloudy modes with more than one quad per thread
 #endif
 __host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV, int G = 1)
 {
-    if (G > 1) return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR_G : RRLW_SWEEP_WAVES_CLOUD_G;
-    if (IDRV) return MODE == 0 ? 4 : 2;       // the d(flux)/dT instantiations carry 32 more registers (clear sky 100-106; rtrnmr spills 170 dwords at 168)
-    return MODE == 0 ? RRLW_SWEEP_WAVES_CLEAR : MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
+    if (G > 1) return RRLW_SWEEP_WAVES_CLOUD_G;
+    if (IDRV) return 2;                       // the d(flux)/dT instantiations carry 32 more registers (rtrnmr spills 170 dwords at 168)
+    return MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
            MODE == 3 ? RRLW_SWEEP_WAVES_MCARR : RRLW_SWEEP_WAVES_MCMASK;
 }
 // column sub-blocks (of 64 columns) per workgroup for bands of NQ quads: one workgroup per CU (the table in LDS) that fills the
@@ -1964,9 +1955,9 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 #endif
     constexpr bool CODES2 = RRLW_SWEEP_CODES2 && PF == 1;
 #ifdef RRLW_SWEEP_EARLY_ALL        // (tuning: rtrnmr at two waves, two slots and early refill 62.7 ms against 51.9 ms at three waves and one slot)
-    constexpr bool EARLY = MODE != 0;
+    constexpr bool EARLY = true;
 #else
-    constexpr bool EARLY = IDRV && MODE != 0;
+    constexpr bool EARLY = IDRV;
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *s_lut = reinterpret_cast<float2 *>(smem);                                              // [NTBL + 1] {1 - exp, tfn}
@@ -2015,7 +2006,8 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
     // The cloudy modes sweep only the layers 1 .. ltop, ltop = the highest layer of the batch that holds cloud in any column: above it
     // k_sweepc<., 1> (downward) and k_sweepc<., 2> (upward) run the clear-sky recurrences with all g-points of a band in one thread, and
     // the radiances at level ltop are handed over through W.hand.
-    const int ltop = MODE == 0 ? nlay : __builtin_amdgcn_readfirstlane(*W.ltop);
+    static_assert(MODE >= 1 && MODE <= 4, "cloud-free calls are k_sweepc's");
+    const int ltop = __builtin_amdgcn_readfirstlane(*W.ltop);
     // W.hand as double2: [stream][quad][column][2]
     auto hand_ptr = [&]() -> double2 * { return reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2; };
 
@@ -2108,7 +2100,6 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
     // (the raw word stays in a vector register until the level that needs it: turning it into a lane mask at once would wait for the
     // load - and, completion being in order, for every prefetch before it - right where it is issued)
     auto ldflag = [&](int lev) -> unsigned {
-        if constexpr (MODE == 0) return 0u;
         return (lev >= 1 && lev <= nlay) ? bload_u32(sFlag + (size_t)lev * ncb, off4) : 0u;
     };
     // the loads of level `lev`: zlev = the interface whose temperature the sweep direction needs, nlev = the next level in sweep
@@ -2129,30 +2120,22 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                 q.tz = bload_f64(tlev + (size_t)nct * zlev, off8);
                 if (any_bin) q.w = bload_u32(sFw + so, off4);
             }
-            if constexpr (MODE != 0) {
-                if ((part & 2) && cloudy) {
+            if ((part & 2) && cloudy) {
 #pragma unroll
-                    for (int k = 0; k < G; k++) q.ct[k] = bload_scr4_nt(sCt + k * qstride + so, off16);
-                    if constexpr (MODE == 1 || MODE == 2) q.cf = bload_f64(cldf + (size_t)nct * (lev - 1), off8);
-                    if constexpr (MODE == 2) q.cfn = (nlev >= 1 && nlev <= nlay) ? bload_f64(cldf + (size_t)nct * (nlev - 1), off8) : 0.0;
-                }
+                for (int k = 0; k < G; k++) q.ct[k] = bload_scr4_nt(sCt + k * qstride + so, off16);
+                if constexpr (MODE == 1 || MODE == 2) q.cf = bload_f64(cldf + (size_t)nct * (lev - 1), off8);
+                if constexpr (MODE == 2) q.cfn = (nlev >= 1 && nlev <= nlay) ? bload_f64(cldf + (size_t)nct * (nlev - 1), off8) : 0.0;
             }
         }
     };
 
-    bool colcloud = false;
-    if constexpr (MODE != 0) colcloud = (bload_u32(sFlag, off4) & 8u) != 0;
+    const bool colcloud = (bload_u32(sFlag, off4) & 8u) != 0;
 
     double radld[NGC], radclrd[NGC], cldrad[NGC], clrrad[NGC], radmr[NGC];
 #pragma unroll
     for (int j = 0; j < NGC; j++) { radld[j] = 0.0; radclrd[j] = 0.0; cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
     bool iclddn = false;
-    if constexpr (MODE == 0) {
-        if (slot == 0 && incol) {   // downward flux at the top level is zero
-            Part2 z{0.0, 0.0};
-            pdn[(size_t)nlay * ncb] = z;
-        }
-    } else {                        // downward radiances at level ltop from k_sweepc<., 1> (zeros when ltop = nlay); clear = total up there
+    {                               // downward radiances at level ltop from k_sweepc<., 1> (zeros when ltop = nlay); clear = total up there
         const double2 *hand = hand_ptr();
 #pragma unroll
         for (int k = 0; k < G; k++) {
@@ -2216,12 +2199,12 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
             if constexpr (CODES2) cq[i & 1] = ldcodes(lev - 2);
             advance_early();
             double dsum = 0.0, dsumc = 0.0;
-            if (MODE == 0 || !cloudy) {
+            if (!cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
                     radld[j] = radld[j] + (bbd[j] - radld[j]) * atr[j];
                     dsum = dsum + radld[j];
-                    if constexpr (MODE != 0) {
+                    {
                         const double upd = radclrd[j] + (bbd[j] - radclrd[j]) * atr[j];
                         radclrd[j] = iclddn ? upd : radld[j];
                         dsumc = dsumc + radclrd[j];
@@ -2229,7 +2212,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                 }
                 if constexpr (MODE == 2) prevcld = false;
             } else {
-                if constexpr (MODE != 0) {
+                {
                     iclddn = true;
                     const double cf = cur.cf;
                     double efcl = 0.0;
@@ -2374,13 +2357,13 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
             if constexpr (CODES2) cq[i & 1] = ldcodes(lev + 2);
             advance_early();
             double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
-            if (MODE == 0 || !cloudy) {
+            if (!cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
                     radlu[j] = radlu[j] + (bbu[j] - radlu[j]) * atr[j];
                     usum = usum + radlu[j];
                     if (idrv) { drad[j] = drad[j] * (1.0 - atr[j]); dusum = dusum + drad[j]; }
-                    if constexpr (MODE != 0) {
+                    {
                         const double upd = radclru[j] + (bbu[j] - radclru[j]) * atr[j];
                         radclru[j] = colcloud ? upd : radlu[j];
                         if (idrv) { dradc[j] = colcloud ? dradc[j] * (1.0 - atr[j]) : drad[j]; dusumc = dusumc + dradc[j]; }
@@ -2389,7 +2372,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                 }
                 if constexpr (MODE == 2) prevcld = false;
             } else {
-                if constexpr (MODE != 0) {
+                {
                     const double cf = cur.cf;
                     double efcl = 0.0;
                     if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
@@ -2465,7 +2448,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
         reduce_round(pup, base, +1);
         if constexpr (idrv) reduce_store(accd, dbase, base, +1);
     }
-    if constexpr (MODE != 0) {          // upward radiances at level ltop for k_sweepc<., 2>
+    {                                   // upward radiances at level ltop for k_sweepc<., 2>
         if (incol) {
             double2 *hand = hand_ptr();
             const size_t hstream = (size_t)NQUAD * ncb * 2;

@@ -312,3 +312,24 @@ def test_chunk_queue_equals_one_call(hip, oracle):
                 assert np.array_equal(o[k], whole[k][a:b]), (config, a, k)
     ref = oracle.rrtmg_lw(ncol, nlay, 0, 0, d)
     assert np.abs(whole["uflx"] - ref["uflx"]).max() <= TIGHT_FLUX
+
+
+def test_north_star_mapping_prototype(hip, oracle):
+    """k_n1 (RRTMG_LW_N1=1 at init): one column per wavefront, g-points across lanes, wave-reduce over all bands, final fluxes and
+    heating rates written by the sweep itself (DESIGN.md, "north-star mapping").  Kept as a measured prototype for cloud-free calls;
+    it must give the oracle's numbers."""
+    import os
+    d = make_gcm_inputs(130, 72, "clear", col0=7)
+    da = make_gcm_inputs(70, 51, "aer_idrv", col0=3)
+    os.environ["RRTMG_LW_N1"] = "1"
+    try:
+        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+        got = hip.rrtmg_lw_from_dict(d, icld=0)
+        gota = hip.rrtmg_lw_from_dict(da, icld=0, idrv=0)           # aerosol, perturbed columns
+    finally:
+        del os.environ["RRTMG_LW_N1"]
+        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+    _compare(got, oracle.rrtmg_lw(130, 72, 0, 0, d), 0, "k_n1 clear 72")
+    _compare(gota, oracle.rrtmg_lw(70, 51, 0, 0, da), 0, "k_n1 aerosol 51")
+    again = hip.rrtmg_lw_from_dict(d, icld=0)                        # the production path, after the switch is off again
+    assert np.abs(again["uflx"] - got["uflx"]).max() <= 1e-9
