@@ -61,11 +61,11 @@ def _gcm_call(fn, ncol, nlay, icld, idrv, d, mcica):
     return rc, out
 
 
-def _column_call(fn, col, istart, iend, iout, icld, idrv, byref_scalars):
+def _column_call(fn, col, istart, iend, iout, icld, idrv, byref_scalars, ngpt=NGPT):
     nl = int(col["nlayers"])
     z = lambda *s: np.zeros(s, order="F")
     outs = [z(nl + 1) for _ in range(10)]
-    taug, fracs = z(nl, NGPT), z(nl, NGPT)
+    taug, fracs = z(nl, ngpt), z(nl, ngpt)
     ncb = C.c_int(0)
     a = dict(pavel=_f(col["pavel"], (nl,)), tavel=_f(col["tavel"], (nl,)), pz=_f(col["pz"], (nl + 1,)),
              tz=_f(col["tz"], (nl + 1,)), semiss=_f(col["semiss"], (NBND,)), coldry=_f(col["coldry"], (nl,)),
@@ -117,8 +117,10 @@ def _column_mc_call(fn, col, sub, istart, iend, iout, icld, idrv):
 class Oracle:
     """The plain-C restatement (oracle/rrtmg_lw_oracle.c)."""
 
-    def __init__(self, kdata=STANDIN_KDATA, cpdair=1004.0, static=STATIC_BLOB):
-        path = os.path.join(HERE, "liboracle.so")
+    def __init__(self, kdata=STANDIN_KDATA, cpdair=1004.0, static=STATIC_BLOB, gpoints=140):
+        """gpoints = 256: the build that keeps every band's 16 original g-points (liboracle_g256.so; non-McICA entries only)."""
+        assert gpoints in (140, 256)
+        path = os.path.join(HERE, "liboracle.so" if gpoints == 140 else "liboracle_g256.so")
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} missing - run `make -C oracle liboracle.so` or __graft_entry__.build()")
         self.lib = C.CDLL(path)
@@ -127,6 +129,8 @@ class Oracle:
         rc = self.lib.orc_init(static.encode(), kdata.encode(), C.c_double(cpdair))
         if rc != 0:
             raise RuntimeError(f"orc_init failed: {self.lib.orc_errmsg().decode()}")
+        self.ngpt = int(self.lib.orc_ngpt())
+        assert self.ngpt == gpoints
 
     def errmsg(self):
         return self.lib.orc_errmsg().decode()
@@ -141,7 +145,7 @@ class Oracle:
     def column(self, col, istart=1, iend=16, iout=0, icld=None, idrv=None):
         icld = int(col["icld"]) if icld is None else icld
         idrv = int(col["idrv"]) if idrv is None else idrv
-        rc, res = _column_call(self.lib.orc_column, col, istart, iend, iout, icld, idrv, False)
+        rc, res = _column_call(self.lib.orc_column, col, istart, iend, iout, icld, idrv, False, self.ngpt)
         if rc != 0:
             raise RuntimeError(f"oracle: {self.errmsg()}")
         return res

@@ -26,7 +26,14 @@
 #include "rrlw_blob.h"
 
 #define NBND 16
+/* -DRRLW_G256: the 256-g-point model the reference keeps as a commented-out alternative (modules/parrrtm.f90:40-41,77-110;
+ * src/rrtmg_lw_init.f90:313-314 "the full 256 g-point set can be restored with ngptlw=256, ngc=16*16, ngn=256*1., etc."):
+ * every band keeps its 16 original g-points, the combination step copies. */
+#ifdef RRLW_G256
+#define NGPT 256
+#else
 #define NGPT 140
+#endif
 #define MG 16
 #define MXLAY 603
 #define NTBL 10000
@@ -38,7 +45,7 @@ static double pref_[59], preflog_[59], tref_[59], chi_mls_[7 * 59];
 static double totplnk_[181 * 16], totplk16_[181], totplnkderiv_[181 * 16], totplk16deriv_[181];
 static double absice0_[2], absice1_[2 * 5], absice2_[43 * 16], absice3_[46 * 16], absliq1_[58 * 16];
 static double abscld1, absliq0;
-static int ngc_[16], ngs_[16], ngm_[256], ngn_[140], ngb_[140], nspa_[16], nspb_[16];
+static int ngc_[16], ngs_[16], ngm_[256], ngn_[256], ngb_[256], nspa_[16], nspb_[16];
 static double wt_[16], delwave_[16], rwgt_[256];
 static double tau_tbl[NTBL + 1], exp_tbl[NTBL + 1], tfn_tbl[NTBL + 1];
 static double bpade, heatfac, oneminus, pi_, fluxfac;
@@ -107,6 +114,10 @@ static int load_static(const char *path)
     GETI("ngc", ngc_, 16); GETI("ngs", ngs_, 16); GETI("ngm", ngm_, 256); GETI("ngn", ngn_, 140);
     GETI("ngb", ngb_, 140); GETI("nspa", nspa_, 16); GETI("nspb", nspb_, 16);
     rrlw_blob_close(&b);
+#ifdef RRLW_G256
+    for (int ib = 0; ib < 16; ib++) { ngc_[ib] = 16; ngs_[ib] = 16 * (ib + 1); }
+    for (int i = 0; i < 256; i++) { ngm_[i] = i % 16 + 1; ngn_[i] = 1; ngb_[i] = i / 16 + 1; }
+#endif
     return 0;
 }
 
@@ -170,6 +181,8 @@ static int load_and_reduce_kdata(const char *path)
     rrlw_blob_close(&b);
     return 0;
 }
+
+int orc_ngpt(void) { return NGPT; }
 
 int orc_init(const char *static_path, const char *kdata_path, double cpdair)
 {
@@ -723,7 +736,7 @@ static double adjcol(double col, double coldry, double chiref, double thresh, do
 /* band 1: :299-392 */
 static void taugb1(col_t *c)
 {
-    const int ng = 10, gs = 0;
+    const int ng = ngc_[0], gs = NGS(0);
     const double *absa = T(1, "ka"), *absb = T(1, "kb"), *ka_mn2 = T(1, "ka_mn2"), *kb_mn2 = T(1, "kb_mn2");
     const double *selfref = T(1, "selfref"), *forref = T(1, "forref"), *fracrefa = T(1, "fracrefa"), *fracrefb = T(1, "fracrefb");
     for (int lay = 1; lay <= c->laytrop; lay++) {
@@ -759,7 +772,7 @@ static void taugb1(col_t *c)
 /* band 2: :395-464 */
 static void taugb2(col_t *c)
 {
-    const int ng = 12, gs = 10;
+    const int ng = ngc_[1], gs = NGS(1);
     const double *absa = T(2, "ka"), *absb = T(2, "kb");
     const double *selfref = T(2, "selfref"), *forref = T(2, "forref"), *fracrefa = T(2, "fracrefa"), *fracrefb = T(2, "fracrefb");
     for (int lay = 1; lay <= c->laytrop; lay++) {
@@ -788,7 +801,7 @@ static void taugb2(col_t *c)
 /* band 3: :467-779 */
 static void taugb3(col_t *c)
 {
-    const int ng = 16, gs = 22;
+    const int ng = ngc_[2], gs = NGS(2);
     const double *absa = T(3, "ka"), *absb = T(3, "kb"), *ka_mn2o = T(3, "ka_mn2o"), *kb_mn2o = T(3, "kb_mn2o");
     const double *selfref = T(3, "selfref"), *forref = T(3, "forref"), *fracrefa = T(3, "fracrefa"), *fracrefb = T(3, "fracrefb");
     double refrat_planck_a = CHI(1, 9) / CHI(2, 9), refrat_planck_b = CHI(1, 13) / CHI(2, 13);
@@ -833,7 +846,7 @@ static void taugb3(col_t *c)
 /* band 4: :782-1038 */
 static void taugb4(col_t *c)
 {
-    const int ng = 14, gs = 38;
+    const int ng = ngc_[3], gs = NGS(3);
     const double *absa = T(4, "ka"), *absb = T(4, "kb");
     const double *selfref = T(4, "selfref"), *forref = T(4, "forref"), *fracrefa = T(4, "fracrefa"), *fracrefb = T(4, "fracrefb");
     double refrat_planck_a = CHI(1, 11) / CHI(2, 11), refrat_planck_b = CHI(3, 13) / CHI(2, 13);
@@ -877,7 +890,7 @@ static void taugb4(col_t *c)
 /* band 5: :1041-1313 */
 static void taugb5(col_t *c)
 {
-    const int ng = 16, gs = 52;
+    const int ng = ngc_[4], gs = NGS(4);
     const double *absa = T(5, "ka"), *absb = T(5, "kb"), *ka_mo3 = T(5, "ka_mo3"), *ccl4 = T(5, "ccl4");
     const double *selfref = T(5, "selfref"), *forref = T(5, "forref"), *fracrefa = T(5, "fracrefa"), *fracrefb = T(5, "fracrefb");
     double refrat_planck_a = CHI(1, 5) / CHI(2, 5), refrat_planck_b = CHI(3, 43) / CHI(2, 43);
@@ -916,7 +929,7 @@ static void taugb5(col_t *c)
 /* band 6: :1316-1399 */
 static void taugb6(col_t *c)
 {
-    const int ng = 8, gs = 68;
+    const int ng = ngc_[5], gs = NGS(5);
     const double *absa = T(6, "ka"), *ka_mco2 = T(6, "ka_mco2"), *cfc11adj = T(6, "cfc11adj"), *cfc12 = T(6, "cfc12");
     const double *selfref = T(6, "selfref"), *forref = T(6, "forref"), *fracrefa = T(6, "fracrefa");
     for (int lay = 1; lay <= c->laytrop; lay++) {
@@ -942,7 +955,7 @@ static void taugb6(col_t *c)
 /* band 7: :1402-1673 */
 static void taugb7(col_t *c)
 {
-    const int ng = 12, gs = 76;
+    const int ng = ngc_[6], gs = NGS(6);
     const double *absa = T(7, "ka"), *absb = T(7, "kb"), *ka_mco2 = T(7, "ka_mco2"), *kb_mco2 = T(7, "kb_mco2");
     const double *selfref = T(7, "selfref"), *forref = T(7, "forref"), *fracrefa = T(7, "fracrefa"), *fracrefb = T(7, "fracrefb");
     double refrat_planck_a = CHI(1, 3) / CHI(3, 3), refrat_m_a = CHI(1, 3) / CHI(3, 3);
@@ -988,7 +1001,7 @@ static void taugb7(col_t *c)
 /* band 8: :1676-1796 */
 static void taugb8(col_t *c)
 {
-    const int ng = 8, gs = 88;
+    const int ng = ngc_[7], gs = NGS(7);
     const double *absa = T(8, "ka"), *absb = T(8, "kb"), *ka_mco2 = T(8, "ka_mco2"), *ka_mn2o = T(8, "ka_mn2o");
     const double *ka_mo3 = T(8, "ka_mo3"), *kb_mco2 = T(8, "kb_mco2"), *kb_mn2o = T(8, "kb_mn2o");
     const double *cfc12 = T(8, "cfc12"), *cfc22adj = T(8, "cfc22adj");
@@ -1026,7 +1039,7 @@ static void taugb8(col_t *c)
 /* band 9: :1799-2059 */
 static void taugb9(col_t *c)
 {
-    const int ng = 12, gs = 96;
+    const int ng = ngc_[8], gs = NGS(8);
     const double *absa = T(9, "ka"), *absb = T(9, "kb"), *ka_mn2o = T(9, "ka_mn2o"), *kb_mn2o = T(9, "kb_mn2o");
     const double *selfref = T(9, "selfref"), *forref = T(9, "forref"), *fracrefa = T(9, "fracrefa"), *fracrefb = T(9, "fracrefb");
     double refrat_planck_a = CHI(1, 9) / CHI(6, 9), refrat_m_a = CHI(1, 3) / CHI(6, 3);
@@ -1065,7 +1078,7 @@ static void taugb9(col_t *c)
 /* band 10: :2062-2126 */
 static void taugb10(col_t *c)
 {
-    const int ng = 6, gs = 108;
+    const int ng = ngc_[9], gs = NGS(9);
     const double *absa = T(10, "ka"), *absb = T(10, "kb");
     const double *selfref = T(10, "selfref"), *forref = T(10, "forref"), *fracrefa = T(10, "fracrefa"), *fracrefb = T(10, "fracrefb");
     for (int lay = 1; lay <= c->laytrop; lay++) {
@@ -1092,7 +1105,7 @@ static void taugb10(col_t *c)
 /* band 11: :2129-2206 */
 static void taugb11(col_t *c)
 {
-    const int ng = 8, gs = 114;
+    const int ng = ngc_[10], gs = NGS(10);
     const double *absa = T(11, "ka"), *absb = T(11, "kb"), *ka_mo2 = T(11, "ka_mo2"), *kb_mo2 = T(11, "kb_mo2");
     const double *selfref = T(11, "selfref"), *forref = T(11, "forref"), *fracrefa = T(11, "fracrefa"), *fracrefb = T(11, "fracrefb");
     for (int lay = 1; lay <= c->laytrop; lay++) {
@@ -1123,7 +1136,7 @@ static void taugb11(col_t *c)
 /* band 12: :2209-2409 */
 static void taugb12(col_t *c)
 {
-    const int ng = 8, gs = 122;
+    const int ng = ngc_[11], gs = NGS(11);
     const double *absa = T(12, "ka");
     const double *selfref = T(12, "selfref"), *forref = T(12, "forref"), *fracrefa = T(12, "fracrefa");
     double refrat_planck_a = CHI(1, 10) / CHI(2, 10);
@@ -1154,7 +1167,7 @@ static void taugb12(col_t *c)
 /* band 13: :2412-2669 */
 static void taugb13(col_t *c)
 {
-    const int ng = 4, gs = 130;
+    const int ng = ngc_[12], gs = NGS(12);
     const double *absa = T(13, "ka"), *ka_mco2 = T(13, "ka_mco2"), *ka_mco = T(13, "ka_mco"), *kb_mo3 = T(13, "kb_mo3");
     const double *selfref = T(13, "selfref"), *forref = T(13, "forref"), *fracrefa = T(13, "fracrefa"), *fracrefb = T(13, "fracrefb");
     double refrat_planck_a = CHI(1, 5) / CHI(4, 5), refrat_m_a = CHI(1, 1) / CHI(4, 1), refrat_m_a3 = CHI(1, 3) / CHI(4, 3);
@@ -1193,7 +1206,7 @@ static void taugb13(col_t *c)
 /* band 14: :2672-2730 */
 static void taugb14(col_t *c)
 {
-    const int ng = 2, gs = 134;
+    const int ng = ngc_[13], gs = NGS(13);
     const double *absa = T(14, "ka"), *absb = T(14, "kb");
     const double *selfref = T(14, "selfref"), *forref = T(14, "forref"), *fracrefa = T(14, "fracrefa"), *fracrefb = T(14, "fracrefb");
     for (int lay = 1; lay <= c->laytrop; lay++) {
@@ -1218,7 +1231,7 @@ static void taugb14(col_t *c)
 /* band 15: :2733-2955 */
 static void taugb15(col_t *c)
 {
-    const int ng = 2, gs = 136;
+    const int ng = ngc_[14], gs = NGS(14);
     const double *absa = T(15, "ka"), *ka_mn2 = T(15, "ka_mn2");
     const double *selfref = T(15, "selfref"), *forref = T(15, "forref"), *fracrefa = T(15, "fracrefa");
     double refrat_planck_a = CHI(4, 1) / CHI(2, 1), refrat_m_a = CHI(4, 1) / CHI(2, 1);
@@ -1252,7 +1265,7 @@ static void taugb15(col_t *c)
 /* band 16: :2958-3164 */
 static void taugb16(col_t *c)
 {
-    const int ng = 2, gs = 138;
+    const int ng = ngc_[15], gs = NGS(15);
     const double *absa = T(16, "ka"), *absb = T(16, "kb");
     const double *selfref = T(16, "selfref"), *forref = T(16, "forref"), *fracrefa = T(16, "fracrefa"), *fracrefb = T(16, "fracrefb");
     double refrat_planck_a = CHI(1, 6) / CHI(6, 6);

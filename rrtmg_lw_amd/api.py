@@ -21,8 +21,12 @@ STANDIN_KDATA = os.path.join(_HERE, "data", "standin.kdata.bin")
 REAL_KDATA = os.path.join(os.path.dirname(_HERE), "data", "rrtmg_lw.kdata.bin")
 NBND, NGPT = 16, 140
 
+LIB_PATH_G256 = os.path.join(_HERE, "librrtmg_lw_hip_g256.so")      # the 256-g-point build (every band keeps its 16 original g-points)
+
 _dp = C.POINTER(C.c_double)
 _lib = None
+_libs = {}
+_gpoints = 140
 _initialised = False
 
 
@@ -31,16 +35,35 @@ class RrtmgLwError(RuntimeError):
 
 
 def lib():
-    """Load librrtmg_lw_hip.so (fails loudly when it has not been built)."""
+    """Load the selected library - librrtmg_lw_hip.so, or librrtmg_lw_hip_g256.so after select_gpoints(256) - and fail loudly when it has
+    not been built.  A process that also uses PyTorch must import torch first (one HIP runtime per process: INTEGRATION.md 2)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RrtmgLwError(f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-        _lib = C.CDLL(LIB_PATH)
-        _lib.rrtmg_lw_hip_last_error.restype = C.c_char_p
-        _lib.rrtmg_lw_hip_workspace_bytes.restype = C.c_longlong
+        path = LIB_PATH if _gpoints == 140 else LIB_PATH_G256
+        if path not in _libs:
+            if not os.path.exists(path):
+                raise RrtmgLwError(f"{path} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+            h = C.CDLL(path)
+            h.rrtmg_lw_hip_last_error.restype = C.c_char_p
+            h.rrtmg_lw_hip_workspace_bytes.restype = C.c_longlong
+            _libs[path] = h
+        _lib = _libs[path]
     return _lib
+
+
+def select_gpoints(n):
+    """Choose the g-point model of the calls that follow: 140 (the reference's shipped model) or 256 (every band keeps its 16 original
+    g-points: the accuracy mode of modules/parrrtm.f90:40-41,77-110; non-McICA entries only).  Each is its own library with its own
+    state: call rrtmg_lw_ini after switching."""
+    global _lib, _gpoints
+    if n not in (140, 256):
+        raise ValueError("gpoints must be 140 or 256")
+    _gpoints, _lib = n, None
+
+
+def gpoints():
+    return int(lib().rrtmg_lw_hip_gpoints())
 
 
 def _check(rc):

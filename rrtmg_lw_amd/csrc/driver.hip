@@ -577,6 +577,13 @@ int ensure_stage(size_t bytes)
     return 0;
 }
 
+// the McICA entries exist for the 140-g-point model only (the sub-column masks are 140 bits; ngptlw sub-columns, src/rrtmg_lw_rad.f90:140)
+int check_mcica_build()
+{
+    if (NGPT != 140) return fail(RRTMG_LW_HIP_EARG, "this library is the 256-g-point build: McICA entries are not available");
+    return 0;
+}
+
 int check_common(int ncol, int nlay)
 {
     if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
@@ -906,6 +913,7 @@ int rrtmg_lw_hip_set_overlap(int on)
 
 long long rrtmg_lw_hip_workspace_bytes(void) { return (long long)(G.ws_bytes + G.stage_bytes); }
 int rrtmg_lw_hip_num_chunks(void) { return NQUAD; }
+int rrtmg_lw_hip_gpoints(void) { return NGPT; }
 
 void rrtmg_lw_hip_profile_begin(void)
 {
@@ -1092,6 +1100,7 @@ int rrtmg_lw_hip_run_columns_mcica(
     double *dtotuflux_dt, double *dtotuclfl_dt)
 {
     ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
     if (int rc = check_common(ncol, nlayers)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
@@ -1319,6 +1328,7 @@ int rrtmg_lw_hip_run_mcica_device(
     const double *reicmcl, const double *relqmcl, const double *tauaer, OUT_PARAMS, void *stream)
 {
     ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.f90:469
@@ -1339,6 +1349,7 @@ int rrtmg_lw_hip_run_mcica(
     const double *reicmcl, const double *relqmcl, const double *tauaer, OUT_PARAMS)
 {
     ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
@@ -1403,6 +1414,7 @@ int rrtmg_lw_hip_mcica_subcol_device(
     double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl, void *stream)
 {
     ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
     if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
     if (icld == 0) return 0;                                      // src/mcica_subcol_gen_lw.f90:265
     hipStream_t s = (hipStream_t)stream;
@@ -1421,6 +1433,7 @@ int rrtmg_lw_hip_mcica_subcol(
     double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl)
 {
     ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
     if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (icld == 0) return 0;
@@ -1470,6 +1483,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS, void *stream)
 {
     ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
@@ -1498,6 +1512,7 @@ int rrtmg_lw_hip_run_mcica_subcol(
     const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS)
 {
     ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace

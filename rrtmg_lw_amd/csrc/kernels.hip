@@ -407,8 +407,13 @@ constexpr Minor NOM = {A_COL, 0, false, 0, 0, 0, 0, 0};
 constexpr Region ZERO_REGION = {K_ZERO, 0, 0, 0, false, false, -1, false, 0, {NOM, NOM, NOM}, 0, {0, 0}, C_NONE, 0};
 
 template <int B> struct BT;
+#ifdef RRLW_G256
+#define BAND_NG(NG_) 16
+#else
+#define BAND_NG(NG_) NG_
+#endif
 #define BAND_TRAITS(B_, NG_, LO, UP) \
-    template <> struct BT<B_> { static constexpr int ng = NG_; static constexpr Region lo = LO; static constexpr Region up = UP; };
+    template <> struct BT<B_> { static constexpr int ng = BAND_NG(NG_); static constexpr Region lo = LO; static constexpr Region up = UP; };
 
 #define R1(...) Region{__VA_ARGS__}
 BAND_TRAITS(1, 10,
@@ -465,7 +470,7 @@ BAND_TRAITS(16, 2,
 #undef R1
 
 __device__ const double kMult4[16] = {1, 1, 1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.88, 0.943, 1, 1};   // taumol :1028-1034
-__device__ const double kMult7[12] = {1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.855, 1};                  // taumol :1664-1669
+__device__ const double kMult7[16] = {1, 1, 1, 1, 1, 0.92, 0.88, 1.07, 1.1, 0.99, 0.855, 1, 1, 1, 1, 1};      // taumol :1664-1669 (g 6-11 of the band, whatever its size)
 
 // setcoef results of one (layer, column), kept in registers by k_layer
 struct LayerCoef {
@@ -540,8 +545,12 @@ __host__ __device__ constexpr int region_minor_base(const Region &R, bool lower,
 
 // g-point "quads": every band is padded to a multiple of 4 g-points; quad q of the 38 holds g-points
 // QG0(band) + 4*(q - QSTART(band)) ... +3 of one band.  Scratch arrays are [array][quad][layer][column][4].
+#ifdef RRLW_G256
+__host__ __device__ constexpr int band_ng(int B) { return B >= 1 ? 16 : 16; }
+#else
 __host__ __device__ constexpr int band_ng(int B) { return B == 1 ? 10 : B == 2 ? 12 : B == 3 ? 16 : B == 4 ? 14 : B == 5 ? 16 : B == 6 ? 8 : B == 7 ? 12 :
                                                     B == 8 ? 8 : B == 9 ? 12 : B == 10 ? 6 : B == 11 ? 8 : B == 12 ? 8 : B == 13 ? 4 : 2; }
+#endif
 __host__ __device__ constexpr int band_nquad(int B) { return (band_ng(B) + 3) / 4; }
 __host__ __device__ constexpr int band_qstart(int B)     // not recursive: a recursive constexpr function that is not folded becomes a
 {                                                       // real device call with a dynamic stack
@@ -557,7 +566,7 @@ __host__ __device__ constexpr int band_g0(int B)      // 0-based first g-point o
     return s;
 }
 static_assert(band_g0(17) == NGPT, "g-point table");
-static_assert(NQUAD == 38, "quad table");
+static_assert(NQUAD == (NGPT == 140 ? 38 : 64), "quad table");
 
 // setcoef's chi_mls ratios and mixing ratios (6 x 59 and 7 x 59 doubles, contiguous in the static buffer): rows_prep reads two or three
 // of them per band and needs them at once; k_layer copies them into LDS once per workgroup (a global read costs ~500 cycles of
@@ -2790,12 +2799,13 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
     const size_t gc = (size_t)a.col0 + col;
     const int laytrop = W.laytrop[col];
     // lane -> g-slot of each pass: slot = 64 p + lane of the 152 padded slots (38 quads x 4)
-    int bnd[3], gi[3];
-    double wt[3];
-    size_t coff[3];
-    bool ok[3];
+    constexpr int NP1 = (4 * NQUAD + 63) / 64;       // passes over the padded g-slots (3 for 152, 4 for 256)
+    int bnd[NP1], gi[NP1];
+    double wt[NP1];
+    size_t coff[NP1];
+    bool ok[NP1];
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
+    for (int p = 0; p < NP1; p++) {
         const int slot = 64 * p + lane, q = slot >> 2;
         int b = 0;
 #pragma unroll
@@ -2834,11 +2844,13 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
         return v;
     };
-    double rad[3] = {0.0, 0.0, 0.0};
+    double rad[NP1];
+#pragma unroll
+    for (int p = 0; p < NP1; p++) rad[p] = 0.0;
     auto level = [&](int lev) -> double {
         double part = 0.0;
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < NP1; p++) {
             const scr_t cj = ok[p] ? codes[coff[p] + (size_t)(lev - 1) * ncb * 4] : (scr_t)0;
             double atr, tfn;
             decode(cj, RRLW_LUT_ENTRY(s_lut, code_index(cj)), atr, tfn);
@@ -2865,7 +2877,7 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
         publish(1, 0, false);          // fraction row of layer 1
         double part = 0.0;
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < NP1; p++) {
             const int b = bnd[p];
             const double fpl = s_pk[4 * b + 2];
             const int r0 = (int)s_pk[4 * b + 3];

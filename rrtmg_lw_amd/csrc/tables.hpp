@@ -22,7 +22,14 @@
 namespace rrlw {
 
 constexpr int NBND = 16;
+// -DRRLW_G256 builds the 256-g-point model the reference keeps as a commented-out alternative (modules/parrrtm.f90:40-41,77-110;
+// src/rrtmg_lw_init.f90:313-314: "the full 256 g-point set can be restored with ngptlw=256, ngc=16*16, ngn=256*1., etc."): every band
+// keeps its 16 original g-points and the combination step copies.  Non-McICA entries only (the sub-column masks are 140 bits).
+#ifdef RRLW_G256
+constexpr int NGPT = 256;
+#else
 constexpr int NGPT = 140;
+#endif
 constexpr int NTBL = 10000;
 
 struct BlobEntry {
@@ -187,6 +194,12 @@ inline bool build_tables(const std::string &static_path, const std::string &kdat
               sb.get_i32("ngn", 140, ngn, err) && sb.get_i32("ngb", 140, ngb, err) &&
               sb.get_i32("nspa", 16, nspa, err) && sb.get_i32("nspb", 16, nspb, err);
     if (!ok) return false;
+#ifdef RRLW_G256
+    ngn.assign(256, 1);
+    ngb.resize(256);
+    for (int b = 0; b < NBND; b++) { ngc[b] = 16; ngs[b] = 16 * (b + 1); }
+    for (int i = 0; i < 256; i++) { ngm[i] = i % 16 + 1; ngb[i] = i / 16 + 1; }
+#endif
 
     // constants: lwdatinit (src/rrtmg_lw_init.f90:243,265,298) and the rad driver (src/rrtmg_lw_rad.f90:451-453)
     T.heatfac = 9.8066 * 8.6400e4 / (cpdair * 1.e2);

@@ -24,6 +24,17 @@ def test_header_symbols_are_exported():
         assert hasattr(lib, n), f"{n} declared in include/rrtmg_lw_hip.h but not exported"
 
 
+def test_g256_library_exports_the_same_symbols():
+    """librrtmg_lw_hip_g256.so is the same translation unit compiled with -DRRLW_G256: same C ABI."""
+    from rrtmg_lw_amd import api
+    assert os.path.exists(api.LIB_PATH_G256), "build it with __graft_entry__.build()"
+    lib = ctypes.CDLL(api.LIB_PATH_G256)
+    for n in _declared():
+        assert hasattr(lib, n), n
+    assert lib.rrtmg_lw_hip_gpoints() == 256
+    assert api.lib().rrtmg_lw_hip_gpoints() == 140
+
+
 def test_no_device_is_a_loud_error():
     import torch
     if torch.cuda.is_available():
