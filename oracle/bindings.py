@@ -208,6 +208,7 @@ class Reference:
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.flavour = flavour
+        self.ngpt = 256 if flavour.endswith("_g256") else NGPT          # "nomcica_g256": the reference's own 256-g-point parameters (oracle/patch_g256.py)
         self.lib = C.CDLL(path)
         kb = kdata.encode()
         self.lib.ref_set_kdata_path(kb, C.c_int(len(kb)))
@@ -224,7 +225,7 @@ class Reference:
     def column(self, col, istart=1, iend=16, iout=0, icld=None, idrv=None):
         icld = int(col["icld"]) if icld is None else icld
         idrv = int(col["idrv"]) if idrv is None else idrv
-        _, res = _column_call(self.lib.ref_column, col, istart, iend, iout, icld, idrv, True)
+        _, res = _column_call(self.lib.ref_column, col, istart, iend, iout, icld, idrv, True, self.ngpt)
         return res
 
     def column_mc(self, col, sub, istart=1, iend=16, iout=0, icld=None, idrv=None):

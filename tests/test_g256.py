@@ -1,7 +1,12 @@
 """The 256-g-point build (librrtmg_lw_hip_g256.so, -DRRLW_G256): every band keeps its 16 original g-points - the accuracy mode the reference
-keeps as a commented-out alternative (modules/parrrtm.f90:40-41,77-110; src/rrtmg_lw_init.f90:313-314).  Checked against the oracle built
-the same way (oracle/liboracle_g256.so); the reference's statement about the reduction ("within 0.5 W m-2", README.md:19 of the reference)
-needs real k-data - with the stand-in tables the two models merely have to be close."""
+keeps as a commented-out alternative (modules/parrrtm.f90:40-41,77-110; src/rrtmg_lw_init.f90:313-314).  Pinned three ways:
+ * tests/golden/ref_g256_*.npz - outputs of the reference's own Fortran built in that configuration (oracle/patch_g256.py switches its
+   commented-out parameters on; tools/gen_ref_fixtures.py --g256) - against the oracle (CPU) and against the HIP library (GPU);
+ * live against oracle/_ref/libref_nomcica_g256.so where that build is present;
+ * HIP vs the oracle built the same way (oracle/liboracle_g256.so) on larger inputs.
+The reference's statement about the reduction ("within 0.5 W m-2", README.md:19 of the reference) needs real k-data - with the stand-in
+tables the two models merely have to be close."""
+import glob
 import os
 
 import numpy as np
@@ -25,6 +30,69 @@ def test_oracle_g256_keeps_sixteen_points_per_band():
     o140 = Oracle().column(col)
     assert np.abs(r["totuflux"] - o140["totuflux"]).max() < 5.0          # stand-in tables: close, not equal
     assert np.abs(r["totuflux"][0] - o140["totuflux"][0]) < 1e-3         # surface emission does not depend on the g-point set
+
+
+COL_KEYS = ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc")
+GCM_FIX = sorted(glob.glob(os.path.join(G, "ref_g256_gcm_*.npz")))
+COL_FIX = sorted(glob.glob(os.path.join(G, "ref_g256_col_*.npz")))
+ORACLE_TOL = 5e-6        # as tests/test_oracle_vs_ref.py
+
+
+def _fixture_column(f):
+    j = lambda n: os.path.join(G, n) if n else None
+    return read_input_rrtm(j(str(f["inp"])), j(str(f["cld"])), j(str(f["aer"])))
+
+
+def _fixture_bands(f):
+    return sorted(int(k[1:-3]) for k in f.files if k.startswith("b") and k.endswith("_up"))
+
+
+@pytest.mark.parametrize("path", GCM_FIX, ids=os.path.basename)
+def test_oracle_g256_matches_reference_gcm_fixture(path):
+    from oracle.bindings import Oracle
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
+    o = Oracle(gpoints=256).rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+    assert o["icld"] == int(f["icld_out"])
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if d["idrv"] else ()):
+        assert np.abs(o[k] - f[k]).max() <= ORACLE_TOL, k
+
+
+@pytest.mark.parametrize("path", COL_FIX, ids=os.path.basename)
+def test_oracle_g256_matches_reference_column_fixture(path):
+    from oracle.bindings import Oracle
+    f = np.load(path)
+    col = _fixture_column(f)
+    orc = Oracle(gpoints=256)
+    o = orc.column(col)
+    assert o["taug"].shape[1] == 256
+    assert np.allclose(o["taug"], f["taug"], rtol=1e-6, atol=0)       # (stored as float32)
+    assert np.allclose(o["fracs"], f["fracs"], rtol=1e-6, atol=0)
+    for k in COL_KEYS:
+        assert np.abs(o[k] - f[k]).max() <= ORACLE_TOL, k
+    for b in _fixture_bands(f):
+        ob = orc.column(col, b, b, 99)
+        for k, fk in (("totuflux", "up"), ("totdflux", "dn"), ("htr", "htr")):
+            assert np.abs(ob[k] - f[f"b{b}_{fk}"]).max() <= ORACLE_TOL, (b, k)
+
+
+def test_oracle_g256_matches_live_reference_build():
+    """Where oracle/_ref/libref_nomcica_g256.so exists (built from /root/reference by oracle/Makefile), a case the fixtures do not hold."""
+    from oracle import bindings
+    if not os.path.exists(os.path.join(os.path.dirname(bindings.__file__), "_ref", "libref_nomcica_g256.so")):
+        pytest.skip("reference 256-g-point build not present")
+    ref, orc = bindings.Reference("nomcica_g256"), bindings.Oracle(gpoints=256)
+    d = make_gcm_inputs(10, 45, "cloudy", col0=99)
+    a, b = ref.rrtmg_lw(10, 45, 3, 0, d), orc.rrtmg_lw(10, 45, 3, 0, d)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.abs(a[k] - b[k]).max() <= ORACLE_TOL, k
+    col = read_input_rrtm(os.path.join(G, "input_rrtm_TROP-clr"))
+    a, b = ref.column(col), orc.column(col)
+    assert a["taug"].shape == b["taug"].shape == (col["nlayers"], 256)
+    assert np.allclose(a["taug"], b["taug"], rtol=1e-12, atol=0) and np.allclose(a["fracs"], b["fracs"], rtol=1e-12, atol=0)
+    for k in COL_KEYS:
+        assert np.abs(a[k] - b[k]).max() <= ORACLE_TOL, k
 
 
 @pytest.fixture()
@@ -69,3 +137,36 @@ def test_g256_columns_and_mcica_refusal(hip256):
     d = make_gcm_inputs(64, 40, "cloudy")
     with pytest.raises(hip256.RrtmgLwError, match="256-g-point build"):
         hip256.mcica_subcol_lw(64, 40, 2, 1, 0, d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"], d["reliq"], d["taucld"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GCM_FIX, ids=os.path.basename)
+def test_g256_gcm_entry_matches_reference_fixture(hip256, path):
+    """HIP (256-g library) against numbers the reference's own 256-g-point build produced - no oracle in between."""
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
+    got = hip256.rrtmg_lw_from_dict(d, icld=icld)
+    assert got["icld"] == int(f["icld_out"])
+    dflux = max(np.abs(got[k] - f[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
+    dhr = max(np.abs(got[k] - f[k]).max() for k in ("hr", "hrc"))
+    print(f"{os.path.basename(path)}: HIP-256 vs reference-256 fixture max|dflux|={dflux:.3e} max|dhr|={dhr:.3e}")
+    assert dflux <= 0.01 and dhr <= 0.001             # BASELINE.json north_star
+    assert dflux <= 5e-5 and dhr <= 5e-5              # regression bar
+    if d["idrv"]:
+        assert max(np.abs(got[k] - f[k]).max() for k in ("duflx_dt", "duflxc_dt")) <= 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", COL_FIX, ids=os.path.basename)
+def test_g256_prepared_columns_match_reference_fixture(hip256, path):
+    f = np.load(path)
+    col = _fixture_column(f)
+    got = hip256.run_columns([col], 1, 16)
+    for k in COL_KEYS:
+        dv = np.abs(got[k][0] - f[k]).max()
+        assert dv <= (0.001 if k.startswith("htr") else 0.01) and dv <= 5e-5, k
+    for b in _fixture_bands(f):
+        gb = hip256.run_columns([col], b, b)
+        for k, fk in (("totuflux", "up"), ("totdflux", "dn"), ("htr", "htr")):
+            assert np.abs(gb[k][0] - f[f"b{b}_{fk}"]).max() <= 5e-5, (b, k)

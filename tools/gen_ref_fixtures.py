@@ -40,7 +40,34 @@ COL_CASES = [  # name, input, cloud file, aerosol file
 ]
 
 
+G256_GCM_CASES = [("clear72", "clear", 4, 72, 0), ("cloudy72_mr", "cloudy", 16, 72, 2), ("aer60_rnd", "aer_idrv", 8, 60, 1)]
+G256_COL_CASES = [c for c in COL_CASES if c[0] in ("MLS-clr", "MLS-cld5-icld2", "SAW-clr")]
+COL_KEYS = ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc", "dtotuflux_dt", "dtotuclfl_dt")
+
+
+def g256():
+    """ref_g256_*.npz: the reference's own 256-g-point configuration (oracle/patch_g256.py: its commented-out parameters switched on)."""
+    ref = Reference("nomcica_g256")
+    for name, cfg, ncol, nlay, icld in G256_GCM_CASES:
+        d = make_gcm_inputs(ncol, nlay, cfg, col0=4242)
+        o = ref.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+        np.savez_compressed(os.path.join(G, f"ref_g256_gcm_{name}.npz"), config=cfg, ncol=ncol, nlay=nlay, icld=icld, col0=4242,
+                            icld_out=o["icld"], **{k: o[k] for k in OUT_KEYS})
+    for name, inp, cld, aer in G256_COL_CASES:
+        col = read_input_rrtm(os.path.join(G, inp), os.path.join(G, cld) if cld else None, os.path.join(G, aer) if aer else None)
+        o = ref.column(col)
+        bands = {}
+        for b in (1, 6, 13, 16):
+            ob = ref.column(col, b, b, 99)
+            bands.update({f"b{b}_up": ob["totuflux"], f"b{b}_dn": ob["totdflux"], f"b{b}_htr": ob["htr"]})
+        np.savez_compressed(os.path.join(G, f"ref_g256_col_{name}.npz"), inp=inp, cld=cld or "", aer=aer or "",
+                            taug=o["taug"].astype(np.float32), fracs=o["fracs"].astype(np.float32), **{k: o[k] for k in COL_KEYS}, **bands)
+    print("wrote 256-g-point fixtures to", G)
+
+
 def main():
+    if "--g256" in sys.argv:        # only the 256-g-point fixtures (the others are left untouched)
+        return g256()
     ref = Reference("nomcica")
     for name, cfg, ncol, nlay, icld in GCM_CASES:
         d = make_gcm_inputs(ncol, nlay, cfg, col0=4242)
