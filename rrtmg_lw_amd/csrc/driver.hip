@@ -185,11 +185,11 @@ int sweep_attr_one()
 template <int Q>
 int sweepc_attr_one()
 {
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     return 0;
 }
 template <int M>
@@ -230,6 +230,10 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     std::vector<Item> items = {
         {(void **)&W.pdn, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.pup, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.gdn1, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(double)},
+        {(void **)&W.gup1, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(double)},
+        {(void **)&W.gup, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.gdp, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.dpart, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
     };
     const bool two_scr = G.split_sweep;
@@ -422,12 +426,25 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     for (int nq = 1; nq <= 4; nq++)
         for (int B = 1; B <= NBND; B++)
             if (band_nquad(B) == nq && B >= istart && B <= iend) lists[nq] |= (unsigned long long)(B - 1) << (4 * nbs[nq]++);
+    // k_sweepc's groups: the bands of a class, at most sweepc_group_cap of them per workgroup
+    FluxGroups fg{};
+    int gq[NGROUP_MAX];
+    for (int nq = 4; nq >= 1; nq--) {
+        const int cap = sweepc_group_cap(nq);
+        for (int k0 = 0; k0 < nbs[nq]; k0 += cap) {
+            if (fg.n >= NGROUP_MAX) return fail(RRTMG_LW_HIP_EARG, "internal: more than %d sweep groups", NGROUP_MAX);
+            const int nbg = std::min(cap, nbs[nq] - k0);
+            fg.nb[fg.n] = nbg;
+            fg.bands[fg.n] = (lists[nq] >> (4 * k0)) & (nbg >= 16 ? ~0ull : ((1ull << (4 * nbg)) - 1ull));
+            gq[fg.n++] = nq;
+        }
+    }
 #define SWEEPC_I(Q, PH, I)                                                                                           \
     do {                                                                                                             \
-        const int ns = sweepc_ns(Q, PH, I);                                                                          \
-        sa.ncb = (nb + 64 * ns - 1) / (64 * ns);                                                                     \
-        const dim3 sgrid((unsigned)(((sa.ncb + 7) / 8) * 8 * sa.nbands)), sblock(64, 1, ns);                         \
-        LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I>), sgrid, sblock, SWEEPC_LDS_BYTES, s, G.D, Wk, sa); \
+        const int nsb = sweepc_nsb(Q, PH, I, sa.nbands);                                                             \
+        sa.ncb = (nb + 64 * nsb - 1) / (64 * nsb);                                                                   \
+        const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands, nsb);                                              \
+        LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I>), sgrid, sblock, sweepc_lds_bytes(PH, I, sa.nbands, nsb), s, G.D, Wk, sa); \
     } while (0)
 #define SWEEPC(Q, PH) do { if (idrv == 1 && PH != 1) SWEEPC_I(Q, PH, true); else SWEEPC_I(Q, PH, false); } while (0)
 #define SWEEPC_Q(PH) do { if (nq == 4) SWEEPC(4, PH); else if (nq == 3) SWEEPC(3, PH); else if (nq == 2) SWEEPC(2, PH); else SWEEPC(1, PH); } while (0)
@@ -442,14 +459,26 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #define SWEEP_MODE(Q) do { if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q); } while (0)
 #define SWEEP_Q() do { if (nq == 4) SWEEP_MODE(4); else if (nq == 3) SWEEP_MODE(3); else if (nq == 2) SWEEP_MODE(2); else SWEEP_MODE(1); } while (0)
     for (int phase = 0; phase < 3; phase++) {
-        for (int nq = 4; nq >= 1; nq--) {
-            if (nbs[nq] == 0) continue;
-            sa.bands = lists[nq];
-            sa.nbands = nbs[nq];
-            const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;     // (shadows the function's stream for the launch macros)
-            if (mode == 0) { if (phase == 0) SWEEPC_Q(0); }
+        if (phase == 1) {                           // cloud zone: one launch per class of bands
+            if (mode == 0) continue;
+            for (int nq = 4; nq >= 1; nq--) {
+                if (nbs[nq] == 0) continue;
+                sa.bands = lists[nq];
+                sa.nbands = nbs[nq];
+                const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;     // (shadows the function's stream for the launch macros)
+                SWEEP_Q();
+            }
+            continue;
+        }
+        if (mode == 0 && phase == 2) continue;
+        for (int g = 0; g < fg.n; g++) {            // above the clouds (or a cloud-free call): one launch per group
+            const int nq = gq[g];
+            sa.bands = fg.bands[g];
+            sa.nbands = fg.nb[g];
+            sa.group = g;
+            const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;
+            if (mode == 0) SWEEPC_Q(0);
             else if (phase == 0) SWEEPC_Q(1);
-            else if (phase == 1) SWEEP_Q();
             else SWEEPC_Q(2);
         }
     }
@@ -467,7 +496,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         }
     }
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
-    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, istart, iend);
+    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg);
     LAUNCH("k_rates", k_rates, rgrid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));

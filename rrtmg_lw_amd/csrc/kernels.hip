@@ -80,6 +80,11 @@ struct Workspace {
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
     unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
     Part2 *pdn, *pup;   // [16 bands][nlay+1][ncolb]
+    // k_sweepc's partials, summed over the bands of a GROUP (bands with the same number of quads, swept by one workgroup and added in
+    // LDS): [NGROUP_MAX][nlay+1][ncolb].  gdn1 / gup1: 8 bytes where the clear-sky stream equals the total one (downward at and above the
+    // batch's highest cloud, both directions of a cloud-free call); gup / gdp {total, clear}: upward above the clouds, d(flux)/dT
+    double *gdn1, *gup1;
+    Part2 *gup, *gdp;
     Part2 *dpart;       // [16 bands][nlay+1][ncolb]  (idrv = 1)
     int *err;           // [1] first physics error code
     // McICA (rtrnmc): per-g-point cloud terms, written by k_cloudmc
@@ -1708,6 +1713,7 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 struct SweepArgs {
     unsigned long long bands;  // the launch's bands (all with the same number of quads), one nibble (band - 1) each
     int nbands, ncb;           // number of those bands, number of column blocks (workgroups per band)
+    int group;                 // k_sweepc: index of the group's partial slabs (W.gdn1 ..)
     int ncol, col0, nct, idrv;
     int istart, iend;          // only bands in [istart, iend] are swept
     const double *emis;        // semiss (nct,16)
@@ -1908,10 +1914,8 @@ __device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool 
 // LDS tables of a sweep workgroup (one band): the transmittance table as float pairs {1 - exp, tfn}, the band's row of totplnk (and band
 // 16's, for the istart = 16 variant of setcoef :233-246), its Planck-fraction rows (0-8 fracrefa, 9-13 fracrefb, 14-15 zeros).  Ends
 // with a barrier.
-__device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned char *smem, int B, bool alt16, bool lo_bin, bool up_bin, int tid, int nth)
+__device__ __forceinline__ void sweep_stage_lut(const DevTables &T, unsigned char *smem, int tid, int nth)
 {
-    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);
-    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);
     const double2 *src = reinterpret_cast<const double2 *>(T.stat + T.sl.lutf);
     double2 *dst = reinterpret_cast<double2 *>(smem);
     // (loads first, then the LDS writes, eight at a time: a plain copy loop waits for every load before it issues the next)
@@ -1927,6 +1931,11 @@ __device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned 
 #pragma unroll
         for (int k = 0; k < 8; k++) if (i0 + k * nth < NLUT) dst[i0 + k * nth] = v[k];
     }
+}
+// one band's Planck integrals and Planck-fraction rows
+__device__ __forceinline__ void sweep_stage_band(const DevTables &T, double (*s_pl)[184], double (*s_fr)[16], int B, bool alt16, bool lo_bin, bool up_bin,
+                                                 int tid, int nth)
+{
     const double *tp = alt16 ? T.stat + T.sl.totplk16 : T.stat + T.sl.totplnk + 181 * (B - 1);
     const double *tq = T.stat + T.sl.totplnk + 181 * 15;
     for (int i = tid; i < 181; i += nth) { s_pl[0][i] = tp[i]; s_pl[1][i] = tq[i]; }
@@ -1941,6 +1950,12 @@ __device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned 
         }
         s_fr[r][g] = v;
     }
+}
+__device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned char *smem, int B, bool alt16, bool lo_bin, bool up_bin, int tid, int nth)
+{
+    sweep_stage_lut(T, smem, tid, nth);
+    sweep_stage_band(T, reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES), reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES),
+                     B, alt16, lo_bin, up_bin, tid, nth);
     __syncthreads();
 }
 
@@ -2489,28 +2504,50 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 // waves per SIMD each instantiation is compiled for = what its registers allow without spilling (a spilled register is reloaded with a
 // scratch load, which counts as a vector-memory operation: its wait drains every prefetch in flight), at most 4 (one workgroup of
 // <= 1024 threads per CU: the transmittance table takes half of the LDS).  Register needs, unconstrained, by quads per thread 4 / 3 / 2 / 1:
-//   phase 1                       132 112  96  70
-//   phase 0                       218 154 124  78
-//   phase 2, phase 0 with d/dT    256+ 232 164  96
-//   phase 2 with d/dT             256+ 256+ 238 126
+//   phase 1                       154 148 102  84
+//   phase 0                       247 171 147 106
+//   phase 2                       256+ 222 172 102
+//   phase 0 with d/dT             250 199 148 105
+//   phase 2 with d/dT             256+ 256+ 241 132
 #ifndef RRLW_SWEEPC_WAVES_CAP
 #define RRLW_SWEEPC_WAVES_CAP 4
 #endif
 __host__ __device__ constexpr int sweepc_waves(int NQ, int PHASE, bool IDRV)
 {
     const int row = PHASE == 1 ? 0 : (PHASE == 0 && !IDRV) ? 1 : (PHASE == 2 && IDRV) ? 3 : 2;
-    const int tab[4][4] = {{7, 5, 4, 3}, {6, 4, 3, 2}, {5, 3, 2, 1}, {4, 2, 1, 1}};      // [row][NQ - 1]
+    const int tab[4][4] = {{7, 5, 4, 3}, {6, 3, 2, 2}, {5, 3, 2, 1}, {3, 2, 1, 1}};      // [row][NQ - 1]
     const int w = tab[row][NQ - 1];
     return w < RRLW_SWEEPC_WAVES_CAP ? w : RRLW_SWEEPC_WAVES_CAP;
 }
-__host__ __device__ constexpr int sweepc_ns(int NQ, int PHASE, bool IDRV) { return 4 * sweepc_waves(NQ, PHASE, IDRV); }      // waves (64-column blocks) per workgroup = per CU
-constexpr int SWEEPC_LDS_BYTES = SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES;
+// A workgroup = the bands of one GROUP (threadIdx.y; all with NQ quads) x column sub-blocks of 64 (threadIdx.z), one workgroup per CU
+// (the transmittance table takes half of the LDS).  The per-level partials of the group's bands are added in LDS, in the order of the
+// group's band list, every RRLW_SWEEPC_CODES levels: one 8- or 16-byte partial per group, level and column goes to HBM instead of one
+// per band (16 bands -> 4 groups: the partial slabs were a quarter of this kernel's traffic and all of k_flux's).
+constexpr int NGROUP_MAX = 8;
+constexpr int SWEEPC_BAND_BYTES = SWEEP_PL_BYTES + SWEEP_FR_BYTES;
+// values per band, level and column in the reduction buffer: total [, clear] [, their d/dT]
+__host__ __device__ constexpr int sweepc_nval(int PHASE, bool IDRV) { return (PHASE == 2 ? 2 : 1) * ((IDRV && PHASE != 1) ? 2 : 1); }
 #ifndef RRLW_SWEEPC_QUAD_BARRIER
 #define RRLW_SWEEPC_QUAD_BARRIER 0   // 1: keep the quads of a level apart in the instruction schedule (fewer registers, less overlap; measured slower)
 #endif
 #ifndef RRLW_SWEEPC_CODES
 #define RRLW_SWEEPC_CODES 2       // code slots: levels of cell codes in flight (the codes are the one HBM stream of the sweep; 4 registers per quad and slot)
 #endif
+__host__ __device__ constexpr int sweepc_lds_bytes(int PHASE, bool IDRV, int nb, int nsb)
+{
+    return SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES + 2 * sweepc_nval(PHASE, IDRV) * nb * RRLW_SWEEPC_CODES * nsb * 64 * 8;
+}
+constexpr int SWEEPC_LDS_MAX = 160 * 1024;
+// bands per group: what fits the wave slots of the most register-hungry instantiation (phase 2 with d/dT)
+__host__ __device__ constexpr int sweepc_group_cap(int NQ) { return 4 * sweepc_waves(NQ, 2, true) < 5 ? 4 * sweepc_waves(NQ, 2, true) : 5; }
+// column sub-blocks per workgroup for a group of nb bands
+__host__ __device__ constexpr int sweepc_nsb(int NQ, int PHASE, bool IDRV, int nb)
+{
+    int nsb = 4 * sweepc_waves(NQ, PHASE, IDRV) / nb;
+    if (nsb < 1) nsb = 1;
+    while (nsb > 1 && sweepc_lds_bytes(PHASE, IDRV, nb, nsb) > SWEEPC_LDS_MAX) nsb--;
+    return nsb;
+}
 
 // One slot of the rolling prefetch.  Every load is issued on every path (rows clamped to 1 .. nlay instead of skipped): the compiler can
 // then count the loads in flight behind the one it needs and wait with vmcnt(N) instead of vmcnt(0) - vector-memory operations complete
@@ -2518,21 +2555,23 @@ constexpr int SWEEPC_LDS_BYTES = SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYT
 template <int G> struct SweepcLev { double tl, tz; unsigned w; };
 
 template <int NQ, int PHASE, bool IDRV>
-__global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, PHASE, IDRV)) void k_sweepc(DevTables T, Workspace W, SweepArgs a)
+__global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(NQ, PHASE, IDRV)) void k_sweepc(DevTables T, Workspace W, SweepArgs a)
 {
-    constexpr int G = NQ, NG = 4 * G, NS = sweepc_ns(NQ, PHASE, IDRV), NC = RRLW_SWEEPC_CODES;
+    constexpr int G = NQ, NG = 4 * G, NC = RRLW_SWEEPC_CODES;
     constexpr bool DOWN = PHASE != 2, UP = PHASE != 1, TWO = PHASE == 2;       // TWO: total and clear-sky streams differ
+    constexpr int NVAL = sweepc_nval(PHASE, IDRV);
     extern __shared__ __align__(16) unsigned char smem[];
+    // (a wave = 64 consecutive threadIdx.x of one (y, z): band and sub-block are wave-uniform - made scalar, so that everything derived
+    // from the band, buffer descriptors included, lives in scalar registers)
+    const int tx = threadIdx.x, bi = __builtin_amdgcn_readfirstlane(threadIdx.y), sub = __builtin_amdgcn_readfirstlane(threadIdx.z);
+    const int nb = blockDim.y, nsb = blockDim.z, ncw = 64 * nsb;                // bands of the group, column sub-blocks, columns of the workgroup
     const float2 *s_lut = reinterpret_cast<const float2 *>(smem);
-    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);
-    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);
-    const int tx = threadIdx.x, sub = threadIdx.z;
-    const int wq = blockIdx.x >> 3;                                            // (workgroup -> (column block, band) as in k_sweep: XCD-aware)
-    const int cblock = (wq / a.nbands) * 8 + (blockIdx.x & 7);
-    if (cblock >= a.ncb) return;
-    const int col = (cblock * NS + sub) * 64 + tx;
-    const int B = (int)((a.bands >> (4 * (wq % a.nbands))) & 15ull) + 1;
-    if (B < a.istart || B > a.iend) return;
+    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES);
+    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES + SWEEP_PL_BYTES);
+    double *red = reinterpret_cast<double *>(smem + SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES);      // [2][NVAL][nb][NC][ncw]
+    const int cblock = blockIdx.x;
+    const int col = (cblock * nsb + sub) * 64 + tx;
+    const int B = (int)((a.bands >> (4 * bi)) & 15ull) + 1;
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;
     const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B));
@@ -2544,7 +2583,9 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
     const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
     const bool any_bin = lo_bin || up_bin;
     const int base_up = ((UP_ZERO >> (B - 1)) & 1u) ? 14 : (((UP_FROM_A >> (B - 1)) & 1u) ? 0 : 9);
-    sweep_stage_tables(T, smem, B, alt16, lo_bin, up_bin, sub * 64 + tx, 64 * NS);
+    sweep_stage_lut(T, smem, (sub * nb + bi) * 64 + tx, 64 * nb * nsb);
+    sweep_stage_band(T, s_pl, s_fr, B, alt16, lo_bin, up_bin, sub * 64 + tx, ncw);
+    __syncthreads();
     const int lo = PHASE == 0 ? 1 : __builtin_amdgcn_readfirstlane(*W.ltop) + 1;       // layers lo .. nlay
     const size_t qstride = (size_t)nlay * ncb;
     const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)quad * qstride;
@@ -2552,9 +2593,11 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
     const double *__restrict__ tlay = a.tlay + a.col0;
     const double *__restrict__ tlev = a.tlev + a.col0;
     const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
-    Part2 *__restrict__ pdn = W.pdn + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
-    Part2 *__restrict__ pup = W.pup + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
-    Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    const size_t gslab = (size_t)a.group * (nlay + 1) * ncb + col;
+    double *__restrict__ gdn1 = W.gdn1 + gslab;
+    double *__restrict__ gup1 = W.gup1 + gslab;
+    Part2 *__restrict__ gup = W.gup + gslab;
+    Part2 *__restrict__ gdp = W.gdp + gslab;
     const int laytrop = W.laytrop[colc];
     const double *tp0 = s_pl[0], *tp1 = s_pl[1];
     double2 *hand = reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2;      // [stream][quad][column][2]
@@ -2583,6 +2626,40 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
         }
         fpl = 0.0;
         return &s_fr[lower ? 0 : base_up][0];
+    };
+
+    // The band's partial of a level goes to the reduction buffer [buffer][value][band][slot][column]; after the NC levels of a round the
+    // workgroup meets at ONE barrier, wave `bi` adds the bands' values of slot bi (bi + nb, ..) in band-list order and stores the group's
+    // partial.  Two buffers: the next round writes the other one, and a buffer is written again only after the barrier in between, which
+    // no wave passes before every wave has finished reading it.
+    const unsigned rlane = (unsigned)(sub * 64 + tx);
+    const unsigned vstride = (unsigned)(nb * NC * ncw), rband = (unsigned)(bi * NC * ncw);      // (uniform)
+    unsigned bufoff = 0u;                                                                       // 0 / NVAL * vstride
+    auto red_put = [&](int c, int val, double v) { red[bufoff + val * vstride + rband + (unsigned)(c * ncw) + rlane] = v; };
+    auto round_end = [&](auto dn_tag, int lev0, int nvalid) {
+        constexpr bool DN = decltype(dn_tag)::value;
+        constexpr int NV = DN ? 1 : NVAL;
+        __syncthreads();
+        for (int c = bi; c < nvalid; c += nb) {       // (wave-uniform)
+            const int lvl = DN ? lev0 - c - 1 : lev0 + c;
+            double sv[NV];
+#pragma unroll
+            for (int val = 0; val < NV; val++) {
+                const double *r = red + (bufoff + val * vstride + (unsigned)(c * ncw) + rlane);
+                double sum = r[0];
+                for (int q = 1; q < nb; q++) sum = sum + r[(unsigned)(q * NC * ncw)];
+                sv[val] = sum;
+            }
+            if (incol) {
+                if constexpr (DN) gdn1[(size_t)lvl * ncb] = sv[0];
+                else {
+                    if constexpr (TWO) gup[(size_t)lvl * ncb] = Part2{sv[0], sv[1]};
+                    else gup1[(size_t)lvl * ncb] = sv[0];
+                    if constexpr (IDRV) gdp[(size_t)lvl * ncb] = TWO ? Part2{sv[2], sv[3]} : Part2{sv[1], sv[1]};
+                }
+            }
+        }
+        bufoff = bufoff ? 0u : NVAL * vstride;
     };
 
     double rad[NG], radc[TWO ? NG : 1], drad[IDRV ? NG : 1], dradc[(IDRV && TWO) ? NG : 1];
@@ -2648,20 +2725,11 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
             else if constexpr (G == 3) return (q[0] + q[1]) + q[2];
             else return (q[0] + q[1]) + (q[2] + q[3]);
         };
-        const double sum = tree(qs);
-        double sumc = 0.0, dsum = 0.0, dsumc = 0.0;
-        if constexpr (TWO && !DN) sumc = tree(qsc);
-        if constexpr (IDRV && !DN) { dsum = tree(qd); if constexpr (TWO) dsumc = tree(qdc); }
-        const double v = (sum * 0.5) * wtdelw, vc = (TWO && !DN) ? (sumc * 0.5) * wtdelw : v;
-        if (incol) {
-            if constexpr (DN) pdn[(size_t)(lev - 1) * ncb] = Part2{v, vc};
-            else {
-                pup[(size_t)lev * ncb] = Part2{v, vc};
-                if constexpr (IDRV) {
-                    const double dv = ((dsum * 0.5) * wtdelw) * T.fluxfac, dvc = TWO ? ((dsumc * 0.5) * wtdelw) * T.fluxfac : dv;
-                    dbase[(size_t)lev * ncb] = Part2{dv, dvc};
-                }
-            }
+        red_put(slot, 0, (tree(qs) * 0.5) * wtdelw);
+        if constexpr (TWO && !DN) red_put(slot, 1, (tree(qsc) * 0.5) * wtdelw);
+        if constexpr (IDRV && !DN) {
+            red_put(slot, TWO ? 2 : 1, ((tree(qd) * 0.5) * wtdelw) * T.fluxfac);
+            if constexpr (TWO) red_put(slot, 3, ((tree(qdc) * 0.5) * wtdelw) * T.fluxfac);
         }
     };
     auto sweep = [&](auto bin_tag, auto dn_tag) {
@@ -2677,21 +2745,24 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
             for (int k = 0; k < G; k++) cc[k][c] = ld_c(first + c * dir, k);
         }
         int n = 0;
-        for (; n + NC <= count; n += NC) {          // whole groups of NC levels: a straight-line body (a skipped level inside the loop makes
+        for (; n + NC <= count; n += NC) {          // whole rounds of NC levels: a straight-line body (a skipped level inside the loop makes
 #pragma unroll                                      // the compiler rotate the slot registers through copies, which wait for every load)
             for (int c = 0; c < NC; c++) level(bin_tag, dn_tag, first + (n + c) * dir, c);
+            round_end(dn_tag, first + n * dir, NC);
         }
+        const int rem = count - n;                  // (uniform over the workgroup)
 #pragma unroll
         for (int c = 0; c < NC - 1; c++) {
-            if (n + c < count) level(bin_tag, dn_tag, first + (n + c) * dir, c);       // uniform
+            if (c < rem) level(bin_tag, dn_tag, first + (n + c) * dir, c);
         }
+        if (rem > 0) round_end(dn_tag, first + n * dir, rem);
     };
     using std::true_type;
     using std::false_type;
 
     if constexpr (DOWN) {
         // ------------------------------------------------------------------ downward: layers nlay .. lo
-        if (incol) pdn[(size_t)nlay * ncb] = Part2{0.0, 0.0};
+        if (incol && bi == 0) gdn1[(size_t)nlay * ncb] = 0.0;
         if (any_bin) sweep(true_type{}, true_type{}); else sweep(false_type{}, true_type{});
     }
     if constexpr (PHASE == 1) {                     // downward radiances at level ltop for k_sweep<1..4>
@@ -2720,11 +2791,9 @@ __global__ __launch_bounds__(64 * sweepc_ns(NQ, PHASE, IDRV), sweepc_waves(NQ, P
             usum = usum + rad[j];
             if constexpr (IDRV) { drad[j] = fr * dpb; dusum = dusum + drad[j]; }
         }
-        const double v = (usum * 0.5) * wtdelw, dv = ((dusum * 0.5) * wtdelw) * T.fluxfac;
-        if (incol) {
-            pup[0] = Part2{v, v};
-            if constexpr (IDRV) dbase[0] = Part2{dv, dv};
-        }
+        red_put(0, 0, (usum * 0.5) * wtdelw);
+        if constexpr (IDRV) red_put(0, 1, ((dusum * 0.5) * wtdelw) * T.fluxfac);
+        round_end(false_type{}, 0, 1);              // level 0
     } else {                                        // upward radiances at level ltop from k_sweep<1..4>
 #pragma unroll
         for (int k = 0; k < G; k++) {
@@ -2914,14 +2983,16 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_flux  : sum of the quad partials in band order (rtrn :549-574) and flux scaling (rtrn :580-594), one
-//           thread per (column, level).  clear_from_total: MODE 0 ran, so the clear-sky stream equals the
-//           total-sky stream.  Only chunks whose band lies in [istart, iend] were swept.
+// k_flux  : sum of the band / group partials (rtrn :549-574) and flux scaling (rtrn :580-594), one
+//           thread per (column, level).  clear_from_total: a cloud-free call, the clear-sky stream equals the
+//           total-sky stream.  Only bands in [istart, iend] were swept: the groups list exactly those.
 // k_rates : net flux and heating rate (rtrn :583-604; output copies src/rrtmg_lw_rad.nomcica.f90:563-583),
 //           one thread per (column, layer).
 // ------------------------------------------------------------------------------------------------
+struct FluxGroups { int n; int nb[NGROUP_MAX]; unsigned long long bands[NGROUP_MAX]; };      // k_sweepc's groups: band lists as nibbles (band - 1)
+
 __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut out, int ncol, int col0, int nct,
-                                              int idrv, int clear_from_total, int istart, int iend)
+                                              int idrv, int clear_from_total, FluxGroups fg)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
@@ -2930,18 +3001,34 @@ __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut 
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
-#pragma unroll 4
-    for (int k = istart - 1; k < iend; k++) {       // band slabs in band order (rtrn :549-574)
-        const size_t po = ((size_t)k * (nlay + 1) + lev) * ncb + col;
-        const Part2 pu = W.pup[po], pd = W.pdn[po];
-        u = u + pu.a;
-        d = d + pd.a;
-        if (!clear_from_total) { uc = uc + pu.b; dc = dc + pd.b; }
-        if (idrv == 1) {
-            const Part2 q = W.dpart[po];
-            du = du + q.a;
-            if (!clear_from_total) duc = duc + q.b;
+    // Where k_sweepc ran - downward at and above the batch's highest cloud, upward above it, everywhere in a cloud-free call - the
+    // partials arrive summed per group; in the cloud zone they arrive per band and are added here in the same order (the bands of a group
+    // in list order, then the groups), so a level's flux does not depend on which kernel swept it.
+    const int ltop = *W.ltop;
+    const bool dn_g = clear_from_total || lev >= ltop, up_g = clear_from_total || lev > ltop;       // uniform over the workgroup
+    for (int g = 0; g < fg.n; g++) {
+        const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;
+        Part2 su{0.0, 0.0}, sd{0.0, 0.0}, sq{0.0, 0.0};
+        if (dn_g) { sd.a = W.gdn1[go]; sd.b = sd.a; }
+        if (up_g) {
+            if (clear_from_total) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
+            if (idrv == 1) sq = W.gdp[go];
         }
+        if (!dn_g || !up_g) {
+            for (int k = 0; k < fg.nb[g]; k++) {
+                const int b = (int)((fg.bands[g] >> (4 * k)) & 15ull);
+                const size_t po = ((size_t)b * (nlay + 1) + lev) * ncb + col;
+                if (!dn_g) { const Part2 p = W.pdn[po]; if (k == 0) sd = p; else { sd.a = sd.a + p.a; sd.b = sd.b + p.b; } }
+                if (!up_g) {
+                    const Part2 p = W.pup[po];
+                    if (k == 0) su = p; else { su.a = su.a + p.a; su.b = su.b + p.b; }
+                    if (idrv == 1) { const Part2 q = W.dpart[po]; if (k == 0) sq = q; else { sq.a = sq.a + q.a; sq.b = sq.b + q.b; } }
+                }
+            }
+        }
+        u = u + su.a; uc = uc + su.b;
+        d = d + sd.a; dc = dc + sd.b;
+        du = du + sq.a; duc = duc + sq.b;
     }
     const size_t o = gc + (size_t)nct * lev;
     u = u * T.fluxfac; d = d * T.fluxfac;
