@@ -185,11 +185,11 @@ int sweep_attr_one()
 template <int Q>
 int sweepc_attr_one()
 {
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, false, sweepc_nt(Q, 0, false)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, true, sweepc_nt(Q, 0, true)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 1, false, sweepc_nt(Q, 1, false)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, false, sweepc_nt(Q, 2, false)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true, sweepc_nt(Q, 2, true)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     return 0;
 }
 template <int M>
@@ -441,10 +441,11 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     }
 #define SWEEPC_I(Q, PH, I)                                                                                           \
     do {                                                                                                             \
+        constexpr int nt = sweepc_nt(Q, PH, I);                                                                      \
         const int nsb = sweepc_nsb(Q, PH, I, sa.nbands);                                                             \
         sa.ncb = (nb + 64 * nsb - 1) / (64 * nsb);                                                                   \
-        const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands, nsb);                                              \
-        LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I>), sgrid, sblock, sweepc_lds_bytes(PH, I, sa.nbands, nsb), s, G.D, Wk, sa); \
+        const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands * nt, nsb);                                         \
+        LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I, nt>), sgrid, sblock, sweepc_lds_bytes(PH, I, sa.nbands, nsb, nt), s, G.D, Wk, sa); \
     } while (0)
 #define SWEEPC(Q, PH) do { if (idrv == 1 && PH != 1) SWEEPC_I(Q, PH, true); else SWEEPC_I(Q, PH, false); } while (0)
 #define SWEEPC_Q(PH) do { if (nq == 4) SWEEPC(4, PH); else if (nq == 3) SWEEPC(3, PH); else if (nq == 2) SWEEPC(2, PH); else SWEEPC(1, PH); } while (0)

@@ -1817,6 +1817,20 @@ __device__ __forceinline__ unsigned bload_u32(const void *base, unsigned voff)
     return __builtin_amdgcn_raw_buffer_load_b32(sweep_rsrc(base), (int)voff, 0, 0);
 }
 
+__device__ __forceinline__ void bstore_f64(void *base, unsigned voff, double v)
+{
+    u32x2 x;
+    __builtin_memcpy(&x, &v, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(x, sweep_rsrc(base), (int)voff, 0, 0);
+}
+__device__ __forceinline__ void bstore_f64x2(void *base, unsigned voff, double v0, double v1)
+{
+    const double t[2] = {v0, v1};
+    u32x4 x;
+    __builtin_memcpy(&x, t, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(x, sweep_rsrc(base), (int)voff, 0, 0);
+}
+
 // table index of a cell's code (0 for the series branch: entry 0 is {1 - exp = 0, tfn = 0})
 __device__ __forceinline__ unsigned code_index(scr_t c) { return (unsigned)max((int)(-c), 0); }
 // the optical depth of a series cell, 0 for a table cell: max(c, 0) on the bit pattern (a negative float is a negative integer)
@@ -2533,19 +2547,40 @@ __host__ __device__ constexpr int sweepc_nval(int PHASE, bool IDRV) { return (PH
 #ifndef RRLW_SWEEPC_CODES
 #define RRLW_SWEEPC_CODES 2       // code slots: levels of cell codes in flight (the codes are the one HBM stream of the sweep; 4 registers per quad and slot)
 #endif
-__host__ __device__ constexpr int sweepc_lds_bytes(int PHASE, bool IDRV, int nb, int nsb)
-{
-    return SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES + 2 * sweepc_nval(PHASE, IDRV) * nb * RRLW_SWEEPC_CODES * nsb * 64 * 8;
-}
 constexpr int SWEEPC_LDS_MAX = 160 * 1024;
+__host__ __device__ constexpr int sweepc_lds_bytes(int PHASE, bool IDRV, int nb, int nsb, int NT = 1)
+{
+    return SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES + 2 * sweepc_nval(PHASE, IDRV) * nb * NT * RRLW_SWEEPC_CODES * nsb * 64 * 8;
+}
+// threads per band: two where a band's 16 g-points with two streams would otherwise leave one wave per SIMD
+#ifndef RRLW_SWEEPC_SPLIT
+#define RRLW_SWEEPC_SPLIT 1
+#endif
+__host__ __device__ constexpr int sweepc_nt(int NQ, int PHASE, bool IDRV)
+{
+    return (RRLW_SWEEPC_SPLIT && NQ == 4 && (PHASE == 2 || (PHASE == 0 && IDRV))) ? 2 : 1;
+}
 // bands per group: what fits the wave slots of the most register-hungry instantiation (phase 2 with d/dT)
-__host__ __device__ constexpr int sweepc_group_cap(int NQ) { return 4 * sweepc_waves(NQ, 2, true) < 5 ? 4 * sweepc_waves(NQ, 2, true) : 5; }
+__host__ __device__ constexpr int sweepc_group_cap(int NQ)
+{
+    int cap = 5;
+    for (int ph = 0; ph < 3; ph++)
+        for (int i = 0; i < 2; i++) {
+            if (ph == 1 && i == 1) continue;
+            const bool idrv = i == 1;
+            const int nt = sweepc_nt(NQ, ph, idrv), w = 4 * sweepc_waves(NQ / nt, ph, idrv) / nt;      // wave slots
+            if (w < cap) cap = w;
+            while (cap > 1 && sweepc_lds_bytes(ph, idrv, cap, 1, nt) > SWEEPC_LDS_MAX) cap--;           // reduction buffer
+        }
+    return cap;
+}
 // column sub-blocks per workgroup for a group of nb bands
 __host__ __device__ constexpr int sweepc_nsb(int NQ, int PHASE, bool IDRV, int nb)
 {
-    int nsb = 4 * sweepc_waves(NQ, PHASE, IDRV) / nb;
+    const int nt = sweepc_nt(NQ, PHASE, IDRV);
+    int nsb = 4 * sweepc_waves(NQ / nt, PHASE, IDRV) / (nb * nt);
     if (nsb < 1) nsb = 1;
-    while (nsb > 1 && sweepc_lds_bytes(PHASE, IDRV, nb, nsb) > SWEEPC_LDS_MAX) nsb--;
+    while (nsb > 1 && sweepc_lds_bytes(PHASE, IDRV, nb, nsb, nt) > SWEEPC_LDS_MAX) nsb--;
     return nsb;
 }
 
@@ -2554,17 +2589,22 @@ __host__ __device__ constexpr int sweepc_nsb(int NQ, int PHASE, bool IDRV, int n
 // in order, so a wait for everything would stall the wave on the codes it has just requested for the next level.
 template <int G> struct SweepcLev { double tl, tz; unsigned w; };
 
-template <int NQ, int PHASE, bool IDRV>
-__global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(NQ, PHASE, IDRV)) void k_sweepc(DevTables T, Workspace W, SweepArgs a)
+// NT threads (waves) per band, each with G = NQ / NT of its quads: the band's partial is the sum of their raw quad sums, formed - with the
+// band's weight - by the wave that adds the group (so a band split over two waves still rounds like one swept by a single thread).  Used
+// where all 16 g-points of a band with two streams would leave one wave per SIMD (sweepc_nt).
+template <int NQ, int PHASE, bool IDRV, int NT = 1>
+__global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_waves(NQ / NT, PHASE, IDRV)) void k_sweepc(DevTables T, Workspace W, SweepArgs a)
 {
-    constexpr int G = NQ, NG = 4 * G, NC = RRLW_SWEEPC_CODES;
+    static_assert(NQ % NT == 0 && (NT == 1 || NT == 2), "threads per band");
+    constexpr int G = NQ / NT, NG = 4 * G, NC = RRLW_SWEEPC_CODES;
     constexpr bool DOWN = PHASE != 2, UP = PHASE != 1, TWO = PHASE == 2;       // TWO: total and clear-sky streams differ
     constexpr int NVAL = sweepc_nval(PHASE, IDRV);
     extern __shared__ __align__(16) unsigned char smem[];
     // (a wave = 64 consecutive threadIdx.x of one (y, z): band and sub-block are wave-uniform - made scalar, so that everything derived
     // from the band, buffer descriptors included, lives in scalar registers)
-    const int tx = threadIdx.x, bi = __builtin_amdgcn_readfirstlane(threadIdx.y), sub = __builtin_amdgcn_readfirstlane(threadIdx.z);
-    const int nb = blockDim.y, nsb = blockDim.z, ncw = 64 * nsb;                // bands of the group, column sub-blocks, columns of the workgroup
+    const int tx = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y), sub = __builtin_amdgcn_readfirstlane(threadIdx.z);
+    const int bi = ty / NT, part = ty % NT;                                     // band of the group, part of the band
+    const int ny = blockDim.y, nb = ny / NT, nsb = blockDim.z, ncw = 64 * nsb;  // waves per column sub-block, bands of the group, sub-blocks, columns of the workgroup
     const float2 *s_lut = reinterpret_cast<const float2 *>(smem);
     double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES);
     double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES + SWEEP_PL_BYTES);
@@ -2574,17 +2614,17 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(N
     const int B = (int)((a.bands >> (4 * bi)) & 15ull) + 1;
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;
-    const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B));
+    const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B) + part * G);
+    const int g0 = NG * part;                                                   // first of this thread's g-points within the band
     const size_t gc = (size_t)a.col0 + colc;
     const int nlay = W.nlay, nct = a.nct;
     const size_t ncb = W.ncolb;
-    const double wtdelw = T.delwave[B - 1];
     const bool alt16 = (B == 16 && a.istart == 16);
     const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
     const bool any_bin = lo_bin || up_bin;
     const int base_up = ((UP_ZERO >> (B - 1)) & 1u) ? 14 : (((UP_FROM_A >> (B - 1)) & 1u) ? 0 : 9);
-    sweep_stage_lut(T, smem, (sub * nb + bi) * 64 + tx, 64 * nb * nsb);
-    sweep_stage_band(T, s_pl, s_fr, B, alt16, lo_bin, up_bin, sub * 64 + tx, ncw);
+    sweep_stage_lut(T, smem, (sub * ny + ty) * 64 + tx, 64 * ny * nsb);
+    sweep_stage_band(T, s_pl, s_fr, B, alt16, lo_bin, up_bin, (sub * NT + part) * 64 + tx, NT * ncw);
     __syncthreads();
     const int lo = PHASE == 0 ? 1 : __builtin_amdgcn_readfirstlane(*W.ltop) + 1;       // layers lo .. nlay
     const size_t qstride = (size_t)nlay * ncb;
@@ -2593,11 +2633,12 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(N
     const double *__restrict__ tlay = a.tlay + a.col0;
     const double *__restrict__ tlev = a.tlev + a.col0;
     const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
-    const size_t gslab = (size_t)a.group * (nlay + 1) * ncb + col;
+    const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;        // (uniform: the group's slabs; a lane's column is the 32-bit offset of a buffer store)
     double *__restrict__ gdn1 = W.gdn1 + gslab;
     double *__restrict__ gup1 = W.gup1 + gslab;
     Part2 *__restrict__ gup = W.gup + gslab;
     Part2 *__restrict__ gdp = W.gdp + gslab;
+    const unsigned so8 = (unsigned)col * 8u, so16 = (unsigned)col * 16u;
     const int laytrop = W.laytrop[colc];
     const double *tp0 = s_pl[0], *tp1 = s_pl[1];
     double2 *hand = reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2;      // [stream][quad][column][2]
@@ -2622,40 +2663,47 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(N
             const unsigned w = (lower ? lo_bin : up_bin) ? fwv : 0x10000000u;
             const int r0 = clampi((lower ? 0 : base_up) + (int)(w >> 28) - 1, 0, 14);
             fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
-            return &s_fr[r0][0];
+            return &s_fr[r0][g0];
         }
         fpl = 0.0;
-        return &s_fr[lower ? 0 : base_up][0];
+        return &s_fr[lower ? 0 : base_up][g0];
     };
 
-    // The band's partial of a level goes to the reduction buffer [buffer][value][band][slot][column]; after the NC levels of a round the
-    // workgroup meets at ONE barrier, wave `bi` adds the bands' values of slot bi (bi + nb, ..) in band-list order and stores the group's
-    // partial.  Two buffers: the next round writes the other one, and a buffer is written again only after the barrier in between, which
-    // no wave passes before every wave has finished reading it.
+    // A wave's raw sum over its g-points of a level goes to the reduction buffer [buffer][value][wave][slot][column]; after the NC levels of a
+    // round the workgroup meets at ONE barrier, wave `ty` forms the bands' partials of slot ty (ty + ny, ..) - (sum of the band's waves x 0.5)
+    // x delwave, rtrn :549-562 - adds them in band-list order and stores the group's partial.  Two buffers: the next round writes the other
+    // one, and a buffer is written again only after the barrier in between, which no wave passes before every wave has finished reading it.
     const unsigned rlane = (unsigned)(sub * 64 + tx);
-    const unsigned vstride = (unsigned)(nb * NC * ncw), rband = (unsigned)(bi * NC * ncw);      // (uniform)
+    const unsigned vstride = (unsigned)(ny * NC * ncw), rband = (unsigned)(ty * NC * ncw);      // (uniform)
     unsigned bufoff = 0u;                                                                       // 0 / NVAL * vstride
     auto red_put = [&](int c, int val, double v) { red[bufoff + val * vstride + rband + (unsigned)(c * ncw) + rlane] = v; };
     auto round_end = [&](auto dn_tag, int lev0, int nvalid) {
         constexpr bool DN = decltype(dn_tag)::value;
         constexpr int NV = DN ? 1 : NVAL;
         __syncthreads();
-        for (int c = bi; c < nvalid; c += nb) {       // (wave-uniform)
+        for (int c = ty; c < nvalid; c += ny) {       // (wave-uniform)
             const int lvl = DN ? lev0 - c - 1 : lev0 + c;
             double sv[NV];
 #pragma unroll
             for (int val = 0; val < NV; val++) {
                 const double *r = red + (bufoff + val * vstride + (unsigned)(c * ncw) + rlane);
-                double sum = r[0];
-                for (int q = 1; q < nb; q++) sum = sum + r[(unsigned)(q * NC * ncw)];
+                const bool deriv = IDRV && !DN && val >= (TWO ? 2 : 1);
+                double sum = 0.0;
+                for (int q = 0; q < nb; q++) {
+                    double pq = r[(unsigned)(q * NT * NC * ncw)];
+                    if constexpr (NT == 2) pq = pq + r[(unsigned)((q * NT + 1) * NC * ncw)];
+                    double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
+                    if (deriv) v = v * T.fluxfac;
+                    sum = q == 0 ? v : sum + v;
+                }
                 sv[val] = sum;
             }
             if (incol) {
-                if constexpr (DN) gdn1[(size_t)lvl * ncb] = sv[0];
+                if constexpr (DN) bstore_f64(gdn1 + (size_t)lvl * ncb, so8, sv[0]);
                 else {
-                    if constexpr (TWO) gup[(size_t)lvl * ncb] = Part2{sv[0], sv[1]};
-                    else gup1[(size_t)lvl * ncb] = sv[0];
-                    if constexpr (IDRV) gdp[(size_t)lvl * ncb] = TWO ? Part2{sv[2], sv[3]} : Part2{sv[1], sv[1]};
+                    if constexpr (TWO) bstore_f64x2(gup + (size_t)lvl * ncb, so16, sv[0], sv[1]);
+                    else bstore_f64(gup1 + (size_t)lvl * ncb, so8, sv[0]);
+                    if constexpr (IDRV) bstore_f64x2(gdp + (size_t)lvl * ncb, so16, TWO ? sv[2] : sv[1], TWO ? sv[3] : sv[1]);
                 }
             }
         }
@@ -2725,11 +2773,11 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(N
             else if constexpr (G == 3) return (q[0] + q[1]) + q[2];
             else return (q[0] + q[1]) + (q[2] + q[3]);
         };
-        red_put(slot, 0, (tree(qs) * 0.5) * wtdelw);
-        if constexpr (TWO && !DN) red_put(slot, 1, (tree(qsc) * 0.5) * wtdelw);
+        red_put(slot, 0, tree(qs));
+        if constexpr (TWO && !DN) red_put(slot, 1, tree(qsc));
         if constexpr (IDRV && !DN) {
-            red_put(slot, TWO ? 2 : 1, ((tree(qd) * 0.5) * wtdelw) * T.fluxfac);
-            if constexpr (TWO) red_put(slot, 3, ((tree(qdc) * 0.5) * wtdelw) * T.fluxfac);
+            red_put(slot, TWO ? 2 : 1, tree(qd));
+            if constexpr (TWO) red_put(slot, 3, tree(qdc));
         }
     };
     auto sweep = [&](auto bin_tag, auto dn_tag) {
@@ -2762,7 +2810,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(N
 
     if constexpr (DOWN) {
         // ------------------------------------------------------------------ downward: layers nlay .. lo
-        if (incol && bi == 0) gdn1[(size_t)nlay * ncb] = 0.0;
+        if (incol && ty == 0) bstore_f64(gdn1 + (size_t)nlay * ncb, so8, 0.0);
         if (any_bin) sweep(true_type{}, true_type{}); else sweep(false_type{}, true_type{});
     }
     if constexpr (PHASE == 1) {                     // downward radiances at level ltop for k_sweep<1..4>
@@ -2791,8 +2839,8 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ, PHASE, IDRV), sweepc_waves(N
             usum = usum + rad[j];
             if constexpr (IDRV) { drad[j] = fr * dpb; dusum = dusum + drad[j]; }
         }
-        red_put(0, 0, (usum * 0.5) * wtdelw);
-        if constexpr (IDRV) red_put(0, 1, ((dusum * 0.5) * wtdelw) * T.fluxfac);
+        red_put(0, 0, usum);
+        if constexpr (IDRV) red_put(0, 1, dusum);
         round_end(false_type{}, 0, 1);              // level 0
     } else {                                        // upward radiances at level ltop from k_sweep<1..4>
 #pragma unroll
