@@ -35,7 +35,7 @@ struct State {
     bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *ltop; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *ltop; double2 *ovl; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by k_sweep exists twice as well: k_sweep/k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -258,6 +258,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         for (auto &ps : G.prep) {
             items.push_back({(void **)&ps.odcld, 16 * L * n * 8});
             items.push_back({(void **)&ps.efcl, 16 * L * n * 8});
+            items.push_back({(void **)&ps.ovl, (size_t)2 * (L + 1) * 3 * n * sizeof(double2)});
         }
     }
     if (mc) {
@@ -277,7 +278,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     {   // G.W itself carries prep set 0 and scratch set 0
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
-        W.odcld = ps.odcld; W.efcl = ps.efcl; W.ltop = ps.ltop;
+        W.odcld = ps.odcld; W.efcl = ps.efcl; W.ltop = ps.ltop; W.ovl = ps.ovl;
     }
     G.ws_bytes = total;
     G.ws_nlay = nlay;
@@ -305,7 +306,7 @@ Workspace ws_for(int k)
     Workspace w = G.W;
     const State::PrepSet &ps = G.prep[k];
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
-    w.odcld = ps.odcld; w.efcl = ps.efcl; w.ltop = ps.ltop;
+    w.odcld = ps.odcld; w.efcl = ps.efcl; w.ltop = ps.ltop; w.ovl = ps.ovl;
     const State::ScrSet &ss = G.scrset[G.ws_two_scr ? k : 0];
     for (int a = 0; a < NSCR; a++) w.scr[a] = ss.scr[a];
     w.fw = ss.fw;
@@ -322,7 +323,7 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
     const dim3 cgrid1((nb + 63) / 64), cblock1(64);
     LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, idrv, istart);
     if (mode == 1 || mode == 2) {
-        LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag);
+        LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag, mode);
         const dim3 lgrid((nb + BLOCK - 1) / BLOCK, Wk.nlay), lblock(BLOCK);
         LAUNCH("k_cloudlay", (k_cloudlay<GCM>), lgrid, lblock, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
     }

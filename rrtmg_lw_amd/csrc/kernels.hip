@@ -73,7 +73,8 @@ struct Workspace {
     int *ncbands;       // [ncolb]
     double *odcld;      // [16][nlay][ncolb]   secdiff(ib) * taucloud
     double *efcl;       // [16][nlay][ncolb]   rtrn: (1 - exp(-odcld)) * cldfrac
-    int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcld, bit2 istcldd; cflag[0] bit3 = column has cloud
+    int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcldd (first cloudy level of a block, downward sweep), bit2 istcld (upward); cflag[0] bit3 = column has cloud
+    double2 *ovl;       // rtrnmr's overlap factors of the cloudy levels: [2: down, up][nlay+1][3][ncolb] {facclr1, faccld1} {faccmb1, faccmb2} {facclr2, faccld2}
     int *ltop;          // [1] highest layer of the batch that holds cloud in any column (0: none): above it every sweep is the clear-sky one
     double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at level ltop: 0 downward (k_sweepc<.,1> -> k_sweep), 1 / 2 upward
                         // total / clear (k_sweep -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
@@ -243,10 +244,54 @@ __device__ __forceinline__ double cloud_tauctot(const GcmIn &g, const ColIn &c, 
     return tauctot;
 }
 
+// Maximum-random overlap factors of ONE cloudy level, src/rrtmg_lw_rtrnmr.f90:347-506 (upward loop :347-425, downward loop :427-506;
+// the two loops are mirror images).  cl = cloud fraction of the level, cn = of the next level in sweep direction, cp = of the previous
+// one (read only when that level is cloudy, i.e. !first), last = the level is the last of the sweep.  rat1 / rat2 carry from cloudy
+// level to cloudy level as in the reference.  faccmb1/2, which the reference reads uninitialised when first (SURVEY.md 0.4), are ZERO.
+struct OvlFac { double clr1, cld1, cmb1, cmb2, clr2, cld2; bool rat1, rat2; };     // rat1 / rat2 (0 or 1 in the reference): carried to the next cloudy level
+__device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool first, bool last, bool brat1, bool brat2)
+{
+    const double rat1 = brat1 ? 1. : 0., rat2 = brat2 ? 1. : 0.;
+    // (everything by value: carried state behind references ends up in scratch memory).  Of the reference's seven ways through this
+    // block at most one needs a quotient, so the ways are told apart by predicates, ONE division runs on the selected operands and the
+    // result is routed by selects: no divergent branches (the nested form cost ~200 instructions per cloudy level, this one ~70).
+    const bool act = !last, up = cn >= cl;
+    const double fmx = fmax(cl, cp), fmn = fmin(cl, cp);
+    const bool u_f = act && up && first && cl < 1.;                 // facclr2 = (cn - cl) / (1 - cl)
+    const bool u_gt = act && up && !first && cn > fmx;              // facclr1 = rat2, facclr2 = (cn - fmx) / (1 - fmx)
+    const bool u_lt = act && up && !first && cn < fmx;              // facclr1 = (cn - cl) / (cp - cl)
+    const bool u_eq = act && up && !first && !(cn > fmx) && !(cn < fmx);      // facclr1 = rat2
+    const bool d_f = act && !up && first;                           // faccld2 = (cl - cn) / cl
+    const bool d_le = act && !up && !first && cn <= fmn;            // faccld1 = rat1, faccld2 = (fmn - cn) / fmn
+    const bool d_gt = act && !up && !first && !(cn <= fmn);         // faccld1 = (cl - cn) / (cl - fmn)
+    double num = 0.0, den = 1.0;
+    num = u_f ? cn - cl : num;     den = u_f ? 1. - cl : den;
+    num = u_gt ? cn - fmx : num;   den = u_gt ? 1. - fmx : den;
+    num = u_lt ? cn - cl : num;    den = u_lt ? cp - cl : den;
+    num = d_f ? cl - cn : num;     den = d_f ? cl : den;
+    num = d_le ? fmn - cn : num;   den = d_le ? fmn : den;
+    num = d_gt ? cl - cn : num;    den = d_gt ? cl - fmn : den;
+    const double q = fdiv(num, den);
+    const double clr1 = (u_gt || u_eq) ? rat2 : (u_lt ? q : 0.0);
+    const double clr2 = (u_f || u_gt) ? q : 0.0;
+    const double cld1 = d_le ? rat1 : (d_gt ? q : 0.0);
+    const double cld2 = (d_f || d_le) ? q : 0.0;
+    const bool r1 = (act && up) ? (clr1 > 0. || clr2 > 0.) : (act ? false : brat1);
+    const bool r2 = (act && !up) ? (cld1 > 0. || cld2 > 0.) : (act ? false : brat2);
+    double cmb1 = 0.0, cmb2 = 0.0;
+    if (!first) {
+        const double cx = last ? 0.0 : cn;          // beyond the last level the reference's neighbour fraction is taken as 0
+        cmb1 = fmax(0., fmin(cx - cl, cp - cl));
+        cmb2 = fmax(0., fmin(cl - cx, cl - cp));
+    }
+    return OvlFac{clr1, cld1, cmb1, cmb2, clr2, cld2, r1, r2};
+}
+
 // cflag[lay][col]: bit 0 = the layer holds cloud for the sweeps (cldfrac >= 1e-6), bits 8.. = cldprop's ncbands in effect at the layer;
-// cflag[0][col] bit 3 = the column holds cloud
+// cflag[0][col] bit 3 = the column holds cloud.  mode 2 (rtrnmr): the overlap factors of every cloudy level for both sweep directions
+// (the reference's two set-up loops, rtrnmr :347-506) go to W.ovl, "first cloudy level of a block" to bits 1 (downward) and 2 (upward).
 template <bool GCM>
-__global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int inflag, int iceflag, int liqflag)
+__global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int inflag, int iceflag, int liqflag, int mode)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
@@ -255,6 +300,9 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
     const double *cldfr = GCM ? g.cldfr : c.cldfrac;
     const double *ciwp_ = GCM ? g.cicewp : c.ciwp, *clwp_ = GCM ? g.cliqwp : c.clwp;
     int ncbands = 1, anycloud = 0, top = 0;
+    const size_t ncb = W.ncolb;
+    bool prevcld = false, rat1 = false, rat2 = false;       // upward sweep order = this loop's order
+    double cfprev = 0.0;
     for (int lay = 1; lay <= nlay; lay++) {
         const size_t gi = gc + (size_t)nct * (lay - 1);
         const double cf = cldfr[gi], ciwp = ciwp_[gi], clwp = clwp_[gi];
@@ -271,7 +319,36 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
         const int cloudy = cf >= 1.e-6;
         anycloud |= cloudy;
         if (cloudy) top = lay;
-        W.cflag[(size_t)lay * W.ncolb + col] = cloudy | (ncbands << 8);
+        int first = 0;
+        if (mode == 2) {
+            if (cloudy) {
+                first = !prevcld;
+                const OvlFac mf = mr_step(cf, lay < nlay ? cldfr[gi + nct] : 0.0, cfprev, first, lay == nlay, rat1, rat2);
+                rat1 = mf.rat1; rat2 = mf.rat2;
+                prevcld = true;
+                cfprev = cf;
+                double2 *o = W.ovl + ((size_t)((nlay + 1) + lay) * 3) * ncb + col;
+                o[0] = make_double2(mf.clr1, mf.cld1); o[ncb] = make_double2(mf.cmb1, mf.cmb2); o[2 * ncb] = make_double2(mf.clr2, mf.cld2);
+            } else prevcld = false;
+        }
+        W.cflag[(size_t)lay * ncb + col] = cloudy | (first << 2) | (ncbands << 8);
+    }
+    if (mode == 2 && anycloud) {            // downward sweep order
+        prevcld = false; rat1 = false; rat2 = false; cfprev = 0.0;
+        for (int lay = top; lay >= 1; lay--) {
+            const size_t gi = gc + (size_t)nct * (lay - 1);
+            const double cf = cldfr[gi];
+            if (cf >= 1.e-6) {
+                const bool first = !prevcld;
+                const OvlFac mf = mr_step(cf, lay > 1 ? cldfr[gi - nct] : 0.0, cfprev, first, lay == 1, rat1, rat2);
+                rat1 = mf.rat1; rat2 = mf.rat2;
+                prevcld = true;
+                cfprev = cf;
+                double2 *o = W.ovl + ((size_t)lay * 3) * ncb + col;
+                o[0] = make_double2(mf.clr1, mf.cld1); o[ncb] = make_double2(mf.cmb1, mf.cmb2); o[2 * ncb] = make_double2(mf.clr2, mf.cld2);
+                if (first) W.cflag[(size_t)lay * ncb + col] |= 2;
+            } else prevcld = false;
+        }
     }
     if (top > *reinterpret_cast<volatile int *>(W.ltop)) atomicMax(W.ltop, top);      // (few columns get past the test once the first waves have reported)
     W.ncbands[col] = ncbands;
@@ -1812,6 +1889,13 @@ __device__ __forceinline__ double bload_f64(const void *base, unsigned voff)
     __builtin_memcpy(&r, &v, 8);
     return r;
 }
+__device__ __forceinline__ double2 bload_f64x2(const void *base, unsigned voff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, 0, 0);
+    double2 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
 __device__ __forceinline__ unsigned bload_u32(const void *base, unsigned voff)
 {
     return __builtin_amdgcn_raw_buffer_load_b32(sweep_rsrc(base), (int)voff, 0, 0);
@@ -1882,49 +1966,6 @@ __device__ __forceinline__ double planck_at(const double *tp, const double *tq, 
     return tp[ind - 1] + f * (tq[ind] - tq[ind - 1]);
 }
 
-// Maximum-random overlap factors of ONE cloudy level, src/rrtmg_lw_rtrnmr.f90:347-506 (upward loop :347-425, downward loop :427-506;
-// the two loops are mirror images).  cl = cloud fraction of the level, cn = of the next level in sweep direction, cp = of the previous
-// one (read only when that level is cloudy, i.e. !first), last = the level is the last of the sweep.  rat1 / rat2 carry from cloudy
-// level to cloudy level as in the reference.  faccmb1/2, which the reference reads uninitialised when first (SURVEY.md 0.4), are ZERO.
-struct OvlFac { double clr1, cld1, cmb1, cmb2, clr2, cld2; bool rat1, rat2; };     // rat1 / rat2 (0 or 1 in the reference): carried to the next cloudy level
-__device__ __forceinline__ OvlFac mr_step(double cl, double cn, double cp, bool first, bool last, bool brat1, bool brat2)
-{
-    const double rat1 = brat1 ? 1. : 0., rat2 = brat2 ? 1. : 0.;
-    // (everything by value: carried state behind references ends up in scratch memory).  Of the reference's seven ways through this
-    // block at most one needs a quotient, so the ways are told apart by predicates, ONE division runs on the selected operands and the
-    // result is routed by selects: no divergent branches (the nested form cost ~200 instructions per cloudy level, this one ~70).
-    const bool act = !last, up = cn >= cl;
-    const double fmx = fmax(cl, cp), fmn = fmin(cl, cp);
-    const bool u_f = act && up && first && cl < 1.;                 // facclr2 = (cn - cl) / (1 - cl)
-    const bool u_gt = act && up && !first && cn > fmx;              // facclr1 = rat2, facclr2 = (cn - fmx) / (1 - fmx)
-    const bool u_lt = act && up && !first && cn < fmx;              // facclr1 = (cn - cl) / (cp - cl)
-    const bool u_eq = act && up && !first && !(cn > fmx) && !(cn < fmx);      // facclr1 = rat2
-    const bool d_f = act && !up && first;                           // faccld2 = (cl - cn) / cl
-    const bool d_le = act && !up && !first && cn <= fmn;            // faccld1 = rat1, faccld2 = (fmn - cn) / fmn
-    const bool d_gt = act && !up && !first && !(cn <= fmn);         // faccld1 = (cl - cn) / (cl - fmn)
-    double num = 0.0, den = 1.0;
-    num = u_f ? cn - cl : num;     den = u_f ? 1. - cl : den;
-    num = u_gt ? cn - fmx : num;   den = u_gt ? 1. - fmx : den;
-    num = u_lt ? cn - cl : num;    den = u_lt ? cp - cl : den;
-    num = d_f ? cl - cn : num;     den = d_f ? cl : den;
-    num = d_le ? fmn - cn : num;   den = d_le ? fmn : den;
-    num = d_gt ? cl - cn : num;    den = d_gt ? cl - fmn : den;
-    const double q = fdiv(num, den);
-    const double clr1 = (u_gt || u_eq) ? rat2 : (u_lt ? q : 0.0);
-    const double clr2 = (u_f || u_gt) ? q : 0.0;
-    const double cld1 = d_le ? rat1 : (d_gt ? q : 0.0);
-    const double cld2 = (d_f || d_le) ? q : 0.0;
-    const bool r1 = (act && up) ? (clr1 > 0. || clr2 > 0.) : (act ? false : brat1);
-    const bool r2 = (act && !up) ? (cld1 > 0. || cld2 > 0.) : (act ? false : brat2);
-    double cmb1 = 0.0, cmb2 = 0.0;
-    if (!first) {
-        const double cx = last ? 0.0 : cn;          // beyond the last level the reference's neighbour fraction is taken as 0
-        cmb1 = fmax(0., fmin(cx - cl, cp - cl));
-        cmb2 = fmax(0., fmin(cl - cx, cl - cp));
-    }
-    return OvlFac{clr1, cld1, cmb1, cmb2, clr2, cld2, r1, r2};
-}
-
 // LDS tables of a sweep workgroup (one band): the transmittance table as float pairs {1 - exp, tfn}, the band's row of totplnk (and band
 // 16's, for the istart = 16 variant of setcoef :233-246), its Planck-fraction rows (0-8 fracrefa, 9-13 fracrefb, 14-15 zeros).  Ends
 // with a barrier.
@@ -1973,7 +2014,7 @@ __device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned 
     __syncthreads();
 }
 
-template <int G> struct SweepLev { scr4 c[G], ct[G]; double tl, tz, cf, cfn; unsigned w; };     // one level's prefetched inputs (G quads of codes)
+template <int G> struct SweepLev { scr4 c[G], ct[G]; double tl, tz, cf; unsigned w; };     // one level's prefetched inputs (G quads of codes)
 
 template <int MODE, int NQ, bool IDRV>
 __global__ __launch_bounds__(64 * sweep_t(NQ, MODE, IDRV) * sweep_ns(NQ, MODE, IDRV), sweep_waves(MODE, IDRV, sweep_g(NQ, MODE, IDRV)))
@@ -2036,9 +2077,12 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
     const double *__restrict__ tlev = a.tlev + a.col0;
     const double *__restrict__ cldf = a.cldfrac + a.col0;
     const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
-    Part2 *__restrict__ pdn = W.pdn + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
-    Part2 *__restrict__ pup = W.pup + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
-    Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb + col;
+    // (uniform bases: the band's slabs; a lane's column is the 32-bit offset of a buffer store)
+    Part2 *__restrict__ pdn = W.pdn + ((size_t)(B - 1) * (nlay + 1)) * ncb;
+    Part2 *__restrict__ pup = W.pup + ((size_t)(B - 1) * (nlay + 1)) * ncb;
+    Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb;
+    const unsigned so16 = (unsigned)col * 16u;
+    auto st_part = [&](Part2 *slab, int lv, const Part2 &v) { bstore_f64x2(slab + (size_t)lv * ncb, so16, v.a, v.b); };
     const int laytrop = W.laytrop[colc];
     const double *tp0 = s_pl[0], *tp1 = s_pl[1];
     // The cloudy modes sweep only the layers 1 .. ltop, ltop = the highest layer of the batch that holds cloud in any column: above it
@@ -2055,7 +2099,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 #pragma unroll
             for (int i = 0; i < LV; i++) {
                 const int lv = lev0 + dir * i;
-                if (incol && lv >= 0 && lv <= ltop) dst[(size_t)lv * ncb] = acc[i];
+                if (incol && lv >= 0 && lv <= ltop) st_part(dst, lv, acc[i]);
             }
         } else {
 #pragma unroll
@@ -2073,7 +2117,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                         sum.a = sum.a + v.a;
                         sum.b = sum.b + v.b;
                     }
-                    dst[(size_t)lv * ncb] = sum;
+                    st_part(dst, lv, sum);
                 }
             }
             __syncthreads();
@@ -2082,7 +2126,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 
     // a level's partial goes straight to the reduction buffer (or, for a one-quad band, to memory): nothing is held across the round
     auto put_part = [&](int i, int lv, const Part2 &v, Part2 *__restrict__ dst) {
-        if constexpr (NT == 1) { if (incol) dst[(size_t)lv * ncb] = v; }
+        if constexpr (NT == 1) { if (incol) st_part(dst, lv, v); }
         else red[(slot * LV + i) * 64 + tx] = v;
     };
     auto reduce_round = [&](Part2 *__restrict__ dst, int lev0, int dir) {
@@ -2100,7 +2144,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                         sum.a = sum.a + v.a;
                         sum.b = sum.b + v.b;
                     }
-                    dst[(size_t)lv * ncb] = sum;
+                    st_part(dst, lv, sum);
                 }
             }
             __syncthreads();
@@ -2118,21 +2162,27 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
     };
 
     // Planck fractions of this thread's g-points in layer `lev`: taumol (constant rows, or :556-561 / :692-693 interpolated between
-    // rows js-1 and js with k_layer's (js, fs) word).  Regions with constant fractions interpolate with weight 0.
-    auto fracs = [&](int lev, unsigned fwv, double (&fr)[NGC]) {
+    // rows js-1 and js with k_layer's (js, fs) word): first row and interpolation weight
+    auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
         const bool lower = lev <= laytrop;
         if (any_bin) {          // uniform
             const unsigned w = (lower ? lo_bin : up_bin) ? fwv : 0x10000000u;
             const int r0 = clampi((lower ? 0 : base_up) + (int)(w >> 28) - 1, 0, 14);
-            const double fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
-            const double *row = &s_fr[r0][NGC * slot];
-#pragma unroll
-            for (int j = 0; j < NGC; j++) fr[j] = row[j] + fpl * (row[16 + j] - row[j]);
-        } else {
-            const double *row = &s_fr[lower ? 0 : base_up][NGC * slot];
-#pragma unroll
-            for (int j = 0; j < NGC; j++) fr[j] = row[j];
+            fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
+            return &s_fr[r0][NGC * slot];
         }
+        fpl = 0.0;
+        return &s_fr[lower ? 0 : base_up][NGC * slot];
+    };
+    auto frac_at = [&](const double *row, double fpl, int j) -> double { return any_bin ? row[j] + fpl * (row[16 + j] - row[j]) : row[j]; };
+    // One cell's gas terms from its code and table entry: (1 - transmittance), Planck fraction, source term bb = fr (blay + tfn dpl).
+    // Formed per g-point where they are used - kept as arrays across the clear / cloudy branch they cost 24 registers and the rtrnmr
+    // instantiations spilled; only the table entries (fetched together, ahead of the branch) and the codes stay live.
+    auto cell = [&](int j, scr_t cj, const float2 &e, const double *row, double fpl, double blay, double dpl, double &atr, double &fr, double &bb) {
+        double tfn;
+        decode(cj, e, atr, tfn);
+        fr = frac_at(row, fpl, j);
+        bb = fr * (blay + tfn * dpl);
     };
     // layer flag (bit 0: the layer holds cloud) - out-of-range levels are clear
     // (the raw word stays in a vector register until the level that needs it: turning it into a lane mask at once would wait for the
@@ -2162,7 +2212,6 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 #pragma unroll
                 for (int k = 0; k < G; k++) q.ct[k] = bload_scr4_nt(sCt + k * qstride + so, off16);
                 if constexpr (MODE == 1 || MODE == 2) q.cf = bload_f64(cldf + (size_t)nct * (lev - 1), off8);
-                if constexpr (MODE == 2) q.cfn = (nlev >= 1 && nlev <= nlay) ? bload_f64(cldf + (size_t)nct * (nlev - 1), off8) : 0.0;
             }
         }
     };
@@ -2205,9 +2254,6 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 #pragma unroll
     for (int i = 0; i < PF; i++) fill(ltop - i, ltop - i - 1, ltop - i - 1, fl[0][i], p[i], 3);
     if constexpr (CODES2) { cq[0] = ldcodes(ltop); cq[1] = ldcodes(ltop - 1); }
-    bool prevcld = false;                // the previous level of the sweep was cloudy (istcldd(lev) == 0)
-    double cfprev = 0.0;
-    bool rat1 = false, rat2 = false;
     for (int top = ltop; top >= 1; top -= LV) {
 #pragma unroll
         for (int i = 0; i < LV; i++) {
@@ -2223,16 +2269,16 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                 fl[1][s] = ldflag(lev - 2 * PF);
             };
             if (lev < 1) { advance_early(); advance(); continue; }          // uniform
-            double fr[NGC], atr[NGC], bbd[NGC];
-            fracs(lev, cur.w, fr);
+            double fpl;
+            const double *row = frac_row(lev, cur.w, fpl);
             const double blay = planck_at(tp0, tp0, cur.tl);
             const double dplankdn = planck_at(tp0, (alt16 && lev == 1) ? tp1 : tp0, cur.tz) - blay;
+            scr_t cg[NGC];
+            float2 eg[NGC];
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
-                double tfn;
-                const scr_t cj = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
-                decode(cj, RRLW_LUT_ENTRY(s_lut, code_index(cj)), atr[j], tfn);
-                bbd[j] = fr[j] * (blay + tfn * dplankdn);
+                cg[j] = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
+                eg[j] = RRLW_LUT_ENTRY(s_lut, code_index(cg[j]));
             }
             if constexpr (CODES2) cq[i & 1] = ldcodes(lev - 2);
             advance_early();
@@ -2240,15 +2286,16 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
             if (!cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    radld[j] = radld[j] + (bbd[j] - radld[j]) * atr[j];
+                    double atr, fr, bbd;
+                    cell(j, cg[j], eg[j], row, fpl, blay, dplankdn, atr, fr, bbd);
+                    radld[j] = radld[j] + (bbd - radld[j]) * atr;
                     dsum = dsum + radld[j];
                     {
-                        const double upd = radclrd[j] + (bbd[j] - radclrd[j]) * atr[j];
+                        const double upd = radclrd[j] + (bbd - radclrd[j]) * atr;
                         radclrd[j] = iclddn ? upd : radld[j];
                         dsumc = dsumc + radclrd[j];
                     }
                 }
-                if constexpr (MODE == 2) prevcld = false;
             } else {
                 {
                     iclddn = true;
@@ -2257,12 +2304,11 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                     if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
                     OvlFac mf{0, 0, 0, 0, 0, 0, false, false};
                     bool first = false;
-                    if constexpr (MODE == 2) {
-                        first = !prevcld;
-                        mf = mr_step(cf, cur.cfn, cfprev, first, lev == 1, rat1, rat2);
-                        rat1 = mf.rat1; rat2 = mf.rat2;
-                        prevcld = true;
-                        cfprev = cf;
+                    if constexpr (MODE == 2) {      // overlap factors of the level (k_cloudscan; rtrnmr :427-506)
+                        first = (fl[0][s] & 2u) != 0u;
+                        const double2 *ov = W.ovl + ((size_t)lev * 3) * ncb;
+                        const double2 f0 = bload_f64x2(ov, off16), f1 = bload_f64x2(ov + ncb, off16), f2 = bload_f64x2(ov + 2 * ncb, off16);
+                        mf.clr1 = f0.x; mf.cld1 = f0.y; mf.cmb1 = f1.x; mf.cmb2 = f1.y; mf.clr2 = f2.x; mf.cld2 = f2.y;
                     }
                     double cfj[NGC], efj[NGC];
 #pragma unroll
@@ -2284,14 +2330,16 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                     }
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
+                        double atr, frj, bbdj;
+                        cell(j, cg[j], eg[j], row, fpl, blay, dplankdn, atr, frj, bbdj);
                         double atot, tftot;
                         decode(cur.ct[j / 4].v[j % 4], RRLW_LUT_ENTRY(s_lut, code_index(cur.ct[j / 4].v[j % 4])), atot, tftot);
-                        const double bbdtot = fr[j] * (blay + tftot * dplankdn);
-                        const double gassrc = bbd[j] * atr[j];
+                        const double bbdtot = frj * (blay + tftot * dplankdn);
+                        const double gassrc = bbdj * atr;
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
                             // (explicit fused operations: the array and the mask flavour of rtrnmc must round identically, whatever the
                             // compiler would contract in either instantiation)
-                            radld[j] = fma(cfj[j], fma(bbdtot, atot, -gassrc), fma(-radld[j], fma(efj[j], 1. - atr[j], atr[j]), radld[j]) + gassrc);
+                            radld[j] = fma(cfj[j], fma(bbdtot, atot, -gassrc), fma(-radld[j], fma(efj[j], 1. - atr, atr), radld[j]) + gassrc);
                         } else {            // rtrnmr :591-615
                             if (first) {        // istcldd(lev) == 1
                                 cldrad[j] = cf * radld[j];
@@ -2301,9 +2349,9 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                             const double ttot = 1. - atot;
                             const double cldsrc = bbdtot * atot;
                             cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                            clrrad[j] = clrrad[j] * (1. - atr[j]) + (1. - cf) * gassrc;
+                            clrrad[j] = clrrad[j] * (1. - atr) + (1. - cf) * gassrc;
                             radld[j] = cldrad[j] + clrrad[j];
-                            const double radmod = radmr[j] * (mf.clr1 * (1. - atr[j]) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
+                            const double radmod = radmr[j] * (mf.clr1 * (1. - atr) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
                             const double oldcld = cldrad[j] - radmod;
                             const double oldclr = clrrad[j] + radmod;
                             radmr[j] = -radmod + mf.clr2 * oldclr - mf.cld2 * oldcld;
@@ -2311,7 +2359,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                             clrrad[j] = clrrad[j] - radmr[j];
                         }
                         dsum = dsum + radld[j];
-                        radclrd[j] = radclrd[j] + (bbd[j] - radclrd[j]) * atr[j];
+                        radclrd[j] = radclrd[j] + (bbdj - radclrd[j]) * atr;
                         dsumc = dsumc + radclrd[j];
                     }
                 }
@@ -2329,17 +2377,18 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
         const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
         const double pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + colc];
         const double dpb = idrv ? W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + colc] : 0.0;
-        double fr1[NGC];                     // fracs(1,g): the surface emits with the lowest layer's Planck fractions
-        fracs(1, any_bin ? bload_u32(sFw, off4) : 0u, fr1);
+        double fpl1;                         // fracs(1,g): the surface emits with the lowest layer's Planck fractions
+        const double *row1 = frac_row(1, any_bin ? bload_u32(sFw, off4) : 0u, fpl1);
         double usum = 0.0, usumc = 0.0, dusum = 0.0;
 #pragma unroll
         for (int j = 0; j < NGC; j++) {
-            const double rad0 = fr1[j] * pb;
+            const double fr1j = frac_at(row1, fpl1, j);
+            const double rad0 = fr1j * pb;
             radlu[j] = rad0 + reflect * radld[j];
             radclru[j] = rad0 + reflect * radclrd[j];
             usum = usum + radlu[j];
             usumc = usumc + radclru[j];
-            drad[j] = idrv ? fr1[j] * dpb : 0.0;
+            drad[j] = idrv ? fr1j * dpb : 0.0;
             dradc[j] = drad[j];
             dusum = dusum + drad[j];
         }
@@ -2356,7 +2405,6 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
 #pragma unroll
     for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i], 3);
     if constexpr (CODES2) { cq[0] = ldcodes(0); cq[1] = ldcodes(1); }
-    prevcld = false; cfprev = 0.0; rat1 = false; rat2 = false;
     for (int base = 0; base <= ltop; base += LV) {
         Part2 accd[idrv ? LV : 1];
 #pragma unroll
@@ -2381,16 +2429,16 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                 advance();
                 continue;
             }
-            double fr[NGC], atr[NGC], bbu[NGC];
-            fracs(lev, cur.w, fr);
+            double fpl;
+            const double *row = frac_row(lev, cur.w, fpl);
             const double blay = planck_at(tp0, tp0, cur.tl);
             const double dplankup = planck_at(tp0, tp0, cur.tz) - blay;
+            scr_t cg[NGC];
+            float2 eg[NGC];
 #pragma unroll
             for (int j = 0; j < NGC; j++) {
-                double tfn;
-                const scr_t cj = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
-                decode(cj, RRLW_LUT_ENTRY(s_lut, code_index(cj)), atr[j], tfn);
-                bbu[j] = fr[j] * (blay + tfn * dplankup);
+                cg[j] = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
+                eg[j] = RRLW_LUT_ENTRY(s_lut, code_index(cg[j]));
             }
             if constexpr (CODES2) cq[i & 1] = ldcodes(lev + 2);
             advance_early();
@@ -2398,17 +2446,18 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
             if (!cloudy) {
 #pragma unroll
                 for (int j = 0; j < NGC; j++) {
-                    radlu[j] = radlu[j] + (bbu[j] - radlu[j]) * atr[j];
+                    double atr, fr, bbu;
+                    cell(j, cg[j], eg[j], row, fpl, blay, dplankup, atr, fr, bbu);
+                    radlu[j] = radlu[j] + (bbu - radlu[j]) * atr;
                     usum = usum + radlu[j];
-                    if (idrv) { drad[j] = drad[j] * (1.0 - atr[j]); dusum = dusum + drad[j]; }
+                    if (idrv) { drad[j] = drad[j] * (1.0 - atr); dusum = dusum + drad[j]; }
                     {
-                        const double upd = radclru[j] + (bbu[j] - radclru[j]) * atr[j];
+                        const double upd = radclru[j] + (bbu - radclru[j]) * atr;
                         radclru[j] = colcloud ? upd : radlu[j];
-                        if (idrv) { dradc[j] = colcloud ? dradc[j] * (1.0 - atr[j]) : drad[j]; dusumc = dusumc + dradc[j]; }
+                        if (idrv) { dradc[j] = colcloud ? dradc[j] * (1.0 - atr) : drad[j]; dusumc = dusumc + dradc[j]; }
                         usumc = usumc + radclru[j];
                     }
                 }
-                if constexpr (MODE == 2) prevcld = false;
             } else {
                 {
                     const double cf = cur.cf;
@@ -2416,12 +2465,11 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                     if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
                     OvlFac mf{0, 0, 0, 0, 0, 0, false, false};
                     bool first = false;
-                    if constexpr (MODE == 2) {
-                        first = !prevcld;
-                        mf = mr_step(cf, cur.cfn, cfprev, first, lev == nlay, rat1, rat2);
-                        rat1 = mf.rat1; rat2 = mf.rat2;
-                        prevcld = true;
-                        cfprev = cf;
+                    if constexpr (MODE == 2) {      // (rtrnmr :347-425)
+                        first = (fl[0][s] & 4u) != 0u;
+                        const double2 *ov = W.ovl + ((size_t)((nlay + 1) + lev) * 3) * ncb;
+                        const double2 f0 = bload_f64x2(ov, off16), f1 = bload_f64x2(ov + ncb, off16), f2 = bload_f64x2(ov + 2 * ncb, off16);
+                        mf.clr1 = f0.x; mf.cld1 = f0.y; mf.cmb1 = f1.x; mf.cmb2 = f1.y; mf.clr2 = f2.x; mf.cld2 = f2.y;
                     }
                     double cfj[NGC], efj[NGC];
 #pragma unroll
@@ -2443,12 +2491,14 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                     }
 #pragma unroll
                     for (int j = 0; j < NGC; j++) {
+                        double atr, frj, bbuj;
+                        cell(j, cg[j], eg[j], row, fpl, blay, dplankup, atr, frj, bbuj);
                         double atot, tftot;
                         decode(cur.ct[j / 4].v[j % 4], RRLW_LUT_ENTRY(s_lut, code_index(cur.ct[j / 4].v[j % 4])), atot, tftot);
-                        const double bbutot = fr[j] * (blay + tftot * dplankup);
-                        const double gassrc = bbu[j] * atr[j];
+                        const double bbutot = frj * (blay + tftot * dplankup);
+                        const double gassrc = bbuj * atr;
                         if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
-                            radlu[j] = fma(cfj[j], fma(bbutot, atot, -gassrc), fma(-radlu[j], fma(efj[j], 1. - atr[j], atr[j]), radlu[j]) + gassrc);
+                            radlu[j] = fma(cfj[j], fma(bbutot, atot, -gassrc), fma(-radlu[j], fma(efj[j], 1. - atr, atr), radlu[j]) + gassrc);
                         } else {            // rtrnmr :680-703
                             if (first) {        // istcld(lev) == 1
                                 cldrad[j] = cf * radlu[j];
@@ -2458,9 +2508,9 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                             const double ttot = 1. - atot;
                             const double cldsrc = bbutot * atot;
                             cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                            clrrad[j] = clrrad[j] * (1.0 - atr[j]) + (1. - cf) * gassrc;
+                            clrrad[j] = clrrad[j] * (1.0 - atr) + (1. - cf) * gassrc;
                             radlu[j] = cldrad[j] + clrrad[j];
-                            const double radmod = radmr[j] * (mf.clr1 * (1.0 - atr[j]) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
+                            const double radmod = radmr[j] * (mf.clr1 * (1.0 - atr) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
                             const double oldcld = cldrad[j] - radmod;
                             const double oldclr = clrrad[j] + radmod;
                             radmr[j] = -radmod + mf.clr2 * oldclr - mf.cld2 * oldcld;
@@ -2469,12 +2519,12 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
                         }
                         usum = usum + radlu[j];
                         if (idrv) {
-                            drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr[j]);
+                            drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr);
                             dusum = dusum + drad[j];
-                            dradc[j] = dradc[j] * (1.0 - atr[j]);
+                            dradc[j] = dradc[j] * (1.0 - atr);
                             dusumc = dusumc + dradc[j];
                         }
-                        radclru[j] = radclru[j] + (bbu[j] - radclru[j]) * atr[j];
+                        radclru[j] = radclru[j] + (bbuj - radclru[j]) * atr;
                         usumc = usumc + radclru[j];
                     }
                 }
