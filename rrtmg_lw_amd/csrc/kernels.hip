@@ -134,7 +134,9 @@ __device__ __forceinline__ double fdiv(double a, double b)
 #else
     double r = __builtin_amdgcn_rcp(b);
     r = fma(fma(-b, r, 1.0), r, r);
+#ifndef RRLW_FDIV_ONE_NEWTON
     r = fma(fma(-b, r, 1.0), r, r);
+#endif
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 #endif
@@ -951,6 +953,9 @@ __device__ __forceinline__ void rows_to_lds(Rows<N> &rw, const unsigned (&delta)
 #ifndef RRLW_LOAD_CHUNK
 #define RRLW_LOAD_CHUNK 2       // loads in flight per pipeline stage.  From LDS two suffice (8 were needed through the vector L1) and the
 #endif                          // registers saved allow three waves per SIMD: 36.4 vs 40.9 ms per 1e6 cloudy columns
+#ifndef RRLW_SERIES_SKIP
+#define RRLW_SERIES_SKIP 0      // 1: a wave skips the table-index divisions of a quad whose cells are all thin (band_cells)
+#endif
 #ifndef RRLW_CLOUD_QUADS
 #define RRLW_CLOUD_QUADS 2      // quads of a band whose cloudy-layer look-ups are in flight together
 #endif
@@ -1096,17 +1101,20 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         scr4 c;
+        // the table index costs a float64 division (~16 instructions per cell, a third of k_layer's arithmetic); the 64 columns of a
+        // wave sit in the same layer, so thin g-points (upper atmosphere, band wings) are thin in all of them: a wave whose four cells
+        // of a quad all take the series branch skips the divisions (wave-uniform test; same values either way).  Per cell instead of
+        // per quad the 140 branches cost more than the divisions they skip (26.0 -> 27.3 ms per 1e6 cloudy columns).
+#if RRLW_SERIES_SKIP
+        const bool thick = od[4 * q] > 0.06 || od[4 * q + 1] > 0.06 || od[4 * q + 2] > 0.06 || od[4 * q + 3] > 0.06;
+        if (__builtin_amdgcn_ballot_w64(thick) == 0ull) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // the table index costs a float64 division (~16 instructions per cell, a third of k_layer's arithmetic); the 64 columns of a
-            // wave sit in the same layer, so thin g-points (upper atmosphere, band wings) are thin in all of them: a wave whose cells
-            // all take the series branch skips the division (wave-uniform test; same values either way)
-            const bool series = od[4 * q + k] <= 0.06;
-#ifdef RRLW_SERIES_SKIP          // (measured: k_layer 26.0 -> 27.3 ms per 1e6 cloudy columns - 140 wave-uniform branches per thread cost more than the skipped divisions)
-            if (__builtin_amdgcn_ballot_w64(!series) == 0ull) c.v[k] = (scr_t)od[4 * q + k];
-            else
+            for (int k = 0; k < 4; k++) c.v[k] = (scr_t)od[4 * q + k];
+        } else
 #endif
-                c.v[k] = cell_code(od[4 * q + k], series, bpade);
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++) c.v[k] = cell_code(od[4 * q + k], od[4 * q + k] <= 0.06, bpade);
         }
         if (incol) scr_store(W.scr[S_CODE], so0 + q * qstride, c);
     }
@@ -2030,7 +2038,7 @@ void k_sweep(DevTables T, Workspace W, SweepArgs a)
     // The code load is the one true HBM stream of the sweep (everything else a level needs hits L2); where the slot count is 1, the
     // codes alone get a second slot (4 registers): issued two levels ahead
 #ifndef RRLW_SWEEP_CODES2
-#define RRLW_SWEEP_CODES2 1
+#define RRLW_SWEEP_CODES2 0       // (the second code slot costs 8 registers; with the leaner branches of round 2 the kernel is faster without: 16.9 -> 16.2 ms)
 #endif
     constexpr bool CODES2 = RRLW_SWEEP_CODES2 && PF == 1;
 #ifdef RRLW_SWEEP_EARLY_ALL        // (tuning: rtrnmr at two waves, two slots and early refill 62.7 ms against 51.9 ms at three waves and one slot)
