@@ -251,3 +251,39 @@ class Reference:
                                        *[_p(o[k]) for k in ("cldfmc", "ciwpmc", "clwpmc", "reicmc", "relqmc", "taucmc")])
         o["irng"] = irng_c.value
         return o
+
+
+def reference_rrtatm_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_rrtatm.so"))
+
+
+def reference_rrtatm(path):
+    """The REFERENCE's own RRTATM (oracle/_ref/libref_rrtatm.so, oracle/ref_rrtatm_harness.f90) on the IATM = 1 records of an
+    INPUT_RRTM file -> dict(nlayers, pavel, tavel, pz, tz, altz, wkl(7, nlayers), wbrodl, nmol).  The harness skips the records readprof
+    itself reads before the call (src/rrtmg_lw.1col.f90:919-957)."""
+    import tempfile
+    lib = C.CDLL(os.path.join(HERE, "_ref", "libref_rrtatm.so"))
+    lines = open(path).read().splitlines()
+    p = 0
+    while not lines[p].startswith("$"):
+        p += 1
+    ctl = lines[p + 1].ljust(95)
+    idrv, icld = int(ctl[91:92].strip() or 0), int(ctl[94:95].strip() or 0)
+    p += 3                                    # '$' record, control record 1.2, surface record 1.4
+    if idrv == 1:
+        p += 1
+    if icld in (4, 5):
+        p += 2
+    mxl = 603
+    nlay, nmol = C.c_long(0), C.c_long(0)
+    pavel, tavel, wbrodl = np.zeros(mxl), np.zeros(mxl), np.zeros(mxl)
+    pz, tz, altz = np.zeros(mxl + 1), np.zeros(mxl + 1), np.zeros(mxl + 1)
+    wkl = np.zeros((mxl, 7))                  # Fortran wkl(7, mxl)
+    with tempfile.TemporaryDirectory() as td:
+        t6 = os.path.join(td, "TAPE6").encode()
+        pb = os.path.abspath(path).encode()
+        lib.ref_rrtatm(pb, C.c_long(len(pb)), C.c_long(p), t6, C.c_long(len(t6)), C.c_long(mxl), C.byref(nlay), _p(pavel), _p(tavel),
+                       _p(pz), _p(tz), _p(altz), _p(wkl), _p(wbrodl), C.byref(nmol))
+    n = nlay.value
+    return dict(nlayers=n, pavel=pavel[:n].copy(), tavel=tavel[:n].copy(), pz=pz[:n + 1].copy(), tz=tz[:n + 1].copy(),
+                altz=altz[:n + 1].copy(), wkl=wkl[:n].T.copy(), wbrodl=wbrodl[:n].copy(), nmol=nmol.value)

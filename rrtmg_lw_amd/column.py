@@ -5,7 +5,8 @@ The sequence of the reference's column driver (src/rrtmg_lw.1col.f90:440-704) ov
 switch asks for - IOUT = 0 the 10-3250 cm-1 total, 1..16 one band, 99 the total followed by the sixteen bands (:452-466,
 :689-696) - with IMCA = 1 as the mean over the driver's 200 Mersenne-Twister samples (:457-459, :471-480, :641-660) and with
 IDRV = 1 the adjustment of the upward fluxes by DTBOUND (:585-610), and write OUTPUT_RRTM in the driver's record formats.
-IATM = 1 inputs (RRTATM layering) are not supported.  There is no CPU path: a GPU and the built library are required.
+IATM = 1 inputs (a level sounding; the reference calls RRTATM) are layered by rrtmg_lw_amd/atmpth.py.  There is no CPU path: a GPU and
+the built library are required.
 """
 from __future__ import annotations
 
@@ -70,18 +71,21 @@ def run_case(col, cpdair=1004.0):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m rrtmg_lw_amd.column", description=__doc__.split("\n\n")[0])
-    ap.add_argument("input", help="INPUT_RRTM file (IATM = 0)")
+    ap.add_argument("input", help="INPUT_RRTM file (IATM = 0 or 1)")
     ap.add_argument("--cld", help="IN_CLD_RRTM file (needed when the input's ICLD > 0)")
     ap.add_argument("--aer", help="IN_AER_RRTM file (needed when the input's IAER = 10)")
     ap.add_argument("-o", "--output", default="OUTPUT_RRTM")
     ap.add_argument("--kdata", help="absorption-coefficient blob (default: data/rrtmg_lw.kdata.bin, else the stand-in with a warning)")
     ap.add_argument("--cpdair", type=float, default=1004.0, help="specific heat of dry air handed to rrtmg_lw_ini (the driver uses 1004.0)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--airmwt", type=float, default=0.0,
+                    help="IATM = 1: mean molecular weight of air for amounts given in g/kg; the reference leaves it unset (0: such amounts "
+                         "vanish, as in its output_rrtm_ICRCCM_sonde), its commented-out value is 28.964")
     a = ap.parse_args(argv)
     for f in (a.cld, a.aer):
         if f and not os.path.exists(f):
             raise SystemExit(f"{f} not found")
-    col = read_input_rrtm(a.input, a.cld, a.aer)
+    col = read_input_rrtm(a.input, a.cld, a.aer, airmwt=a.airmwt)
     api.rrtmg_lw_ini(a.cpdair, kdata=a.kdata, device=a.device)
     try:
         blocks = run_case(col, a.cpdair)

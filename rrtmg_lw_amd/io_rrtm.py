@@ -75,8 +75,12 @@ def read_aer(path, nlayers):
     return tau
 
 
-def read_input_rrtm(path, cld_path=None, aer_path=None):
+def read_input_rrtm(path, cld_path=None, aer_path=None, airmwt=0.0):
     """Parse one INPUT_RRTM case into the prepared-column dictionary handed to the physics.
+
+    IATM = 1 (a level sounding instead of layer amounts; the reference calls RRTATM, src/rrtmg_lw.1col.f90:998-1002) goes through
+    rrtmg_lw_amd/atmpth.py; `airmwt` is that module's switch between the reference's unset mean molecular weight of air (0: amounts given
+    in g/kg vanish, as in the reference's own output_rrtm_ICRCCM_sonde) and 28.964.
 
     Keys mirror readprof's outputs: nlayers, iout, imca, icld, iaer, idrv, pavel, tavel, pz, tz (0:nlayers),
     tbound, dtbound, semiss(16), coldry, wkl(7,nlayers), wbrodl, wx(4,nlayers), pwvcm, dz (m), inflag,
@@ -92,8 +96,6 @@ def read_input_rrtm(path, cld_path=None, aer_path=None):
     ctl = lines[p].ljust(95); p += 1
     iaer, iatm, ixsect = _i(ctl[18:20]), _i(ctl[49:50]), _i(ctl[69:70])
     iout, idrv, imca, icld = _i(ctl[87:90]), _i(ctl[91:92]), _i(ctl[93:94]), _i(ctl[94:95])
-    if iatm != 0:
-        raise NotImplementedError("IATM=1 (RRTATM layering) is out of scope")
     rec = lines[p].ljust(16 + 5 * NBND); p += 1
     tbound, iemiss = _f(rec[0:10]), _i(rec[11:12])
     semis = [_f(rec[15 + 5 * k:20 + 5 * k]) for k in range(NBND)]
@@ -115,6 +117,15 @@ def read_input_rrtm(path, cld_path=None, aer_path=None):
             if semis[k] != 0.0:
                 semiss[k] = semis[k]
 
+    if iatm == 1:
+        from . import atmpth
+        a, p = atmpth.rrtatm(lines, p, ixsect=ixsect, airmwt=airmwt)
+        nlayers, nmol = a["nlayers"], a["nmol"]
+        pavel, tavel, pz, tz, altz = a["pavel"], a["tavel"], a["pz"], a["tz"], a["altz"]
+        wkl = np.zeros((7, nlayers))
+        wkl[:min(nmol, 7)] = a["wkl"][:7]
+        wbrodl = a["wbrodl"]
+        return _finish_column(locals(), cld_path, aer_path)
     rec = lines[p].ljust(10); p += 1
     iform, nlayers, nmol = _i(rec[1:2]), _i(rec[2:5]), _i(rec[5:10])
     if nmol == 0:
@@ -164,6 +175,16 @@ def read_input_rrtm(path, cld_path=None, aer_path=None):
                 ln = lines[p].ljust(8 * wx3); p += 1
                 wx0[7:nxmol0, l] = [_f(ln[k * wx3:(k + 1) * wx3]) for k in range(nxmol0 - 7)]
 
+    return _finish_column(locals(), cld_path, aer_path)
+
+
+def _finish_column(v, cld_path, aer_path):
+    """Column amounts, precipitable water, cloud and aerosol files: what readprof does after the layer records (or RRTATM)."""
+    nlayers, nmol, iout, imca, icld, iaer, idrv = (v[k] for k in ("nlayers", "nmol", "iout", "imca", "icld", "iaer", "idrv"))
+    pavel, tavel, pz, tz, altz, wkl, wbrodl = (v[k] for k in ("pavel", "tavel", "pz", "tz", "altz", "wkl", "wbrodl"))
+    tbound, dtbound, semiss = v["tbound"], v["dtbound"], v["semiss"]
+    idcor, decorr_con, juldat, lat = v["idcor"], v["decorr_con"], v["juldat"], v["lat"]
+    wx0, ixindx = v.get("wx0"), v.get("ixindx", [])
     if tbound < 0:
         tbound = tz[0]
     # column amounts: readprof :1014-1060

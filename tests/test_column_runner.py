@@ -58,7 +58,8 @@ def test_write_then_read_round_trip(tmp_path):
 
 
 CASES = [("input_rrtm_MLS-clr", None, None), ("input_rrtm_MLS-clr-aer12", None, "in_aer_rrtm-aer12"),
-         ("input_rrtm_MLS-clr-idrv1", None, None), ("input_rrtm_MLS-cld-imca0-icld2", "in_cld_rrtm-cld5", None)]
+         ("input_rrtm_MLS-clr-idrv1", None, None), ("input_rrtm_MLS-cld-imca0-icld2", "in_cld_rrtm-cld5", None),
+         ("input_rrtm_ICRCCM_sonde", None, None)]           # (IATM = 1: layered by rrtmg_lw_amd/atmpth.py)
 
 
 @pytest.mark.gpu

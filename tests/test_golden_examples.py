@@ -18,7 +18,8 @@ needs_kdata = pytest.mark.skipif(not os.path.exists(api.REAL_KDATA),
 CASES = [("MLS-clr", "input_rrtm_MLS-clr", None, None), ("MLS-clr-aer12", "input_rrtm_MLS-clr-aer12", None, "in_aer_rrtm-aer12"),
          ("MLS-clr-idrv1", "input_rrtm_MLS-clr-idrv1", None, None), ("MLS-clr-xsec", "input_rrtm_MLS-clr-xsec", None, None),
          ("MLS-cld5-imca0-icld2", "input_rrtm_MLS-cld-imca0-icld2", "in_cld_rrtm-cld5", None),
-         ("MLW-clr", "input_rrtm_MLW-clr", None, None), ("SAW-clr", "input_rrtm_SAW-clr", None, None), ("TROP-clr", "input_rrtm_TROP-clr", None, None)]
+         ("MLW-clr", "input_rrtm_MLW-clr", None, None), ("SAW-clr", "input_rrtm_SAW-clr", None, None), ("TROP-clr", "input_rrtm_TROP-clr", None, None),
+         ("ICRCCM_sonde", "input_rrtm_ICRCCM_sonde", None, None)]        # IATM = 1 (rrtmg_lw_amd/atmpth.py, the reference's unset AIRMWT)
 
 
 MC_CASES = [("MLS-cld5-imca1-icld2", "input_rrtm_MLS-cld-imca1-icld2", "in_cld_rrtm-cld5"),

@@ -107,5 +107,5 @@ def test_input_and_output_readers():
     assert a["iaer"] == 10 and np.count_nonzero(a["tauaer"].sum(axis=1)) == 12
     o = read_output_rrtm(os.path.join(G, "output_rrtm_MLS-clr"))
     assert len(o) == 17 and o[0]["level"][0] == 0 and o[0]["uflx"][0] == 424.7960 and (o[16]["wn1"], o[16]["wn2"]) == (2600.0, 3250.0)
-    with pytest.raises(NotImplementedError):
-        read_input_rrtm(os.path.join(G, "input_rrtm_ICRCCM_sonde"))
+    s = read_input_rrtm(os.path.join(G, "input_rrtm_ICRCCM_sonde"))          # IATM = 1: tests/test_atmpth.py
+    assert s["nlayers"] == 31 and s["tbound"] == 290.93 and abs(s["pz"][0] - 973.6) < 1e-9

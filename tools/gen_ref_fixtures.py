@@ -65,7 +65,21 @@ def g256():
     print("wrote 256-g-point fixtures to", G)
 
 
+RRTATM_CASES = ("input_rrtm_ICRCCM_sonde", "input_rrtm_iatm1_model6", "input_rrtm_iatm1_units")
+
+
+def rrtatm():
+    """ref_rrtatm_*.npz: the reference's own RRTATM (oracle/_ref/libref_rrtatm.so) on the IATM = 1 inputs."""
+    from oracle.bindings import reference_rrtatm
+    for name in RRTATM_CASES:
+        r = reference_rrtatm(os.path.join(G, name))
+        np.savez_compressed(os.path.join(G, "ref_rrtatm_" + name.replace("input_rrtm_", "") + ".npz"), inp=name, **r)
+    print("wrote RRTATM fixtures to", G)
+
+
 def main():
+    if "--rrtatm" in sys.argv:      # only the IATM = 1 layering fixtures
+        return rrtatm()
     if "--g256" in sys.argv:        # only the 256-g-point fixtures (the others are left untouched)
         return g256()
     ref = Reference("nomcica")
