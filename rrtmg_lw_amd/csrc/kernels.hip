@@ -866,7 +866,10 @@ template <int B> constexpr int stage_max() { return std::max(std::max(Stage<B, t
 template <> constexpr int stage_max<0>() { return 0; }
 constexpr int STAGE_DOUBLES = stage_max<16>();       // 5166 doubles = 41.3 KB (bands 3 and 5, lower atmosphere)
 
-constexpr int LAYER_BLOCK = 256;   // threads of a k_layer workgroup: three workgroups per CU (a 41 KB staging buffer each), three waves per SIMD
+#ifndef RRLW_LAYER_BLOCK
+#define RRLW_LAYER_BLOCK 256      // (measured: 192 threads 29.9 ms, 256 25.5, 384 43.0, 512 35.5 per 1e6 cloudy columns)
+#endif
+constexpr int LAYER_BLOCK = RRLW_LAYER_BLOCK;   // threads of a k_layer workgroup: three workgroups per CU (a 41 KB staging buffer each), three waves per SIMD
 
 // One segment of a band's staging list: [g0, g0 + N) doubles of the packed table buffer -> lds[l0 ..) (all even).  The copy of a band
 // is two-phase - every thread first issues ALL its 16-byte loads of ALL segments (at most 11, independent), then writes them to LDS -
