@@ -333,3 +333,26 @@ def test_north_star_mapping_prototype(hip, oracle):
     _compare(gota, oracle.rrtmg_lw(70, 51, 0, 0, da), 0, "k_n1 aerosol 51")
     again = hip.rrtmg_lw_from_dict(d, icld=0)                        # the production path, after the switch is off again
     assert np.abs(again["uflx"] - got["uflx"]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,nlay,icld,ncol", [("cloudy", 72, 2, 24576), ("aer_idrv", 137, 2, 6144), ("clear", 72, 0, 16384)])
+def test_large_sample_parity(hip, oracle, config, nlay, icld, ncol):
+    """Tens of thousands of columns (3.4 million cells x 140 g-points in the first case) against the oracle: the per-cell decisions -
+    series or table, the table index formed with the reciprocal-based division - are the only place where a last-bit difference could
+    show as more than rounding, one table step (~1e-6 W m-2 per cell) at a time; the worst column must stay inside the regression bar,
+    and the sample spans more than one device batch boundary when the batch is set small."""
+    d = make_gcm_inputs(ncol, nlay, config, col0=100000)
+    hip.set_batch(8192)
+    try:
+        got = hip.rrtmg_lw_from_dict(d, icld=icld)
+    finally:
+        hip.set_batch(262144)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+    dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
+    dhr = max(np.abs(got[k] - ref[k]).max() for k in ("hr", "hrc"))
+    print(f"large sample {config} L{nlay} icld{icld} x {ncol}: max|dflux|={dflux:.3e} max|dhr|={dhr:.3e}")
+    assert dflux <= 0.01 and dhr <= 0.001
+    assert dflux <= 5e-5 and dhr <= 5e-5
+    if d["idrv"]:
+        assert max(np.abs(got[k] - ref[k]).max() for k in ("duflx_dt", "duflxc_dt")) <= 5e-5
