@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrtmg_lw_hip.h"
@@ -1278,6 +1279,19 @@ int rrtmg_lw_hip_queue_add(
 
 }   // extern "C" (the flush calls rrtmg_lw_hip_run_nomcica, which takes the entry lock itself)
 
+// f(i) for i in [0, n) on up to 8 host threads (contiguous index ranges)
+template <class F>
+static void queue_parallel(size_t n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
+    if (n < 64 || nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([=, &f]() { for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) f(i); });
+    for (auto &x : th) x.join();
+}
+
 extern "C" int rrtmg_lw_hip_queue_flush(void)
 {
     size_t in_inner[23], in_rows[23], out_rows[8];
@@ -1302,17 +1316,18 @@ extern "C" int rrtmg_lw_hip_queue_flush(void)
         for (int k = 0; k < 8; k++) { out_p[k] = p; p += out_rows[k] * (size_t)N; }
         // pack: every array is [rows][columns][inner] - row r of a chunk goes to row r of the packed array at the chunk's column offset
         const bool cloud = !(Q.icld == 0);
-        size_t off = 0;
-        for (const QueuedChunk &c : Q.chunks) {
+        std::vector<size_t> offs(Q.chunks.size());
+        { size_t off = 0; for (size_t i = 0; i < Q.chunks.size(); i++) { offs[i] = off; off += (size_t)Q.chunks[i].ncol; } }
+        queue_parallel(Q.chunks.size(), [&](size_t i) {          // (the copies are many short rows: host-bound, spread over a few threads)
+            const QueuedChunk &c = Q.chunks[i];
             for (int k = 0; k < 23; k++) {
                 const bool cloud_arr = k >= 16 && k <= 21;
                 if (cloud_arr && !cloud) continue;
                 const size_t w = in_inner[k] * (size_t)c.ncol;
                 for (size_t r = 0; r < in_rows[k]; r++)
-                    memcpy(in_p[k] + (r * (size_t)N + off) * in_inner[k], c.in[k] + r * w, w * sizeof(double));
+                    memcpy(in_p[k] + (r * (size_t)N + offs[i]) * in_inner[k], c.in[k] + r * w, w * sizeof(double));
             }
-            off += (size_t)c.ncol;
-        }
+        });
     }
     int icld = Q.icld;
     const bool cloud = !(Q.icld == 0);
@@ -1324,16 +1339,17 @@ extern "C" int rrtmg_lw_hip_queue_flush(void)
                                             Q.idrv == 1 ? out_p[6] : nullptr, Q.idrv == 1 ? out_p[7] : nullptr);
     ENTRY_LOCK;
     if (rc == 0) {
-        size_t off = 0;
-        for (const QueuedChunk &c : Q.chunks) {
+        std::vector<size_t> offs(Q.chunks.size());
+        { size_t off = 0; for (size_t i = 0; i < Q.chunks.size(); i++) { offs[i] = off; off += (size_t)Q.chunks[i].ncol; } }
+        queue_parallel(Q.chunks.size(), [&](size_t i) {
+            const QueuedChunk &c = Q.chunks[i];
             for (int k = 0; k < 8; k++) {
                 if (!c.out[k] || (k >= 6 && Q.idrv != 1)) continue;
                 for (size_t r = 0; r < out_rows[k]; r++)
-                    memcpy(c.out[k] + r * (size_t)c.ncol, out_p[k] + r * (size_t)N + off, (size_t)c.ncol * sizeof(double));
+                    memcpy(c.out[k] + r * (size_t)c.ncol, out_p[k] + r * (size_t)N + offs[i], (size_t)c.ncol * sizeof(double));
             }
             if (c.icld) *c.icld = icld;
-            off += (size_t)c.ncol;
-        }
+        });
     }
     Q.chunks.clear();
     Q.ncol = 0;
