@@ -760,7 +760,7 @@ struct MT19937 {
 // kissvec masks of columns col0 .. col0+nb-1 (of ncol) on stream s; G.W.mask must be set up (prepare_mask)
 int launch_kiss(hipStream_t s, const Workspace &Wk, int ncol, int col0, int nb, int nlay, int icld, int permuteseed, const SubcolIn &in)
 {
-    const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned);
+    const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned short);
     const dim3 grid((nb + SUBCOL_BLOCK - 1) / SUBCOL_BLOCK), block(SUBCOL_BLOCK);
     if (G.profile) {
         State::ProfRec r{"k_subcol_kiss", get_event(), get_event()};
@@ -787,7 +787,7 @@ int prepare_mask(int ncol, int nlay, int icld, int irng, const double *alpha)
     G.W.mask_col0 = 0;
     G.W.err = G.d_err;
     if (irng == 0) {
-        const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned);
+        const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned short);
         if (lds > 160 * 1024) return fail(RRTMG_LW_HIP_EARG, "nlay=%d exceeds the generator's LDS budget", nlay);
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

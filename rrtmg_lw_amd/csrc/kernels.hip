@@ -1638,7 +1638,9 @@ constexpr int SUBCOL_BLOCK = 64;
 __global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn in, int ncol, int col0, int nb, int nlay, int icld, int permuteseed)
 {
 #pragma clang fp contract(off)
-    extern __shared__ unsigned acc[];                           // [nlay][SUBCOL_BLOCK]
+    // the masks of 16 sub-columns at a time, [nlay][SUBCOL_BLOCK] halfwords: 9 KB per wave at 72 layers (32 sub-columns in words took
+    // 18 KB and left two waves per SIMD for a kernel that is one dependent integer chain per lane)
+    extern __shared__ unsigned short acc[];
     const int tid = threadIdx.x;
     if (blockIdx.x * SUBCOL_BLOCK + tid >= nb) return;
     const size_t gc = (size_t)col0 + (size_t)blockIdx.x * SUBCOL_BLOCK + tid;
@@ -1656,9 +1658,9 @@ __global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, Subco
     for (int q = 0; q < permuteseed; q++) (void)kiss_next(s);                       // :471-474
     const bool two = icld == 4 || icld == 5;
 #pragma unroll 1
-    for (int w = 0; w < 5; w++) {
-        for (int l = 0; l < nlay; l++) acc[l * SUBCOL_BLOCK + tid] = 0u;
-        const int nb = min(32, NGPT - 32 * w);
+    for (int w = 0; w < (NGPT + 15) / 16; w++) {
+        for (int l = 0; l < nlay; l++) acc[l * SUBCOL_BLOCK + tid] = (unsigned short)0;
+        const int nb = min(16, NGPT - 16 * w);
 #pragma unroll 1
         for (int k = 0; k < nb; k++) {
             double r3 = 0.0;
@@ -1686,12 +1688,17 @@ __global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, Subco
                         if (cf < cldmin) cf = 0.0;
                         x = overlap_rule(icld, l, x, x2, prev, cf_below, alc[i]);
                         prev = x; cf_below = cf;
-                        if (x >= 1. - cf) acc[l * SUBCOL_BLOCK + tid] |= 1u << k;               // :655-661
+                        if (x >= 1. - cf) acc[l * SUBCOL_BLOCK + tid] |= (unsigned short)(1u << k);    // :655-661
                     }
                 }
             }
         }
-        for (int l = 0; l < nlay; l++) W.mask[((size_t)w * nlay + l) * W.mask_stride + gc] = acc[l * SUBCOL_BLOCK + tid];
+        // halfword (w & 1) of mask word w / 2 (little endian: sub-column 16 w + k = bit 16 (w & 1) + k)
+        for (int l = 0; l < nlay; l++) {
+            unsigned short *m = reinterpret_cast<unsigned short *>(&W.mask[((size_t)(w >> 1) * nlay + l) * W.mask_stride + gc]);
+            m[w & 1] = acc[l * SUBCOL_BLOCK + tid];
+            if (w == (NGPT + 15) / 16 - 1 && (w & 1) == 0) m[1] = (unsigned short)0;        // (the unused upper half of the last word)
+        }
     }
 }
 
