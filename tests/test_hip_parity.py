@@ -221,20 +221,43 @@ def _special_cloud_inputs(ncol, nlay, kind):
             same = cloudy[:, l] & cloudy[:, l - 1] & (rng.random(ncol) < 0.3)
             cf[same, l] = cf[same, l - 1]
         d["cldfr"] = np.asfortranarray(cf)
+    elif kind == "toplayer":                          # cloud in the top layer: nothing lies above the cloud zone (ltop = nlay)
+        cf[:, nlay - 1] = np.where(rng.random(ncol) < 0.5, 0.6, 0.0)
+        d["cldfr"] = np.asfortranarray(cf)
+        for k in ("cliqwp", "cicewp"):
+            a = np.array(d[k]); a[:, nlay - 1] = np.where(cf[:, nlay - 1] > 0, 20.0, 0.0); d[k] = np.asfortranarray(a)
+    elif kind == "bottomonly":                        # clouds in the lowest layer only (ltop = 1)
+        cf[:, 1:] = 0.0
+        cf[:, 0] = np.where(rng.random(ncol) < 0.6, 0.7, 0.0)
+        d["cldfr"] = np.asfortranarray(cf)
+        for k in ("cliqwp", "cicewp"):
+            a = np.array(d[k]); a[:, 1:] = 0.0; a[:, 0] = np.where(cf[:, 0] > 0, 30.0, 0.0); d[k] = np.asfortranarray(a)
+    elif kind == "nocloud":                           # a cloudy-mode call whose batch holds no cloud at all (ltop = 0)
+        d["cldfr"] = np.asfortranarray(cf * 0.0)
     elif kind == "thin":
         d["cldfr"] = np.asfortranarray(np.where(cf > 0, np.where(rng.random(cf.shape) < 0.5, 5e-7, 2e-6), 0.0))   # around rtrn's 1e-6 threshold
     return d
 
 
-@pytest.mark.parametrize("kind", ["inflag0", "overcast", "thin"])
+@pytest.mark.parametrize("kind", ["inflag0", "overcast", "thin", "toplayer", "bottomonly", "nocloud"])
 @pytest.mark.parametrize("icld", [1, 2])
 def test_special_cloud_configurations(hip, oracle, kind, icld):
     ncol, nlay = 300, 60
     d = _special_cloud_inputs(ncol, nlay, kind)
     got = hip.rrtmg_lw_from_dict(d, icld=icld)
     ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
-    _compare(got, ref, d["idrv"], f"{kind} icld={icld}")
-    if kind != "thin":
+    if kind == "toplayer":
+        # An (unphysical) water cloud in the 0.03 hPa thick top layer: the heating rate of that layer is the flux divergence times
+        # 8.4 / dp[hPa] = 280 K d-1 per W m-2, so the float32 transmittance of the cloud (7e-6 W m-2 in the fluxes, inside the bar like
+        # everywhere else) shows as 2e-3 K d-1 there - 1e-5 of the layer's own heating rate.  Fluxes at the usual bar, rates relative.
+        dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
+        rel = max((np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1.0)).max() for k in ("hr", "hrc"))
+        print(f"{kind} icld={icld}: max|dflux|={dflux:.3e} W/m2  max relative dhr={rel:.3e}")
+        assert dflux <= TIGHT_FLUX and rel <= 1e-4
+        assert np.abs(got["hr"][:, :-1] - ref["hr"][:, :-1]).max() <= TIGHT_HR          # every layer below the top one: the usual bar
+    else:
+        _compare(got, ref, d["idrv"], f"{kind} icld={icld}")
+    if kind not in ("thin", "nocloud"):
         assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
 
 
