@@ -55,6 +55,7 @@ struct State {
                                  // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -1 %)
     bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device
     bool n1 = false;             // RRTMG_LW_N1=1: cloud-free calls take the north-star-mapping prototype k_n1 (measurement only)
+    bool sweepz = true;          // RRTMG_LW_SWEEPZ=0: the cloud zone of rtrnmr calls goes through k_sweep<2, .> instead of k_sweepz (measurement only)
     bool ws_two_scr = false;     // the workspace holds the second scratch set that split_sweep needs
     // host-entry staging
     void *stage_base = nullptr;
@@ -204,6 +205,10 @@ int sweep_attr_mode()
 int ensure_sweep_attrs()
 {
     if (G.sweep_attrs) return 0;
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     if (int rc = sweepc_attr_one<1>()) return rc;
     if (int rc = sweepc_attr_one<2>()) return rc;
     if (int rc = sweepc_attr_one<3>()) return rc;
@@ -235,6 +240,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         {(void **)&W.gup1, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(double)},
         {(void **)&W.gup, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.gdp, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.gdn, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.dpart, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
     };
     const bool two_scr = G.split_sweep;
@@ -461,7 +467,28 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #define SWEEP(M, Q) do { if (idrv == 1) SWEEP_I(M, Q, true); else SWEEP_I(M, Q, false); } while (0)
 #define SWEEP_MODE(Q) do { if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q); } while (0)
 #define SWEEP_Q() do { if (nq == 4) SWEEP_MODE(4); else if (nq == 3) SWEEP_MODE(3); else if (nq == 2) SWEEP_MODE(2); else SWEEP_MODE(1); } while (0)
+    const bool zone_groups = G.sweepz && mode == 2 && idrv != 1;       // the cloud zone's partials arrive per group (k_sweepz)
     for (int phase = 0; phase < 3; phase++) {
+        if (phase == 1 && zone_groups) {            // cloud zone, rtrnmr without d/dT: k_sweepz, one launch per group
+            for (int g = 0; g < fg.n; g++) {
+                const int nq = gq[g];
+                sa.bands = fg.bands[g];
+                sa.nbands = fg.nb[g];
+                sa.group = g;
+                const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;
+#define SWEEPZ(Q)                                                                                                    \
+    do {                                                                                                             \
+        constexpr int nt = sweepz_nt(Q);                                                                             \
+        const int nsb = sweepz_nsb(Q, sa.nbands);                                                                    \
+        sa.ncb = (nb + 64 * nsb - 1) / (64 * nsb);                                                                   \
+        const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands * nt, nsb);                                         \
+        LAUNCH_LDS("k_sweepz<" #Q ">", (k_sweepz<Q>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt), s, G.D, Wk, sa); \
+    } while (0)
+                if (nq == 4) SWEEPZ(4); else if (nq == 3) SWEEPZ(3); else if (nq == 2) SWEEPZ(2); else SWEEPZ(1);
+#undef SWEEPZ
+            }
+            continue;
+        }
         if (phase == 1) {                           // cloud zone: one launch per class of bands
             if (mode == 0) continue;
             for (int nq = 4; nq >= 1; nq--) {
@@ -499,7 +526,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         }
     }
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
-    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg);
+    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, zone_groups ? 1 : 0, fg);
     LAUNCH("k_rates", k_rates, rgrid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -888,6 +915,8 @@ int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, do
     {
         const char *e = std::getenv("RRTMG_LW_N1");
         G.n1 = e && e[0] == '1';
+        const char *z = std::getenv("RRTMG_LW_SWEEPZ");
+        G.sweepz = !(z && z[0] == '0');
     }
     G.init = true;
     G.err.clear();

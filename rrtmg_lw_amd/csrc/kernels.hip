@@ -85,7 +85,7 @@ struct Workspace {
     // LDS): [NGROUP_MAX][nlay+1][ncolb].  gdn1 / gup1: 8 bytes where the clear-sky stream equals the total one (downward at and above the
     // batch's highest cloud, both directions of a cloud-free call); gup / gdp {total, clear}: upward above the clouds, d(flux)/dT
     double *gdn1, *gup1;
-    Part2 *gup, *gdp;
+    Part2 *gup, *gdp, *gdn;     // gdn {total, clear}: downward inside the cloud zone (k_sweepz)
     Part2 *dpart;       // [16 bands][nlay+1][ncolb]  (idrv = 1)
     int *err;           // [1] first physics error code
     // McICA (rtrnmc): per-g-point cloud terms, written by k_cloudmc
@@ -2931,6 +2931,305 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_sweepz : the cloud zone (layers 1 .. ltop) of the maximum-random-overlap sweep, rtrnmr (src/rrtmg_lw_rtrnmr.f90:509-704), without
+//            d(flux)/dT, in k_sweepc's form: one thread = (column, G quads of a band), a workgroup = the bands of one group, every load
+//            issued on every path (the cloudy level's extra inputs - total-optical-depth codes, cloud fraction, overlap factors - are
+//            read for every level of the zone) so that the waits are counted ones, partials added over the group in LDS every two
+//            levels, ONE barrier per round.  A wave none of whose 64 columns is cloudy at a level runs the clear-sky body; otherwise
+//            both updates are formed and selected per lane (what divergence does anyway).  k_sweep<2, ., false> did the same work at
+//            1.9x the time per clear level (per-quad duplication of the level's Planck terms, conditional loads with full waits, two
+//            barriers per four levels).  The other modes (rtrn, rtrnmc, d/dT) stay with k_sweep.
+// ------------------------------------------------------------------------------------------------
+#ifndef RRLW_SWEEPZ_G2
+#define RRLW_SWEEPZ_G2 0          // 1: two quads per thread for bands of 4 and 2 quads (253 registers, two waves per SIMD: measured slower)
+#endif
+__host__ __device__ constexpr int sweepz_g(int NQ) { return (RRLW_SWEEPZ_G2 && (NQ == 4 || NQ == 2)) ? 2 : 1; }          // quads per thread
+__host__ __device__ constexpr int sweepz_nt(int NQ) { return NQ / sweepz_g(NQ); }                    // threads (waves) per band
+#ifndef RRLW_SWEEPZ_WAVES_G2
+#define RRLW_SWEEPZ_WAVES_G2 2
+#endif
+#ifndef RRLW_SWEEPZ_WAVES_G1
+#define RRLW_SWEEPZ_WAVES_G1 3
+#endif
+__host__ __device__ constexpr int sweepz_waves(int NQ) { return sweepz_g(NQ) == 2 ? RRLW_SWEEPZ_WAVES_G2 : RRLW_SWEEPZ_WAVES_G1; }
+__host__ __device__ constexpr int sweepz_lds_bytes(int nb, int nsb, int NT)
+{
+    return SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES + 2 * 2 * nb * NT * RRLW_SWEEPC_CODES * nsb * 64 * 8;
+}
+__host__ __device__ constexpr int sweepz_nsb(int NQ, int nb)
+{
+    const int nt = sweepz_nt(NQ);
+    int nsb = 4 * sweepz_waves(NQ) / (nb * nt);
+    if (nsb < 1) nsb = 1;
+    while (nsb > 1 && sweepz_lds_bytes(nb, nsb, nt) > SWEEPC_LDS_MAX) nsb--;
+    return nsb;
+}
+
+struct SweepzLev { double tl, tz, cf; unsigned w, flag; };
+
+template <int NQ>
+__global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sweepz(DevTables T, Workspace W, SweepArgs a)
+{
+    constexpr int G = sweepz_g(NQ), NT = sweepz_nt(NQ), NG = 4 * G, NC = RRLW_SWEEPC_CODES, NVAL = 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tx = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y), sub = __builtin_amdgcn_readfirstlane(threadIdx.z);
+    const int bi = ty / NT, part = ty % NT;
+    const int ny = blockDim.y, nb = ny / NT, nsb = blockDim.z, ncw = 64 * nsb;
+    const float2 *s_lut = reinterpret_cast<const float2 *>(smem);
+    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES);
+    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES + SWEEP_PL_BYTES);
+    double *red = reinterpret_cast<double *>(smem + SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES);      // [2][NVAL][ny][NC][ncw]
+    const int cblock = blockIdx.x;
+    const int col = (cblock * nsb + sub) * 64 + tx;
+    const int B = (int)((a.bands >> (4 * bi)) & 15ull) + 1;
+    const bool incol = col < a.ncol;
+    const int colc = incol ? col : a.ncol - 1;
+    const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B) + part * G);
+    const int g0 = NG * part;
+    const size_t gc = (size_t)a.col0 + colc;
+    const int nlay = W.nlay, nct = a.nct;
+    const size_t ncb = W.ncolb;
+    const bool alt16 = (B == 16 && a.istart == 16);
+    const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
+    const bool any_bin = lo_bin || up_bin;
+    const int base_up = ((UP_ZERO >> (B - 1)) & 1u) ? 14 : (((UP_FROM_A >> (B - 1)) & 1u) ? 0 : 9);
+    sweep_stage_lut(T, smem, (sub * ny + ty) * 64 + tx, 64 * ny * nsb);
+    sweep_stage_band(T, s_pl, s_fr, B, alt16, lo_bin, up_bin, (sub * NT + part) * 64 + tx, NT * ncw);
+    __syncthreads();
+    const int ltop = __builtin_amdgcn_readfirstlane(*W.ltop);                  // layers 1 .. ltop
+    const size_t qstride = (size_t)nlay * ncb;
+    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)quad * qstride;
+    const scr4 *__restrict__ sCt = reinterpret_cast<const scr4 *>(W.scr[S_CODET]) + (size_t)quad * qstride;
+    const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
+    const int *__restrict__ sFlag = W.cflag;
+    const double *__restrict__ tlay = a.tlay + a.col0;
+    const double *__restrict__ tlev = a.tlev + a.col0;
+    const double *__restrict__ cldf = a.cldfrac + a.col0;
+    const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
+    const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;
+    Part2 *__restrict__ gdn = W.gdn + gslab;
+    Part2 *__restrict__ gup = W.gup + gslab;
+    const unsigned so16 = (unsigned)col * 16u;
+    const int laytrop = W.laytrop[colc];
+    const double *tp0 = s_pl[0], *tp1 = s_pl[1];
+    double2 *hand = reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2;
+    const size_t hstream = (size_t)NQUAD * ncb * 2;
+    const bool colcloud = (bload_u32(sFlag, off4) & 8u) != 0;
+
+    auto clampl = [&](int lev) { return min(max(lev, 1), nlay); };
+    // the level's own inputs, one level ahead; zoff: 0 = interface below the layer (downward), 1 = above (upward)
+    auto fill_t = [&](auto bin_tag, int lev, int zoff, SweepzLev &q) {
+        const int l = clampl(lev);
+        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8);
+        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8);
+        q.cf = bload_f64(cldf + (size_t)nct * (l - 1), off8);
+        q.flag = bload_u32(sFlag + (size_t)l * ncb, off4);
+        if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
+    };
+    auto ld_c = [&](const scr4 *base, int lev, int k) -> scr4 { return bload_scr4_nt(base + k * qstride + (size_t)(clampl(lev) - 1) * ncb, off16); };
+    auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
+        const bool lower = lev <= laytrop;
+        if (any_bin) {          // uniform
+            const unsigned w = (lower ? lo_bin : up_bin) ? fwv : 0x10000000u;
+            const int r0 = clampi((lower ? 0 : base_up) + (int)(w >> 28) - 1, 0, 14);
+            fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
+            return &s_fr[r0][g0];
+        }
+        fpl = 0.0;
+        return &s_fr[lower ? 0 : base_up][g0];
+    };
+
+    // reduction over the group, as in k_sweepc (raw sums in, band weight applied by the reducing wave)
+    const unsigned rlane = (unsigned)(sub * 64 + tx);
+    const unsigned vstride = (unsigned)(ny * NC * ncw), rband = (unsigned)(ty * NC * ncw);
+    unsigned bufoff = 0u;
+    auto red_put = [&](int c, int val, double v) { red[bufoff + val * vstride + rband + (unsigned)(c * ncw) + rlane] = v; };
+    auto round_end = [&](auto dn_tag, int lev0, int nvalid) __attribute__((always_inline)) {
+        constexpr bool DN = decltype(dn_tag)::value;
+        __syncthreads();
+        for (int c = ty; c < nvalid; c += ny) {       // (wave-uniform)
+            const int lvl = DN ? lev0 - c - 1 : lev0 + c;
+            double sv[NVAL];
+#pragma unroll
+            for (int val = 0; val < NVAL; val++) {
+                const double *r = red + (bufoff + val * vstride + (unsigned)(c * ncw) + rlane);
+                double sum = 0.0;
+                for (int q = 0; q < nb; q++) {
+                    double pq = r[(unsigned)(q * NT * NC * ncw)];
+#pragma unroll
+                    for (int t = 1; t < NT; t++) pq = pq + r[(unsigned)((q * NT + t) * NC * ncw)];
+                    const double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
+                    sum = q == 0 ? v : sum + v;
+                }
+                sv[val] = sum;
+            }
+            if (incol) bstore_f64x2((DN ? gdn : gup) + (size_t)lvl * ncb, so16, sv[0], sv[1]);
+        }
+        bufoff = bufoff ? 0u : NVAL * vstride;
+    };
+
+    // state: total-sky radiance, clear-sky radiance, rtrnmr's cloudy / clear parts and carried correction, per g-point
+    double rad[NG], radc[NG], cldrad[NG], clrrad[NG], radmr[NG];
+#pragma unroll
+    for (int j = 0; j < NG; j++) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
+    {                               // downward radiances at level ltop from k_sweepc<., 1>; clear = total up there
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const double2 h0 = hand[(size_t)k * ncb * 2], h1 = hand[(size_t)k * ncb * 2 + 1];
+            rad[4 * k] = h0.x; rad[4 * k + 1] = h0.y; rad[4 * k + 2] = h1.x; rad[4 * k + 3] = h1.y;
+        }
+#pragma unroll
+        for (int j = 0; j < NG; j++) radc[j] = rad[j];
+    }
+    bool seen = false;              // downward: a cloud lies above (iclddn); upward: the column holds cloud (set before the upward sweep)
+
+    SweepzLev cur;
+    cur.w = 0u;
+    scr4 cc[G][NC], ct[G][NC];
+    // One level.  DN: downward (Planck difference towards the interface below, partial of level lev - 1, istcldd = flag bit 1), else
+    // upward (istcld = bit 2).  The overlap factors of the level are requested first and used last.
+    auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) __attribute__((always_inline)) {
+        constexpr bool BIN = decltype(bin_tag)::value, DN = decltype(dn_tag)::value;
+        constexpr int dir = DN ? -1 : 1;
+        const double2 *ov = W.ovl + ((size_t)((DN ? 0 : nlay + 1) + clampl(lev)) * 3) * ncb;
+        const double2 f0 = bload_f64x2(ov, off16), f1 = bload_f64x2(ov + ncb, off16), f2 = bload_f64x2(ov + 2 * ncb, off16);
+        double fpl;
+        const double *row = frac_row(lev, cur.w, fpl);
+        const double blay = planck_at(tp0, tp0, cur.tl);
+        const double dpl = planck_at(tp0, (DN && alt16 && lev == 1) ? tp1 : tp0, cur.tz) - blay;
+        const bool cloudy = (cur.flag & 1u) != 0u;
+        const bool first = (cur.flag & (DN ? 2u : 4u)) != 0u;
+        const double cf = cur.cf;
+        const bool anycld = __builtin_amdgcn_ballot_w64(cloudy) != 0ull;       // (wave-uniform)
+        fill_t(bin_tag, lev + dir, DN ? 0 : 1, cur);
+        double qs[G], qsc[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            scr4 ck, ckt;
+#pragma unroll
+            for (int c = 0; c < NC; c++) if (c == slot) { ck = cc[k][c]; ckt = ct[k][c]; }
+            float2 e[4], et[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) e[jj] = RRLW_LUT_ENTRY(s_lut, code_index(ck.v[jj]));
+            if (anycld) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) et[jj] = RRLW_LUT_ENTRY(s_lut, min(code_index(ckt.v[jj]), (unsigned)NTBL));
+            }
+            {
+                const scr4 nx = ld_c(sC, lev + NC * dir, k), nxt = ld_c(sCt, lev + NC * dir, k);
+#pragma unroll
+                for (int c = 0; c < NC; c++) if (c == slot) { cc[k][c] = nx; ct[k][c] = nxt; }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * k + jj;
+                double atr, tfn;
+                decode(ck.v[jj], e[jj], atr, tfn);
+                double fr = row[j];
+                if constexpr (BIN) fr = fr + fpl * (row[16 + j] - fr);
+                const double bb = fr * (blay + tfn * dpl);
+                // clear level: rtrnmr :617-627 / :705-716
+                const double rad_s = rad[j] + (bb - rad[j]) * atr;
+                const double updc = radc[j] + (bb - radc[j]) * atr;
+                if (!anycld) {
+                    rad[j] = rad_s;
+                    radc[j] = seen ? updc : rad_s;
+                } else {
+                    // cloudy level: rtrnmr :591-615 / :680-703, formed for every lane of the wave and selected
+                    double atot, tftot;
+                    decode(ckt.v[jj], et[jj], atot, tftot);
+                    const double bbtot = fr * (blay + tftot * dpl);
+                    const double gassrc = bb * atr;
+                    double cr = cldrad[j], lr = clrrad[j], mr = radmr[j];
+                    if (first) { cr = cf * rad[j]; lr = rad[j] - cr; mr = 0.0; }
+                    const double ttot = 1. - atot;
+                    const double cldsrc = bbtot * atot;
+                    cr = cr * ttot + cf * cldsrc;
+                    lr = lr * (1. - atr) + (1. - cf) * gassrc;
+                    const double rad_c = cr + lr;
+                    const double radmod = mr * (f0.x * (1. - atr) + f0.y * ttot) - f1.x * gassrc + f1.y * cldsrc;
+                    const double oldcld = cr - radmod;
+                    const double oldclr = lr + radmod;
+                    mr = -radmod + f2.x * oldclr - f2.y * oldcld;
+                    cr = cr + mr;
+                    lr = lr - mr;
+                    rad[j] = cloudy ? rad_c : rad_s;
+                    cldrad[j] = cloudy ? cr : cldrad[j];
+                    clrrad[j] = cloudy ? lr : clrrad[j];
+                    radmr[j] = cloudy ? mr : radmr[j];
+                    radc[j] = (cloudy || seen) ? updc : rad_s;
+                }
+            }
+            qs[k] = (rad[4 * k] + rad[4 * k + 1]) + (rad[4 * k + 2] + rad[4 * k + 3]);
+            qsc[k] = (radc[4 * k] + radc[4 * k + 1]) + (radc[4 * k + 2] + radc[4 * k + 3]);
+        }
+        if constexpr (DN) seen = seen || cloudy;
+        if constexpr (G == 1) { red_put(slot, 0, qs[0]); red_put(slot, 1, qsc[0]); }
+        else { red_put(slot, 0, qs[0] + qs[1]); red_put(slot, 1, qsc[0] + qsc[1]); }
+    };
+    auto sweep = [&](auto bin_tag, auto dn_tag) __attribute__((always_inline)) {
+        constexpr bool DN = decltype(dn_tag)::value;
+        constexpr int dir = DN ? -1 : 1;
+        const int first = DN ? ltop : 1, count = ltop;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (c == NC - 1) fill_t(bin_tag, first, DN ? 0 : 1, cur);
+#pragma unroll
+            for (int k = 0; k < G; k++) { cc[k][c] = ld_c(sC, first + c * dir, k); ct[k][c] = ld_c(sCt, first + c * dir, k); }
+        }
+        int n = 0;
+        for (; n + NC <= count; n += NC) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) level(bin_tag, dn_tag, first + (n + c) * dir, c);
+            round_end(dn_tag, first + n * dir, NC);
+        }
+        const int rem = count - n;
+#pragma unroll
+        for (int c = 0; c < NC - 1; c++) {
+            if (c < rem) level(bin_tag, dn_tag, first + (n + c) * dir, c);
+        }
+        if (rem > 0) round_end(dn_tag, first + n * dir, rem);
+    };
+    using std::true_type;
+    using std::false_type;
+
+    // ------------------------------------------------------------------ downward: layers ltop .. 1
+    if (any_bin) sweep(true_type{}, true_type{}); else sweep(false_type{}, true_type{});
+    // ------------------------------------------------------------------ surface: rtrnmr :629-652
+    {
+        const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
+        const double pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + colc];
+        double fpl;
+        const double *row = frac_row(1, any_bin ? bload_u32(sFw, off4) : 0u, fpl);
+        double usum = 0.0, usumc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            const double fr = any_bin ? row[j] + fpl * (row[16 + j] - row[j]) : row[j];
+            const double rad0 = fr * pb;
+            rad[j] = rad0 + reflect * rad[j];
+            radc[j] = rad0 + reflect * radc[j];
+            usum = usum + rad[j];
+            usumc = usumc + radc[j];
+            cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0;
+        }
+        red_put(0, 0, usum);
+        red_put(0, 1, usumc);
+        round_end(false_type{}, 0, 1);              // level 0
+    }
+    seen = colcloud;
+    // ------------------------------------------------------------------ upward: layers 1 .. ltop
+    if (any_bin) sweep(true_type{}, false_type{}); else sweep(false_type{}, false_type{});
+    if (incol) {                    // upward radiances at level ltop for k_sweepc<., 2>
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            double2 *h = hand + (size_t)k * ncb * 2;
+            h[hstream] = make_double2(rad[4 * k], rad[4 * k + 1]);        h[hstream + 1] = make_double2(rad[4 * k + 2], rad[4 * k + 3]);
+            h[2 * hstream] = make_double2(radc[4 * k], radc[4 * k + 1]);  h[2 * hstream + 1] = make_double2(radc[4 * k + 2], radc[4 * k + 3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_n1 : PROTOTYPE of the mapping BASELINE.json's north_star names, for cloud-free calls (icld = 0), kept to put a number beside the
 //        production mapping ("north-star mapping"): ONE COLUMN PER WAVEFRONT, G-POINTS ACROSS LANES (three passes over the
 //        152 padded g-slots), Planck / fraction tables in LDS, the transmittance either from the table in LDS or (EXPF) from
@@ -3108,7 +3407,7 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
 struct FluxGroups { int n; int nb[NGROUP_MAX]; unsigned long long bands[NGROUP_MAX]; };      // k_sweepc's groups: band lists as nibbles (band - 1)
 
 __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut out, int ncol, int col0, int nct,
-                                              int idrv, int clear_from_total, FluxGroups fg)
+                                              int idrv, int clear_from_total, int zone_groups, FluxGroups fg)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
@@ -3130,7 +3429,10 @@ __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut 
             if (clear_from_total) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
             if (idrv == 1) sq = W.gdp[go];
         }
-        if (!dn_g || !up_g) {
+        if (zone_groups) {                          // (k_sweepz: the cloud zone's partials are per group as well)
+            if (!dn_g) sd = W.gdn[go];
+            if (!up_g) su = W.gup[go];
+        } else if (!dn_g || !up_g) {
             for (int k = 0; k < fg.nb[g]; k++) {
                 const int b = (int)((fg.bands[g] >> (4 * k)) & 15ull);
                 const size_t po = ((size_t)b * (nlay + 1) + lev) * ncb + col;
