@@ -3154,9 +3154,11 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
                     cr = cr + mr;
                     lr = lr - mr;
                     rad[j] = cloudy ? rad_c : rad_s;
-                    cldrad[j] = cloudy ? cr : cldrad[j];
-                    clrrad[j] = cloudy ? lr : clrrad[j];
-                    radmr[j] = cloudy ? mr : radmr[j];
+                    // (the cloudy / clear parts and the carried correction of a lane that is clear at this level need not be kept: the
+                    // next cloudy level of that column is the first of a block, istcld = 1, and sets them anew)
+                    cldrad[j] = cr;
+                    clrrad[j] = lr;
+                    radmr[j] = mr;
                     radc[j] = (cloudy || seen) ? updc : rad_s;
                 }
             }

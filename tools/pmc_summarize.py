@@ -35,6 +35,12 @@ def short_name(k):
     m = re.match(r"k_sweepc<(\d+), (\d+), (\w+)>", k)      # (quads per thread, phase); the d(flux)/dT instantiation shares the bench's kernel name
     if m:
         return "k_sweepc<%s,%s>" % (m.group(1), m.group(2))
+    m = re.match(r"k_sweepz<(\d+)>", k)
+    if m:
+        return "k_sweepz<%s>" % m.group(1)
+    m = re.match(r"k_sweepc<(\d+), (\d+), (\w+), (\d+)>", k)      # (with the waves-per-band parameter)
+    if m:
+        return "k_sweepc<%s,%s>" % (m.group(1), m.group(2))
     m = re.match(r"k_n1<\w+>", k)
     if m:
         return "k_n1"
