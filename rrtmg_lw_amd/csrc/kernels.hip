@@ -2967,10 +2967,13 @@ __host__ __device__ constexpr int sweepz_nsb(int NQ, int nb)
 
 struct SweepzLev { double tl, tz, cf; unsigned w, flag; };
 
-template <int NQ>
+// MODE as k_sweep's: 1 rtrn (random overlap), 2 rtrnmr, 3 rtrnmc with per-g-point arrays, 4 rtrnmc with the generator's sub-column mask
+template <int NQ, int MODE>
 __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sweepz(DevTables T, Workspace W, SweepArgs a)
 {
+    static_assert(MODE >= 1 && MODE <= 4, "modes of the cloud-zone sweep");
     constexpr int G = sweepz_g(NQ), NT = sweepz_nt(NQ), NG = 4 * G, NC = RRLW_SWEEPC_CODES, NVAL = 2;
+    constexpr int NS2 = MODE == 2 ? NG : 1;          // rtrnmr's extra state
     extern __shared__ __align__(16) unsigned char smem[];
     const int tx = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y), sub = __builtin_amdgcn_readfirstlane(threadIdx.z);
     const int bi = ty / NT, part = ty % NT;
@@ -3015,6 +3018,9 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
     double2 *hand = reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2;
     const size_t hstream = (size_t)NQUAD * ncb * 2;
     const bool colcloud = (bload_u32(sFlag, off4) & 8u) != 0;
+    // MODE 4: the mask bits of this thread's g-points (bits of padding g-points cleared): first g-point, its words, valid count
+    const int ig0 = band_g0(B) + g0, mw0 = ig0 >> 5, mw1 = mw0 < 4 ? mw0 + 1 : 4;
+    const int nvalid = max(0, min(NG, band_ng(B) - g0));
 
     auto clampl = [&](int lev) { return min(max(lev, 1), nlay); };
     // the level's own inputs, one level ahead; zoff: 0 = interface below the layer (downward), 1 = above (upward)
@@ -3069,9 +3075,9 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
     };
 
     // state: total-sky radiance, clear-sky radiance, rtrnmr's cloudy / clear parts and carried correction, per g-point
-    double rad[NG], radc[NG], cldrad[NG], clrrad[NG], radmr[NG];
+    double rad[NG], radc[NG], cldrad[NS2], clrrad[NS2], radmr[NS2];
 #pragma unroll
-    for (int j = 0; j < NG; j++) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
+    for (int j = 0; j < NS2; j++) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
     {                               // downward radiances at level ltop from k_sweepc<., 1>; clear = total up there
 #pragma unroll
         for (int k = 0; k < G; k++) {
@@ -3091,8 +3097,32 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
     auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) __attribute__((always_inline)) {
         constexpr bool BIN = decltype(bin_tag)::value, DN = decltype(dn_tag)::value;
         constexpr int dir = DN ? -1 : 1;
-        const double2 *ov = W.ovl + ((size_t)((DN ? 0 : nlay + 1) + clampl(lev)) * 3) * ncb;
-        const double2 f0 = bload_f64x2(ov, off16), f1 = bload_f64x2(ov + ncb, off16), f2 = bload_f64x2(ov + 2 * ncb, off16);
+        double2 f0 = make_double2(0., 0.), f1 = f0, f2 = f0;
+        double efcl = 0.0;
+        unsigned mlo = 0u, mhi = 0u;
+        float4 cf4[G], ef4[G];
+        if constexpr (MODE == 2) {
+            const double2 *ov = W.ovl + ((size_t)((DN ? 0 : nlay + 1) + clampl(lev)) * 3) * ncb;
+            f0 = bload_f64x2(ov, off16); f1 = bload_f64x2(ov + ncb, off16); f2 = bload_f64x2(ov + 2 * ncb, off16);
+        } else {
+            if constexpr (MODE != 3) efcl = bload_f64(W.efcl + ((size_t)(B - 1) * nlay + (clampl(lev) - 1)) * ncb, off8);
+            if constexpr (MODE == 3) {              // cloud fraction (0 / 1) and effective emissivity per g-point: 8 floats per quad
+#pragma unroll
+                for (int k = 0; k < G; k++) {
+                    const float *pc = W.cfef + ((size_t)(quad + k) * nlay + (clampl(lev) - 1)) * ncb * 8;
+                    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(pc), (int)((unsigned)colc * 32u), 0, 0);
+                    const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(pc), (int)((unsigned)colc * 32u + 16u), 0, 0);
+                    __builtin_memcpy(&cf4[k], &c, 16);
+                    __builtin_memcpy(&ef4[k], &e, 16);
+                }
+            }
+            if constexpr (MODE == 4) {              // the two mask words that can hold this thread's g-points
+                const unsigned moff = (unsigned)(W.mask_col0 + gc) * 4u;
+                const unsigned *mrow = W.mask + (size_t)(clampl(lev) - 1) * W.mask_stride;
+                mlo = bload_u32(mrow + (size_t)mw0 * nlay * W.mask_stride, moff);
+                mhi = bload_u32(mrow + (size_t)mw1 * nlay * W.mask_stride, moff);
+            }
+        }
         double fpl;
         const double *row = frac_row(lev, cur.w, fpl);
         const double blay = planck_at(tp0, tp0, cur.tl);
@@ -3101,6 +3131,8 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
         const bool first = (cur.flag & (DN ? 2u : 4u)) != 0u;
         const double cf = cur.cf;
         const bool anycld = __builtin_amdgcn_ballot_w64(cloudy) != 0ull;       // (wave-uniform)
+        unsigned gbits = 0u;
+        if constexpr (MODE == 4) gbits = (unsigned)((((unsigned long long)mlo | ((unsigned long long)mhi << 32)) >> (ig0 & 31)) & ((1ull << nvalid) - 1ull));
         fill_t(bin_tag, lev + dir, DN ? 0 : 1, cur);
         double qs[G], qsc[G];
 #pragma unroll
@@ -3140,25 +3172,34 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
                     decode(ckt.v[jj], et[jj], atot, tftot);
                     const double bbtot = fr * (blay + tftot * dpl);
                     const double gassrc = bb * atr;
-                    double cr = cldrad[j], lr = clrrad[j], mr = radmr[j];
-                    if (first) { cr = cf * rad[j]; lr = rad[j] - cr; mr = 0.0; }
-                    const double ttot = 1. - atot;
-                    const double cldsrc = bbtot * atot;
-                    cr = cr * ttot + cf * cldsrc;
-                    lr = lr * (1. - atr) + (1. - cf) * gassrc;
-                    const double rad_c = cr + lr;
-                    const double radmod = mr * (f0.x * (1. - atr) + f0.y * ttot) - f1.x * gassrc + f1.y * cldsrc;
-                    const double oldcld = cr - radmod;
-                    const double oldclr = lr + radmod;
-                    mr = -radmod + f2.x * oldclr - f2.y * oldcld;
-                    cr = cr + mr;
-                    lr = lr - mr;
+                    double rad_c;
+                    if constexpr (MODE == 2) {
+                        double cr = cldrad[j], lr = clrrad[j], mr = radmr[j];
+                        if (first) { cr = cf * rad[j]; lr = rad[j] - cr; mr = 0.0; }
+                        const double ttot = 1. - atot;
+                        const double cldsrc = bbtot * atot;
+                        cr = cr * ttot + cf * cldsrc;
+                        lr = lr * (1. - atr) + (1. - cf) * gassrc;
+                        rad_c = cr + lr;
+                        const double radmod = mr * (f0.x * (1. - atr) + f0.y * ttot) - f1.x * gassrc + f1.y * cldsrc;
+                        const double oldcld = cr - radmod;
+                        const double oldclr = lr + radmod;
+                        mr = -radmod + f2.x * oldclr - f2.y * oldcld;
+                        // (the cloudy / clear parts and the carried correction of a lane that is clear at this level need not be kept:
+                        // the next cloudy level of that column is the first of a block, istcld = 1, and sets them anew)
+                        cldrad[j] = cr + mr;
+                        clrrad[j] = lr - mr;
+                        radmr[j] = mr;
+                    } else {                        // rtrn :372-435 / rtrnmc: the same explicit fused form as k_sweep (the array and the mask
+                        double cfj = cf, efj = efcl;    // flavour of rtrnmc must round identically)
+                        if constexpr (MODE == 4) { const bool on = (gbits >> j) & 1u; cfj = on ? 1.0 : 0.0; efj = on ? efcl : 0.0; }
+                        if constexpr (MODE == 3) {
+                            const float *c4 = reinterpret_cast<const float *>(&cf4[k]), *e4 = reinterpret_cast<const float *>(&ef4[k]);
+                            cfj = c4[jj]; efj = e4[jj];
+                        }
+                        rad_c = fma(cfj, fma(bbtot, atot, -gassrc), fma(-rad[j], fma(efj, 1. - atr, atr), rad[j]) + gassrc);
+                    }
                     rad[j] = cloudy ? rad_c : rad_s;
-                    // (the cloudy / clear parts and the carried correction of a lane that is clear at this level need not be kept: the
-                    // next cloudy level of that column is the first of a block, istcld = 1, and sets them anew)
-                    cldrad[j] = cr;
-                    clrrad[j] = lr;
-                    radmr[j] = mr;
                     radc[j] = (cloudy || seen) ? updc : rad_s;
                 }
             }
@@ -3212,7 +3253,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
             radc[j] = rad0 + reflect * radc[j];
             usum = usum + rad[j];
             usumc = usumc + radc[j];
-            cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0;
+            if constexpr (MODE == 2) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
         }
         red_put(0, 0, usum);
         red_put(0, 1, usumc);
