@@ -206,21 +206,37 @@ int ensure_sweep_attrs()
 {
     if (G.sweep_attrs) return 0;
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     if (int rc = sweepc_attr_one<1>()) return rc;
     if (int rc = sweepc_attr_one<2>()) return rc;
     if (int rc = sweepc_attr_one<3>()) return rc;
@@ -450,7 +466,9 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     FluxGroups fg{};
     int gq[NGROUP_MAX];
     for (int nq = 4; nq >= 1; nq--) {
-        const int cap = sweepc_group_cap(nq);
+        // (a group is one workgroup in k_sweepc and in k_sweepz: what fits the wave slots of both)
+        const int zcap = sweepz_group_cap(nq, idrv == 1);
+        const int cap = std::max(1, std::min(sweepc_group_cap(nq), mode != 0 && G.sweepz ? zcap : 99));
         for (int k0 = 0; k0 < nbs[nq]; k0 += cap) {
             if (fg.n >= NGROUP_MAX) return fail(RRTMG_LW_HIP_EARG, "internal: more than %d sweep groups", NGROUP_MAX);
             const int nbg = std::min(cap, nbs[nq] - k0);
@@ -479,8 +497,8 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #define SWEEP(M, Q) do { if (idrv == 1) SWEEP_I(M, Q, true); else SWEEP_I(M, Q, false); } while (0)
 #define SWEEP_MODE(Q) do { if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q); } while (0)
 #define SWEEP_Q() do { if (nq == 4) SWEEP_MODE(4); else if (nq == 3) SWEEP_MODE(3); else if (nq == 2) SWEEP_MODE(2); else SWEEP_MODE(1); } while (0)
-    // the cloud zone's partials arrive per group (k_sweepz): rtrn, rtrnmr and rtrnmc (both flavours), without d/dT
-    const bool zone_groups = G.sweepz && idrv != 1 && mode >= 1 && mode <= 3;
+    // the cloud zone's partials arrive per group (k_sweepz)
+    const bool zone_groups = G.sweepz && mode >= 1 && mode <= 3;
     for (int phase = 0; phase < 3; phase++) {
         if (phase == 1 && zone_groups) {            // cloud zone, rtrnmr without d/dT: k_sweepz, one launch per group
             for (int g = 0; g < fg.n; g++) {
@@ -489,18 +507,19 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
                 sa.nbands = fg.nb[g];
                 sa.group = g;
                 const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;
-#define SWEEPZ(Q)                                                                                                    \
+#define SWEEPZ_I(Q, M, I)                                                                                            \
     do {                                                                                                             \
         constexpr int nt = sweepz_nt(Q);                                                                             \
-        const int nsb = sweepz_nsb(Q, sa.nbands);                                                                    \
+        const int nsb = sweepz_nsb(Q, sa.nbands, I);                                                                 \
         sa.ncb = (nb + 64 * nsb - 1) / (64 * nsb);                                                                   \
         const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands * nt, nsb);                                         \
-        if (mode == 1) LAUNCH_LDS("k_sweepz<" #Q ",1>", (k_sweepz<Q, 1>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt), s, G.D, Wk, sa);      \
-        else if (mode == 3 && mc) LAUNCH_LDS("k_sweepz<" #Q ",3>", (k_sweepz<Q, 3>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt), s, G.D, Wk, sa); \
-        else if (mode == 3) LAUNCH_LDS("k_sweepz<" #Q ",4>", (k_sweepz<Q, 4>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt), s, G.D, Wk, sa); \
-        else LAUNCH_LDS("k_sweepz<" #Q ",2>", (k_sweepz<Q, 2>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt), s, G.D, Wk, sa);               \
+        LAUNCH_LDS("k_sweepz<" #Q "," #M ">", (k_sweepz<Q, M, I>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt, I), s, G.D, Wk, sa); \
     } while (0)
+#define SWEEPZ_M(Q, M) do { if (idrv == 1) SWEEPZ_I(Q, M, true); else SWEEPZ_I(Q, M, false); } while (0)
+#define SWEEPZ(Q) do { if (mode == 1) SWEEPZ_M(Q, 1); else if (mode == 3 && mc) SWEEPZ_M(Q, 3); else if (mode == 3) SWEEPZ_M(Q, 4); else SWEEPZ_M(Q, 2); } while (0)
                 if (nq == 4) SWEEPZ(4); else if (nq == 3) SWEEPZ(3); else if (nq == 2) SWEEPZ(2); else SWEEPZ(1);
+#undef SWEEPZ_I
+#undef SWEEPZ_M
 #undef SWEEPZ
             }
             continue;

@@ -2951,29 +2951,47 @@ __host__ __device__ constexpr int sweepz_nt(int NQ) { return NQ / sweepz_g(NQ); 
 #ifndef RRLW_SWEEPZ_WAVES_G1
 #define RRLW_SWEEPZ_WAVES_G1 3
 #endif
-__host__ __device__ constexpr int sweepz_waves(int NQ) { return sweepz_g(NQ) == 2 ? RRLW_SWEEPZ_WAVES_G2 : RRLW_SWEEPZ_WAVES_G1; }
-__host__ __device__ constexpr int sweepz_lds_bytes(int nb, int nsb, int NT)
+#ifndef RRLW_SWEEPZ_WAVES_IDRV
+#define RRLW_SWEEPZ_WAVES_IDRV 2          // with d(flux)/dT: 16 more state registers per thread
+#endif
+__host__ __device__ constexpr int sweepz_waves(int NQ, bool IDRV = false)
 {
-    return SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES + 2 * 2 * nb * NT * RRLW_SWEEPC_CODES * nsb * 64 * 8;
+    return IDRV ? RRLW_SWEEPZ_WAVES_IDRV : (sweepz_g(NQ) == 2 ? RRLW_SWEEPZ_WAVES_G2 : RRLW_SWEEPZ_WAVES_G1);
 }
-__host__ __device__ constexpr int sweepz_nsb(int NQ, int nb)
+__host__ __device__ constexpr int sweepz_lds_bytes(int nb, int nsb, int NT, bool IDRV = false)
+{
+    return SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES + 2 * (IDRV ? 4 : 2) * nb * NT * RRLW_SWEEPC_CODES * nsb * 64 * 8;
+}
+__host__ __device__ constexpr int sweepz_nsb(int NQ, int nb, bool IDRV = false)
 {
     const int nt = sweepz_nt(NQ);
-    int nsb = 4 * sweepz_waves(NQ) / (nb * nt);
+    int nsb = 4 * sweepz_waves(NQ, IDRV) / (nb * nt);
     if (nsb < 1) nsb = 1;
-    while (nsb > 1 && sweepz_lds_bytes(nb, nsb, nt) > SWEEPC_LDS_MAX) nsb--;
+    while (nsb > 1 && sweepz_lds_bytes(nb, nsb, nt, IDRV) > SWEEPC_LDS_MAX) nsb--;
     return nsb;
+}
+
+// bands per group: wave slots and LDS of one workgroup
+__host__ __device__ constexpr int sweepz_group_cap(int NQ, bool IDRV)
+{
+    const int nt = sweepz_nt(NQ);
+    int cap = 4 * sweepz_waves(NQ, IDRV) / nt;
+    if (cap < 1) cap = 1;
+    while (cap > 1 && sweepz_lds_bytes(cap, 1, nt, IDRV) > SWEEPC_LDS_MAX) cap--;
+    return cap;
 }
 
 struct SweepzLev { double tl, tz, cf; unsigned w, flag; };
 
 // MODE as k_sweep's: 1 rtrn (random overlap), 2 rtrnmr, 3 rtrnmc with per-g-point arrays, 4 rtrnmc with the generator's sub-column mask
-template <int NQ, int MODE>
-__global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sweepz(DevTables T, Workspace W, SweepArgs a)
+// IDRV: d(upward flux)/dT carried along (idrv = 1), src/rrtmg_lw_rtrnmr.f90:655-703 and its siblings
+template <int NQ, int MODE, bool IDRV = false>
+__global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV)) void k_sweepz(DevTables T, Workspace W, SweepArgs a)
 {
     static_assert(MODE >= 1 && MODE <= 4, "modes of the cloud-zone sweep");
-    constexpr int G = sweepz_g(NQ), NT = sweepz_nt(NQ), NG = 4 * G, NC = RRLW_SWEEPC_CODES, NVAL = 2;
+    constexpr int G = sweepz_g(NQ), NT = sweepz_nt(NQ), NG = 4 * G, NC = RRLW_SWEEPC_CODES, NVAL = IDRV ? 4 : 2;
     constexpr int NS2 = MODE == 2 ? NG : 1;          // rtrnmr's extra state
+    constexpr int NSD = IDRV ? NG : 1;               // d/dT state
     extern __shared__ __align__(16) unsigned char smem[];
     const int tx = threadIdx.x, ty = __builtin_amdgcn_readfirstlane(threadIdx.y), sub = __builtin_amdgcn_readfirstlane(threadIdx.z);
     const int bi = ty / NT, part = ty % NT;
@@ -3012,6 +3030,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
     const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;
     Part2 *__restrict__ gdn = W.gdn + gslab;
     Part2 *__restrict__ gup = W.gup + gslab;
+    Part2 *__restrict__ gdp = W.gdp + gslab;
     const unsigned so16 = (unsigned)col * 16u;
     const int laytrop = W.laytrop[colc];
     const double *tp0 = s_pl[0], *tp1 = s_pl[1];
@@ -3053,29 +3072,34 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
     auto round_end = [&](auto dn_tag, int lev0, int nvalid) __attribute__((always_inline)) {
         constexpr bool DN = decltype(dn_tag)::value;
         __syncthreads();
+        constexpr int NV = DN ? 2 : NVAL;
         for (int c = ty; c < nvalid; c += ny) {       // (wave-uniform)
             const int lvl = DN ? lev0 - c - 1 : lev0 + c;
-            double sv[NVAL];
+            double sv[NV];
 #pragma unroll
-            for (int val = 0; val < NVAL; val++) {
+            for (int val = 0; val < NV; val++) {
                 const double *r = red + (bufoff + val * vstride + (unsigned)(c * ncw) + rlane);
                 double sum = 0.0;
                 for (int q = 0; q < nb; q++) {
                     double pq = r[(unsigned)(q * NT * NC * ncw)];
 #pragma unroll
                     for (int t = 1; t < NT; t++) pq = pq + r[(unsigned)((q * NT + t) * NC * ncw)];
-                    const double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
+                    double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
+                    if (val >= 2) v = v * T.fluxfac;
                     sum = q == 0 ? v : sum + v;
                 }
                 sv[val] = sum;
             }
-            if (incol) bstore_f64x2((DN ? gdn : gup) + (size_t)lvl * ncb, so16, sv[0], sv[1]);
+            if (incol) {
+                bstore_f64x2((DN ? gdn : gup) + (size_t)lvl * ncb, so16, sv[0], sv[1]);
+                if constexpr (IDRV && !DN) bstore_f64x2(gdp + (size_t)lvl * ncb, so16, sv[2], sv[3]);
+            }
         }
         bufoff = bufoff ? 0u : NVAL * vstride;
     };
 
     // state: total-sky radiance, clear-sky radiance, rtrnmr's cloudy / clear parts and carried correction, per g-point
-    double rad[NG], radc[NG], cldrad[NS2], clrrad[NS2], radmr[NS2];
+    double rad[NG], radc[NG], cldrad[NS2], clrrad[NS2], radmr[NS2], drad[NSD], dradc[NSD];
 #pragma unroll
     for (int j = 0; j < NS2; j++) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
     {                               // downward radiances at level ltop from k_sweepc<., 1>; clear = total up there
@@ -3166,6 +3190,10 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
                 if (!anycld) {
                     rad[j] = rad_s;
                     radc[j] = seen ? updc : rad_s;
+                    if constexpr (IDRV && !DN) {
+                        drad[j] = drad[j] * (1.0 - atr);
+                        dradc[j] = seen ? dradc[j] * (1.0 - atr) : drad[j];
+                    }
                 } else {
                     // cloudy level: rtrnmr :591-615 / :680-703, formed for every lane of the wave and selected
                     double atot, tftot;
@@ -3201,6 +3229,16 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
                     }
                     rad[j] = cloudy ? rad_c : rad_s;
                     radc[j] = (cloudy || seen) ? updc : rad_s;
+                    if constexpr (IDRV && !DN) {        // d/dT: rtrnmr :697-702 (cloudy), :712-714 (clear)
+                        double cfd = cf;
+                        if constexpr (MODE == 4) cfd = ((gbits >> j) & 1u) ? 1.0 : 0.0;
+                        if constexpr (MODE == 3) cfd = reinterpret_cast<const float *>(&cf4[k])[jj];
+                        const double d_s = drad[j] * (1.0 - atr);
+                        const double d_c = drad[j] * cfd * (1.0 - atot) + drad[j] * (1.0 - cfd) * (1.0 - atr);
+                        const double dc_s = seen ? dradc[j] * (1.0 - atr) : d_s;
+                        drad[j] = cloudy ? d_c : d_s;
+                        dradc[j] = cloudy ? dradc[j] * (1.0 - atr) : dc_s;
+                    }
                 }
             }
             qs[k] = (rad[4 * k] + rad[4 * k + 1]) + (rad[4 * k + 2] + rad[4 * k + 3]);
@@ -3209,6 +3247,16 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
         if constexpr (DN) seen = seen || cloudy;
         if constexpr (G == 1) { red_put(slot, 0, qs[0]); red_put(slot, 1, qsc[0]); }
         else { red_put(slot, 0, qs[0] + qs[1]); red_put(slot, 1, qsc[0] + qsc[1]); }
+        if constexpr (IDRV && !DN) {
+            double ds = 0.0, dsc = 0.0;
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                ds = ds + ((drad[4 * k] + drad[4 * k + 1]) + (drad[4 * k + 2] + drad[4 * k + 3]));
+                dsc = dsc + ((dradc[4 * k] + dradc[4 * k + 1]) + (dradc[4 * k + 2] + dradc[4 * k + 3]));
+            }
+            red_put(slot, 2, ds);
+            red_put(slot, 3, dsc);
+        }
     };
     auto sweep = [&](auto bin_tag, auto dn_tag) __attribute__((always_inline)) {
         constexpr bool DN = decltype(dn_tag)::value;
@@ -3242,9 +3290,10 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
     {
         const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
         const double pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + colc];
+        const double dpb = IDRV ? W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + colc] : 0.0;
         double fpl;
         const double *row = frac_row(1, any_bin ? bload_u32(sFw, off4) : 0u, fpl);
-        double usum = 0.0, usumc = 0.0;
+        double usum = 0.0, usumc = 0.0, dusum = 0.0;
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             const double fr = any_bin ? row[j] + fpl * (row[16 + j] - row[j]) : row[j];
@@ -3254,9 +3303,11 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
             usum = usum + rad[j];
             usumc = usumc + radc[j];
             if constexpr (MODE == 2) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
+            if constexpr (IDRV) { drad[j] = fr * dpb; dradc[j] = drad[j]; dusum = dusum + drad[j]; }
         }
         red_put(0, 0, usum);
         red_put(0, 1, usumc);
+        if constexpr (IDRV) { red_put(0, 2, dusum); red_put(0, 3, dusum); }
         round_end(false_type{}, 0, 1);              // level 0
     }
     seen = colcloud;
@@ -3268,6 +3319,10 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ), sweepz_waves(NQ)) void k_sw
             double2 *h = hand + (size_t)k * ncb * 2;
             h[hstream] = make_double2(rad[4 * k], rad[4 * k + 1]);        h[hstream + 1] = make_double2(rad[4 * k + 2], rad[4 * k + 3]);
             h[2 * hstream] = make_double2(radc[4 * k], radc[4 * k + 1]);  h[2 * hstream + 1] = make_double2(radc[4 * k + 2], radc[4 * k + 3]);
+            if constexpr (IDRV) {
+                h[3 * hstream] = make_double2(drad[4 * k], drad[4 * k + 1]);    h[3 * hstream + 1] = make_double2(drad[4 * k + 2], drad[4 * k + 3]);
+                h[4 * hstream] = make_double2(dradc[4 * k], dradc[4 * k + 1]);  h[4 * hstream + 1] = make_double2(dradc[4 * k + 2], dradc[4 * k + 3]);
+            }
         }
     }
 }
@@ -3474,7 +3529,7 @@ __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut 
         }
         if (zone_groups) {                          // (k_sweepz: the cloud zone's partials are per group as well)
             if (!dn_g) sd = W.gdn[go];
-            if (!up_g) su = W.gup[go];
+            if (!up_g) { su = W.gup[go]; if (idrv == 1) sq = W.gdp[go]; }
         } else if (!dn_g || !up_g) {
             for (int k = 0; k < fg.nb[g]; k++) {
                 const int b = (int)((fg.bands[g] >> (4 * k)) & 15ull);
