@@ -55,7 +55,6 @@ struct State {
                                  // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -1 %)
     bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device
     bool n1 = false;             // RRTMG_LW_N1=1: cloud-free calls take the north-star-mapping prototype k_n1 (measurement only)
-    bool sweepz = true;          // RRTMG_LW_SWEEPZ=0: the cloud zone of rtrnmr calls goes through k_sweep<2, .> instead of k_sweepz (measurement only)
     bool ws_two_scr = false;     // the workspace holds the second scratch set that split_sweep needs
     // host-entry staging
     void *stage_base = nullptr;
@@ -176,14 +175,7 @@ hipEvent_t get_event()
         }                                                                                        \
     } while (0)
 
-// k_sweep stages the transmittance table in LDS: more than the 64 KB a kernel may use without asking
-template <int M, int Q>
-int sweep_attr_one()
-{
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M, false)));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweep<M, Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_bytes(Q, M, true)));
-    return 0;
-}
+// the sweeps stage the transmittance table in LDS: more than the 64 KB a kernel may use without asking
 template <int Q>
 int sweepc_attr_one()
 {
@@ -193,14 +185,6 @@ int sweepc_attr_one()
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, false, sweepc_nt(Q, 2, false)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true, sweepc_nt(Q, 2, true)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     return 0;
-}
-template <int M>
-int sweep_attr_mode()
-{
-    if (int rc = sweep_attr_one<M, 1>()) return rc;
-    if (int rc = sweep_attr_one<M, 2>()) return rc;
-    if (int rc = sweep_attr_one<M, 3>()) return rc;
-    return sweep_attr_one<M, 4>();
 }
 int ensure_sweep_attrs()
 {
@@ -241,10 +225,6 @@ int ensure_sweep_attrs()
     if (int rc = sweepc_attr_one<2>()) return rc;
     if (int rc = sweepc_attr_one<3>()) return rc;
     if (int rc = sweepc_attr_one<4>()) return rc;
-    if (int rc = sweep_attr_mode<1>()) return rc;
-    if (int rc = sweep_attr_mode<2>()) return rc;
-    if (int rc = sweep_attr_mode<3>()) return rc;
-    if (int rc = sweep_attr_mode<4>()) return rc;
     G.sweep_attrs = true;
     return 0;
 }
@@ -262,14 +242,11 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     Workspace &W = G.W;
     W = Workspace{};
     std::vector<Item> items = {
-        {(void **)&W.pdn, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.pup, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.gdn1, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(double)},
         {(void **)&W.gup1, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(double)},
         {(void **)&W.gup, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.gdp, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
         {(void **)&W.gdn, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.dpart, (size_t)NBND * (L + 1) * n * sizeof(Part2)},
     };
     const bool two_scr = G.split_sweep;
     G.scrset[1] = State::ScrSet{};
@@ -453,7 +430,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     sa.tlay = GCM ? g.tlay : c.tavel;
     sa.tlev = GCM ? g.tlev : c.tz;
     // Per class of bands with the same number of quads: a cloud-free call (mode 0) is one k_sweepc<., 0> launch; the cloudy modes run
-    // k_sweepc<., 1> (layers above the batch's highest cloud, downward), k_sweep<mode> (layers 1 .. ltop down, surface, up) and
+    // k_sweepc<., 1> (layers above the batch's highest cloud, downward), k_sweepz<., mode> (layers 1 .. ltop down, surface, up) and
     // k_sweepc<., 2> (layers above, upward).  The classes are independent of each other: with `fan` each class has its own stream;
     // on one stream the launches go phase by phase (all downward ones, then the cloud zone, then the upward ones) so that consecutive
     // launches never wait for each other's last workgroups.
@@ -463,12 +440,12 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         for (int B = 1; B <= NBND; B++)
             if (band_nquad(B) == nq && B >= istart && B <= iend) lists[nq] |= (unsigned long long)(B - 1) << (4 * nbs[nq]++);
     // k_sweepc's groups: the bands of a class, at most sweepc_group_cap of them per workgroup
-    FluxGroups fg{};
+    struct { int n = 0; int nb[NGROUP_MAX]; unsigned long long bands[NGROUP_MAX]; } fg;
     int gq[NGROUP_MAX];
     for (int nq = 4; nq >= 1; nq--) {
         // (a group is one workgroup in k_sweepc and in k_sweepz: what fits the wave slots of both)
         const int zcap = sweepz_group_cap(nq, idrv == 1);
-        const int cap = std::max(1, std::min(sweepc_group_cap(nq), mode != 0 && G.sweepz ? zcap : 99));
+        const int cap = std::max(1, std::min(sweepc_group_cap(nq), mode != 0 ? zcap : 99));
         for (int k0 = 0; k0 < nbs[nq]; k0 += cap) {
             if (fg.n >= NGROUP_MAX) return fail(RRTMG_LW_HIP_EARG, "internal: more than %d sweep groups", NGROUP_MAX);
             const int nbg = std::min(cap, nbs[nq] - k0);
@@ -487,20 +464,9 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     } while (0)
 #define SWEEPC(Q, PH) do { if (idrv == 1 && PH != 1) SWEEPC_I(Q, PH, true); else SWEEPC_I(Q, PH, false); } while (0)
 #define SWEEPC_Q(PH) do { if (nq == 4) SWEEPC(4, PH); else if (nq == 3) SWEEPC(3, PH); else if (nq == 2) SWEEPC(2, PH); else SWEEPC(1, PH); } while (0)
-#define SWEEP_I(M, Q, I)                                                                                             \
-    do {                                                                                                             \
-        const int ns = sweep_ns(Q, M, I);                                                                            \
-        sa.ncb = (nb + 64 * ns - 1) / (64 * ns);                                                                     \
-        const dim3 sgrid((unsigned)(((sa.ncb + 7) / 8) * 8 * sa.nbands)), sblock(64, sweep_t(Q, M, I), ns);          \
-        LAUNCH_LDS("k_sweep<" #M "," #Q ">", (k_sweep<M, Q, I>), sgrid, sblock, sweep_lds_bytes(Q, M, I), s, G.D, Wk, sa); \
-    } while (0)
-#define SWEEP(M, Q) do { if (idrv == 1) SWEEP_I(M, Q, true); else SWEEP_I(M, Q, false); } while (0)
-#define SWEEP_MODE(Q) do { if (mode == 1) SWEEP(1, Q); else if (mode == 3 && mc) SWEEP(3, Q); else if (mode == 3) SWEEP(4, Q); else SWEEP(2, Q); } while (0)
-#define SWEEP_Q() do { if (nq == 4) SWEEP_MODE(4); else if (nq == 3) SWEEP_MODE(3); else if (nq == 2) SWEEP_MODE(2); else SWEEP_MODE(1); } while (0)
-    // the cloud zone's partials arrive per group (k_sweepz)
-    const bool zone_groups = G.sweepz && mode >= 1 && mode <= 3;
     for (int phase = 0; phase < 3; phase++) {
-        if (phase == 1 && zone_groups) {            // cloud zone, rtrnmr without d/dT: k_sweepz, one launch per group
+        if (phase == 1) {                           // cloud zone: k_sweepz, one launch per group
+            if (mode == 0) continue;
             for (int g = 0; g < fg.n; g++) {
                 const int nq = gq[g];
                 sa.bands = fg.bands[g];
@@ -524,17 +490,6 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             }
             continue;
         }
-        if (phase == 1) {                           // cloud zone: one launch per class of bands
-            if (mode == 0) continue;
-            for (int nq = 4; nq >= 1; nq--) {
-                if (nbs[nq] == 0) continue;
-                sa.bands = lists[nq];
-                sa.nbands = nbs[nq];
-                const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;     // (shadows the function's stream for the launch macros)
-                SWEEP_Q();
-            }
-            continue;
-        }
         if (mode == 0 && phase == 2) continue;
         for (int g = 0; g < fg.n; g++) {            // above the clouds (or a cloud-free call): one launch per group
             const int nq = gq[g];
@@ -547,10 +502,6 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             else SWEEPC_Q(2);
         }
     }
-#undef SWEEP_Q
-#undef SWEEP_MODE
-#undef SWEEP
-#undef SWEEP_I
 #undef SWEEPC_Q
 #undef SWEEPC
 #undef SWEEPC_I
@@ -561,7 +512,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         }
     }
     const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
-    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, zone_groups ? 1 : 0, fg);
+    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
     LAUNCH("k_rates", k_rates, rgrid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -950,8 +901,6 @@ int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, do
     {
         const char *e = std::getenv("RRTMG_LW_N1");
         G.n1 = e && e[0] == '1';
-        const char *z = std::getenv("RRTMG_LW_SWEEPZ");
-        G.sweepz = !(z && z[0] == '0');
     }
     G.init = true;
     G.err.clear();

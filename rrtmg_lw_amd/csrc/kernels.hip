@@ -80,13 +80,11 @@ struct Workspace {
                         // total / clear (k_sweep -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
     unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
-    Part2 *pdn, *pup;   // [16 bands][nlay+1][ncolb]
     // k_sweepc's partials, summed over the bands of a GROUP (bands with the same number of quads, swept by one workgroup and added in
     // LDS): [NGROUP_MAX][nlay+1][ncolb].  gdn1 / gup1: 8 bytes where the clear-sky stream equals the total one (downward at and above the
     // batch's highest cloud, both directions of a cloud-free call); gup / gdp {total, clear}: upward above the clouds, d(flux)/dT
     double *gdn1, *gup1;
     Part2 *gup, *gdp, *gdn;     // gdn {total, clear}: downward inside the cloud zone (k_sweepz)
-    Part2 *dpart;       // [16 bands][nlay+1][ncolb]  (idrv = 1)
     int *err;           // [1] first physics error code
     // McICA (rtrnmc): per-g-point cloud terms, written by k_cloudmc
     double *odg;        // [NQUAD][nlay][ncolb][4]     secdiff(band) * taucmc(g)
@@ -1790,25 +1788,18 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sweep : the vertical recurrences.  One thread owns NGC consecutive g-points of one band for one column.
-//   (cloud-free calls, icld = 0, and the layers above the batch's highest cloud are k_sweepc's, below)
-//   MODE 1 rtrn   (random overlap)                                 src/rrtmg_lw_rtrn.f90:361-540
-//   MODE 2 rtrnmr (maximum-random overlap)                         src/rrtmg_lw_rtrnmr.f90:347-738
-//   MODE 3 rtrnmc (McICA: cloud terms per g-point, k_cloudmc)      src/rrtmg_lw_rtrnmc.f90:331-520
-//   MODE 4 rtrnmc with the cloud terms given per band + the generator's sub-column mask
-// Per cell it reads k_layer's 4-byte code (cell_code) and forms, in float64: transmittance and tfn factor (series, or the
-// transmittance table staged in LDS; rtrn :372-451), the layer's Planck functions for this band (setcoef :173-269, from
-// tlay / tlev and the band's totplnk row staged in LDS), the Planck fractions (taumol: constant per g-point, or interpolated
-// between two fracref rows staged in LDS with the layer's (js, fs) from k_layer) and from them the source terms bbd / bbu
-// (rtrn :447-449).  For rtrnmr the overlap factors of a cloudy level (rtrnmr :347-506) are formed on the fly from the cloud
-// fractions of the level and its two neighbours, in sweep order, exactly as the reference's two set-up loops form them.
-// Writes the band's flux contribution (sum over its g-points x 0.5 x delwave, rtrn :549-562) per level.
-// Lanes beyond the last column work on a copy of the last column (no divergence); only their stores are masked.
+// The vertical recurrences: k_sweepc (cloud-free calls and the layers above the batch's highest cloud) and k_sweepz (the cloud zone:
+// rtrn, rtrnmr, rtrnmc), below.  Per cell they read k_layer's 4-byte code (cell_code) and form, in float64: transmittance and tfn
+// factor (series, or the transmittance table staged in LDS; rtrn :372-451), the layer's Planck functions for the band (setcoef
+// :173-269, from tlay / tlev and the band's totplnk row staged in LDS), the Planck fractions (taumol: constant per g-point, or
+// interpolated between two fracref rows staged in LDS with the layer's (js, fs) from k_layer) and from them the source terms
+// (rtrn :447-449).  The flux contributions (sum over g-points x 0.5 x delwave, rtrn :549-562) are added over a group of bands in LDS
+// and written once per group and level.  Lanes beyond the last column work on a copy of the last column; only their stores are masked.
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
-    unsigned long long bands;  // the launch's bands (all with the same number of quads), one nibble (band - 1) each
-    int nbands, ncb;           // number of those bands, number of column blocks (workgroups per band)
-    int group;                 // k_sweepc: index of the group's partial slabs (W.gdn1 ..)
+    unsigned long long bands;  // the group's bands (all with the same number of quads), one nibble (band - 1) each
+    int nbands, ncb;           // number of those bands, number of column blocks (= workgroups)
+    int group;                 // index of the group's partial slabs (W.gdn1 ..)
     int ncol, col0, nct, idrv;
     int istart, iend;          // only bands in [istart, iend] are swept
     const double *emis;        // semiss (nct,16)
@@ -1817,76 +1808,14 @@ struct SweepArgs {
     const double *tlev;        // (nct,nlay+1)   interface temperatures (tlev | tz)
 };
 
-constexpr int SWEEP_LV = 4;       // levels per reduction round
-// prefetch distance in levels (= register slots of the rolling prefetch; divides SWEEP_LV).  Two levels everywhere except the rtrnmr
-// sweep, which fits three waves per SIMD (168 VGPRs) only with one slot: measured 61.2 ms per 1e6 cloudy columns (1 slot, 3 waves)
-// against 70.2 ms (2 slots, 2 waves) and 71.5 ms (1 slot, 2 waves).
-#ifndef RRLW_SWEEP_PF
-#define RRLW_SWEEP_PF 2
-#endif
-#ifndef RRLW_SWEEP_PF_RTRNMR
-#define RRLW_SWEEP_PF_RTRNMR 1
-#endif
-__host__ __device__ constexpr int sweep_pf(int MODE, bool IDRV) { return MODE == 2 && !IDRV ? RRLW_SWEEP_PF_RTRNMR : RRLW_SWEEP_PF; }
-#ifndef RRLW_SWEEP_WAVES_RTRN
-#define RRLW_SWEEP_WAVES_RTRN 4   // MODE 1 (121-123 VGPRs)
-#endif
-#ifndef RRLW_SWEEP_WAVES_RTRNMR
-#define RRLW_SWEEP_WAVES_RTRNMR 3 // MODE 2 (one prefetch slot: 168 VGPRs + 6-7 spilled dwords; two slots: 181-184, 49-56 spilled at 168)
-#endif
-#ifndef RRLW_SWEEP_WAVES_MCARR
-#define RRLW_SWEEP_WAVES_MCARR 2  // MODE 3
-#endif
-#ifndef RRLW_SWEEP_WAVES_MCMASK
-#define RRLW_SWEEP_WAVES_MCMASK 4 // MODE 4 (125-127 VGPRs; 130.3 vs 143.2 ms per 1e6 McICA columns at 3)
-#endif
-// quads of a band one thread carries through the sweep (G); a band of NQ quads then takes T = NQ / G threads per column, and only
-// T > 1 needs the reduction of the quad partials through LDS.  More quads per thread spread the per-level work that does not depend
-// on the g-point (Planck functions of the level, fraction rows, layer flags, loads of temperatures, loop control: ~40 % of a clear
-// level's instructions at G = 1) over more g-points and give the wave more independent recurrences to overlap; they cost registers
-// (2 per g-point for the clear-sky sweep, 8-10 in the cloudy ones).
-#ifndef RRLW_SWEEP_G_CLOUD
-#define RRLW_SWEEP_G_CLOUD 1      // cloudy modes: quads per thread where it divides NQ
-#endif
-__host__ __device__ constexpr int sweep_g(int NQ, int MODE, bool IDRV)
-{
-    const int want = RRLW_SWEEP_G_CLOUD;
-    (void)IDRV; (void)MODE;
-    return (want >= 1 && want <= NQ && NQ % want == 0) ? want : 1;
-}
-__host__ __device__ constexpr int sweep_t(int NQ, int MODE, bool IDRV) { return NQ / sweep_g(NQ, MODE, IDRV); }
-#ifndef RRLW_SWEEP_WAVES_CLOUD_G
-#define RRLW_SWEEP_WAVES_CLOUD_G 2   // cloudy modes with more than one quad per thread
-#endif
-__host__ __device__ constexpr int sweep_waves(int MODE, bool IDRV, int G = 1)
-{
-    if (G > 1) return RRLW_SWEEP_WAVES_CLOUD_G;
-    if (IDRV) return 2;                       // the d(flux)/dT instantiations carry 32 more registers (rtrnmr spills 170 dwords at 168)
-    return MODE == 1 ? RRLW_SWEEP_WAVES_RTRN : MODE == 2 ? RRLW_SWEEP_WAVES_RTRNMR :
-           MODE == 3 ? RRLW_SWEEP_WAVES_MCARR : RRLW_SWEEP_WAVES_MCMASK;
-}
-// column sub-blocks (of 64 columns) per workgroup for bands of NQ quads: one workgroup per CU (the table in LDS) that fills the
-// 4 x sweep_waves wave slots the kernel is compiled for
-__host__ __device__ constexpr int sweep_ns(int NQ, int MODE, bool IDRV)
-{
-    const int waves = 4 * sweep_waves(MODE, IDRV, sweep_g(NQ, MODE, IDRV));         // per workgroup = per CU
-    const int T = sweep_t(NQ, MODE, IDRV);
-    return T == 3 ? (waves / 3 > 1 ? waves / 3 : 1) : waves / T;     // (3 threads per band: 12 of 12, 15 of 16 or 6 of 8 wave slots)
-}
-// dynamic LDS of k_sweep<., NQ>: transmittance table (float pairs), Planck rows, fraction rows, reduction buffer
+// LDS of a sweep workgroup: transmittance table (float pairs), per band the Planck rows and the fraction rows
 #ifdef RRLW_SWEEP_EXPF
 constexpr int SWEEP_LUT_BYTES = 16;                   // no table in LDS
 #else
 constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8;
 #endif
 constexpr int SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
-__host__ __device__ constexpr int sweep_lds_bytes(int NQ, int MODE, bool IDRV)
-{
-    const int T = sweep_t(NQ, MODE, IDRV);
-    return SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES + (T > 1 ? sweep_ns(NQ, MODE, IDRV) * T * SWEEP_LV * 64 * 16 : 0);
-}
-
-// Loads of k_sweep: wave-uniform base pointer in a buffer descriptor (scalar registers), per-lane 32-bit byte offset that does not
+// Loads of the sweeps: wave-uniform base pointer in a buffer descriptor (scalar registers), per-lane 32-bit byte offset that does not
 // change from level to level - no 64-bit vector address arithmetic per load.  nt = streaming (non-temporal) access.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_rsrc(const void *base)
 {
@@ -2024,554 +1953,6 @@ __device__ __forceinline__ void sweep_stage_band(const DevTables &T, double (*s_
         s_fr[r][g] = v;
     }
 }
-__device__ __forceinline__ void sweep_stage_tables(const DevTables &T, unsigned char *smem, int B, bool alt16, bool lo_bin, bool up_bin, int tid, int nth)
-{
-    sweep_stage_lut(T, smem, tid, nth);
-    sweep_stage_band(T, reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES), reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES),
-                     B, alt16, lo_bin, up_bin, tid, nth);
-    __syncthreads();
-}
-
-template <int G> struct SweepLev { scr4 c[G], ct[G]; double tl, tz, cf; unsigned w; };     // one level's prefetched inputs (G quads of codes)
-
-template <int MODE, int NQ, bool IDRV>
-__global__ __launch_bounds__(64 * sweep_t(NQ, MODE, IDRV) * sweep_ns(NQ, MODE, IDRV), sweep_waves(MODE, IDRV, sweep_g(NQ, MODE, IDRV)))
-void k_sweep(DevTables T, Workspace W, SweepArgs a)
-{
-    constexpr int G = sweep_g(NQ, MODE, IDRV), NT = sweep_t(NQ, MODE, IDRV);      // quads per thread, threads (waves) per band and column block
-    constexpr int NGC = 4 * G;
-    constexpr int LV = SWEEP_LV, PF = sweep_pf(MODE, IDRV);
-    static_assert(LV % PF == 0, "prefetch slots");
-    constexpr int NS = sweep_ns(NQ, MODE, IDRV);
-    // refill a slot's first part in mid-level?  Pays where registers are not the limit (the two-wave d(flux)/dT sweeps: 137 layers
-    // 68.4 -> 60.3 ms per 5e5 columns); at the rtrnmr sweep's 168-register cap it doubles the spills (51.9 -> 70.0 ms)
-    // The code load is the one true HBM stream of the sweep (everything else a level needs hits L2); where the slot count is 1, the
-    // codes alone get a second slot (4 registers): issued two levels ahead
-#ifndef RRLW_SWEEP_CODES2
-#define RRLW_SWEEP_CODES2 0       // (the second code slot costs 8 registers; with the leaner branches of round 2 the kernel is faster without: 16.9 -> 16.2 ms)
-#endif
-    constexpr bool CODES2 = RRLW_SWEEP_CODES2 && PF == 1;
-#ifdef RRLW_SWEEP_EARLY_ALL        // (tuning: rtrnmr at two waves, two slots and early refill 62.7 ms against 51.9 ms at three waves and one slot)
-    constexpr bool EARLY = true;
-#else
-    constexpr bool EARLY = IDRV;
-#endif
-    extern __shared__ __align__(16) unsigned char smem[];
-    float2 *s_lut = reinterpret_cast<float2 *>(smem);                                              // [NTBL + 1] {1 - exp, tfn}
-    double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES);              // [0] this band's Planck integrals, [1] band 16's (istart = 16 quirk)
-    double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES);   // Planck fractions: rows 0-8 fracrefa, 9-13 fracrefb, 14-15 zeros
-    const int tx = threadIdx.x, slot = threadIdx.y, sub = threadIdx.z;
-    Part2 *red = reinterpret_cast<Part2 *>(smem + SWEEP_LUT_BYTES + SWEEP_PL_BYTES + SWEEP_FR_BYTES) + (size_t)sub * NT * LV * 64;   // [slot][level-in-round][column]
-    // Workgroup -> (column block, band).  Consecutive workgroup ids go round the 8 XCDs (each with its own L2), and the bands of one
-    // column block read the same temperatures, flags and cloud fractions: ids that share an XCD (same id % 8) walk the bands of one
-    // column block before they move to the next block, so those re-reads hit that XCD's L2 instead of HBM.
-    const int wq = blockIdx.x >> 3;
-    const int cblock = (wq / a.nbands) * 8 + (blockIdx.x & 7);
-    if (cblock >= a.ncb) return;                    // uniform over the workgroup (the grid is padded to a multiple of 8 column blocks)
-    const int col = (cblock * NS + sub) * 64 + tx;
-    const int B = (int)((a.bands >> (4 * (wq % a.nbands))) & 15ull) + 1;     // bands with NQ quads, packed as nibbles (band - 1)
-    if (B < a.istart || B > a.iend) return;         // uniform over the workgroup
-    const bool incol = col < a.ncol;
-    const int colc = incol ? col : a.ncol - 1;      // lanes past the end shadow the last column
-    const int quad = band_qstart(B) + slot * G;        // first of this thread's G quads
-    const size_t gc = (size_t)a.col0 + colc;
-    const int nlay = W.nlay, nct = a.nct;
-    const size_t ncb = W.ncolb;
-    const double wtdelw = T.delwave[B - 1];
-    constexpr bool idrv = IDRV;          // d(upward flux)/dT carried along (idrv = 1): a separate instantiation, the common case carries nothing
-    const bool alt16 = (B == 16 && a.istart == 16);
-    const bool lo_bin = (LO_BINARY >> (B - 1)) & 1u, up_bin = (UP_BINARY >> (B - 1)) & 1u;
-    const bool any_bin = lo_bin || up_bin;
-    const int base_up = ((UP_ZERO >> (B - 1)) & 1u) ? 14 : (((UP_FROM_A >> (B - 1)) & 1u) ? 0 : 9);     // first fracs row of the upper atmosphere
-    sweep_stage_tables(T, smem, B, alt16, lo_bin, up_bin, (sub * NT + slot) * 64 + tx, 64 * NT * NS);
-    // wave-uniform bases (the quad index is uniform over a wave: one wave = 64 columns of one quad) and per-lane byte offsets
-    const int uquad = __builtin_amdgcn_readfirstlane(quad);
-    const size_t qstride = (size_t)nlay * ncb;            // scr4 cells between consecutive quads
-    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)uquad * qstride;
-    const scr4 *__restrict__ sCt = reinterpret_cast<const scr4 *>(W.scr[S_CODET]) + (size_t)uquad * qstride;
-    const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
-    const int *__restrict__ sFlag = W.cflag;
-    const double *__restrict__ tlay = a.tlay + a.col0;
-    const double *__restrict__ tlev = a.tlev + a.col0;
-    const double *__restrict__ cldf = a.cldfrac + a.col0;
-    const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
-    // (uniform bases: the band's slabs; a lane's column is the 32-bit offset of a buffer store)
-    Part2 *__restrict__ pdn = W.pdn + ((size_t)(B - 1) * (nlay + 1)) * ncb;
-    Part2 *__restrict__ pup = W.pup + ((size_t)(B - 1) * (nlay + 1)) * ncb;
-    Part2 *__restrict__ dbase = W.dpart + ((size_t)(B - 1) * (nlay + 1)) * ncb;
-    const unsigned so16 = (unsigned)col * 16u;
-    auto st_part = [&](Part2 *slab, int lv, const Part2 &v) { bstore_f64x2(slab + (size_t)lv * ncb, so16, v.a, v.b); };
-    const int laytrop = W.laytrop[colc];
-    const double *tp0 = s_pl[0], *tp1 = s_pl[1];
-    // The cloudy modes sweep only the layers 1 .. ltop, ltop = the highest layer of the batch that holds cloud in any column: above it
-    // k_sweepc<., 1> (downward) and k_sweepc<., 2> (upward) run the clear-sky recurrences with all g-points of a band in one thread, and
-    // the radiances at level ltop are handed over through W.hand.
-    static_assert(MODE >= 1 && MODE <= 4, "cloud-free calls are k_sweepc's");
-    const int ltop = __builtin_amdgcn_readfirstlane(*W.ltop);
-    // W.hand as double2: [stream][quad][column][2]
-    auto hand_ptr = [&]() -> double2 * { return reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + colc) * 2; };
-
-    // adds the round's partials of the band's quads in quad order; wave `slot` finishes levels lev0 + dir * (slot, slot + NQ, ..)
-    auto reduce_store = [&](const Part2 (&acc)[LV], Part2 *__restrict__ dst, int lev0, int dir) {
-        if constexpr (NT == 1) {
-#pragma unroll
-            for (int i = 0; i < LV; i++) {
-                const int lv = lev0 + dir * i;
-                if (incol && lv >= 0 && lv <= ltop) st_part(dst, lv, acc[i]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < LV; i++) red[(slot * LV + i) * 64 + tx] = acc[i];
-            __syncthreads();
-#pragma unroll
-            for (int i0 = 0; i0 < LV; i0 += NT) {
-                const int i = i0 + slot;
-                const int lv = lev0 + dir * i;
-                if (i < LV && incol && lv >= 0 && lv <= ltop) {
-                    Part2 sum = red[i * 64 + tx];
-#pragma unroll
-                    for (int q = 1; q < NT; q++) {
-                        const Part2 v = red[(q * LV + i) * 64 + tx];
-                        sum.a = sum.a + v.a;
-                        sum.b = sum.b + v.b;
-                    }
-                    st_part(dst, lv, sum);
-                }
-            }
-            __syncthreads();
-        }
-    };
-
-    // a level's partial goes straight to the reduction buffer (or, for a one-quad band, to memory): nothing is held across the round
-    auto put_part = [&](int i, int lv, const Part2 &v, Part2 *__restrict__ dst) {
-        if constexpr (NT == 1) { if (incol) st_part(dst, lv, v); }
-        else red[(slot * LV + i) * 64 + tx] = v;
-    };
-    auto reduce_round = [&](Part2 *__restrict__ dst, int lev0, int dir) {
-        if constexpr (NT > 1) {
-            __syncthreads();
-#pragma unroll
-            for (int i0 = 0; i0 < LV; i0 += NT) {
-                const int i = i0 + slot;
-                const int lv = lev0 + dir * i;
-                if (i < LV && incol && lv >= 0 && lv <= ltop) {
-                    Part2 sum = red[i * 64 + tx];
-#pragma unroll
-                    for (int q = 1; q < NT; q++) {
-                        const Part2 v = red[(q * LV + i) * 64 + tx];
-                        sum.a = sum.a + v.a;
-                        sum.b = sum.b + v.b;
-                    }
-                    st_part(dst, lv, sum);
-                }
-            }
-            __syncthreads();
-        }
-    };
-
-    // MODE 4: the sub-column mask bits of this thread's NGC g-points in layer `lev` (bits of padding g-points cleared)
-    auto quad_bits = [&](int lev) -> unsigned {
-        const int ig0 = band_g0(B) + NGC * slot, w0 = ig0 >> 5;
-        const int nvalid = max(0, min(NGC, band_ng(B) - NGC * slot));
-        const size_t mo = (size_t)(lev - 1) * W.mask_stride + W.mask_col0 + gc;
-        const unsigned long long lo = W.mask[(size_t)w0 * nlay * W.mask_stride + mo];
-        const unsigned long long hi = (w0 < 4 && (ig0 & 31) + NGC > 32) ? W.mask[(size_t)(w0 + 1) * nlay * W.mask_stride + mo] : 0u;
-        return (unsigned)(((lo | (hi << 32)) >> (ig0 & 31)) & ((1u << nvalid) - 1u));
-    };
-
-    // Planck fractions of this thread's g-points in layer `lev`: taumol (constant rows, or :556-561 / :692-693 interpolated between
-    // rows js-1 and js with k_layer's (js, fs) word): first row and interpolation weight
-    auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
-        const bool lower = lev <= laytrop;
-        if (any_bin) {          // uniform
-            const unsigned w = (lower ? lo_bin : up_bin) ? fwv : 0x10000000u;
-            const int r0 = clampi((lower ? 0 : base_up) + (int)(w >> 28) - 1, 0, 14);
-            fpl = (double)(w & 0x0fffffffu) * (1.0 / 268435456.0);
-            return &s_fr[r0][NGC * slot];
-        }
-        fpl = 0.0;
-        return &s_fr[lower ? 0 : base_up][NGC * slot];
-    };
-    auto frac_at = [&](const double *row, double fpl, int j) -> double { return any_bin ? row[j] + fpl * (row[16 + j] - row[j]) : row[j]; };
-    // One cell's gas terms from its code and table entry: (1 - transmittance), Planck fraction, source term bb = fr (blay + tfn dpl).
-    // Formed per g-point where they are used - kept as arrays across the clear / cloudy branch they cost 24 registers and the rtrnmr
-    // instantiations spilled; only the table entries (fetched together, ahead of the branch) and the codes stay live.
-    auto cell = [&](int j, scr_t cj, const float2 &e, const double *row, double fpl, double blay, double dpl, double &atr, double &fr, double &bb) {
-        double tfn;
-        decode(cj, e, atr, tfn);
-        fr = frac_at(row, fpl, j);
-        bb = fr * (blay + tfn * dpl);
-    };
-    // layer flag (bit 0: the layer holds cloud) - out-of-range levels are clear
-    // (the raw word stays in a vector register until the level that needs it: turning it into a lane mask at once would wait for the
-    // load - and, completion being in order, for every prefetch before it - right where it is issued)
-    auto ldflag = [&](int lev) -> unsigned {
-        return (lev >= 1 && lev <= nlay) ? bload_u32(sFlag + (size_t)lev * ncb, off4) : 0u;
-    };
-    // the loads of level `lev`: zlev = the interface whose temperature the sweep direction needs, nlev = the next level in sweep
-    // direction; cloudy = the level's flag (known a round earlier) selects the extra loads of a cloudy level
-    // part 1: what a level consumes first (codes, temperatures, fraction word), part 2: what only a cloudy level's recurrence needs;
-    // 3 = both.  A slot's first part is refilled as soon as the level has decoded it, half a level before the second.
-    auto fill = [&](int lev, int zlev, int nlev, unsigned flagword, SweepLev<G> &q, int part) {
-        const bool cloudy = (flagword & 1u) != 0u;
-        if (part & 1) q.w = 0u;
-        if (lev >= 1 && lev <= nlay) {                         // uniform
-            const size_t so = (size_t)(lev - 1) * ncb;
-            if (part & 1) {
-                if (!CODES2) {
-#pragma unroll
-                    for (int k = 0; k < G; k++) q.c[k] = bload_scr4_nt(sC + k * qstride + so, off16);
-                }
-                q.tl = bload_f64(tlay + (size_t)nct * (lev - 1), off8);
-                q.tz = bload_f64(tlev + (size_t)nct * zlev, off8);
-                if (any_bin) q.w = bload_u32(sFw + so, off4);
-            }
-            if ((part & 2) && cloudy) {
-#pragma unroll
-                for (int k = 0; k < G; k++) q.ct[k] = bload_scr4_nt(sCt + k * qstride + so, off16);
-                if constexpr (MODE == 1 || MODE == 2) q.cf = bload_f64(cldf + (size_t)nct * (lev - 1), off8);
-            }
-        }
-    };
-
-    const bool colcloud = (bload_u32(sFlag, off4) & 8u) != 0;
-
-    double radld[NGC], radclrd[NGC], cldrad[NGC], clrrad[NGC], radmr[NGC];
-#pragma unroll
-    for (int j = 0; j < NGC; j++) { radld[j] = 0.0; radclrd[j] = 0.0; cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
-    bool iclddn = false;
-    {                               // downward radiances at level ltop from k_sweepc<., 1> (zeros when ltop = nlay); clear = total up there
-        const double2 *hand = hand_ptr();
-#pragma unroll
-        for (int k = 0; k < G; k++) {
-            const double2 h0 = hand[(size_t)k * ncb * 2], h1 = hand[(size_t)k * ncb * 2 + 1];
-            radld[4 * k] = h0.x; radld[4 * k + 1] = h0.y; radld[4 * k + 2] = h1.x; radld[4 * k + 3] = h1.y;
-        }
-#pragma unroll
-        for (int j = 0; j < NGC; j++) radclrd[j] = radld[j];
-    }
-
-    // ------------------------------------------------------------------ downward sweep, SWEEP_LV levels per round
-    // Rolling prefetch: the loads of a level are issued SWEEP_LV levels before it is processed (into the slot of the level just
-    // consumed), its cloud flag 2 x SWEEP_LV levels before, so that the conditional loads of a cloudy level are part of the prefetch.
-    SweepLev<G> p[PF];
-    struct CodesG { scr4 q[G]; };
-    CodesG cq[2];                        // CODES2: gas codes of the next two levels
-    auto ldcodes = [&](int lev) -> CodesG {
-        CodesG r;
-#pragma unroll
-        for (int k = 0; k < G; k++) {
-            scr4 z; z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
-            r.q[k] = (lev >= 1 && lev <= nlay) ? bload_scr4_nt(sC + k * qstride + (size_t)(lev - 1) * ncb, off16) : z;
-        }
-        return r;
-    };
-    unsigned fl[2][PF];
-#pragma unroll
-    for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(ltop - i); fl[1][i] = ldflag(ltop - PF - i); }
-#pragma unroll
-    for (int i = 0; i < PF; i++) fill(ltop - i, ltop - i - 1, ltop - i - 1, fl[0][i], p[i], 3);
-    if constexpr (CODES2) { cq[0] = ldcodes(ltop); cq[1] = ldcodes(ltop - 1); }
-    for (int top = ltop; top >= 1; top -= LV) {
-#pragma unroll
-        for (int i = 0; i < LV; i++) {
-            const int lev = top - i;
-            const int s = i % PF;
-            const SweepLev<G> &cur = p[s];
-            const bool cloudy = (fl[0][s] & 1u) != 0u;
-            // the slot is refilled (level lev - PF) once this level has consumed it
-            auto advance_early = [&]() { if constexpr (EARLY) fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[1][s], p[s], 1); };
-            auto advance = [&]() {
-                fl[0][s] = fl[1][s];
-                fill(lev - PF, lev - PF - 1, lev - PF - 1, fl[0][s], p[s], EARLY ? 2 : 3);
-                fl[1][s] = ldflag(lev - 2 * PF);
-            };
-            if (lev < 1) { advance_early(); advance(); continue; }          // uniform
-            double fpl;
-            const double *row = frac_row(lev, cur.w, fpl);
-            const double blay = planck_at(tp0, tp0, cur.tl);
-            const double dplankdn = planck_at(tp0, (alt16 && lev == 1) ? tp1 : tp0, cur.tz) - blay;
-            scr_t cg[NGC];
-            float2 eg[NGC];
-#pragma unroll
-            for (int j = 0; j < NGC; j++) {
-                cg[j] = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
-                eg[j] = RRLW_LUT_ENTRY(s_lut, code_index(cg[j]));
-            }
-            if constexpr (CODES2) cq[i & 1] = ldcodes(lev - 2);
-            advance_early();
-            double dsum = 0.0, dsumc = 0.0;
-            if (!cloudy) {
-#pragma unroll
-                for (int j = 0; j < NGC; j++) {
-                    double atr, fr, bbd;
-                    cell(j, cg[j], eg[j], row, fpl, blay, dplankdn, atr, fr, bbd);
-                    radld[j] = radld[j] + (bbd - radld[j]) * atr;
-                    dsum = dsum + radld[j];
-                    {
-                        const double upd = radclrd[j] + (bbd - radclrd[j]) * atr;
-                        radclrd[j] = iclddn ? upd : radld[j];
-                        dsumc = dsumc + radclrd[j];
-                    }
-                }
-            } else {
-                {
-                    iclddn = true;
-                    const double cf = cur.cf;
-                    double efcl = 0.0;
-                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
-                    OvlFac mf{0, 0, 0, 0, 0, 0, false, false};
-                    bool first = false;
-                    if constexpr (MODE == 2) {      // overlap factors of the level (k_cloudscan; rtrnmr :427-506)
-                        first = (fl[0][s] & 2u) != 0u;
-                        const double2 *ov = W.ovl + ((size_t)lev * 3) * ncb;
-                        const double2 f0 = bload_f64x2(ov, off16), f1 = bload_f64x2(ov + ncb, off16), f2 = bload_f64x2(ov + 2 * ncb, off16);
-                        mf.clr1 = f0.x; mf.cld1 = f0.y; mf.cmb1 = f1.x; mf.cmb2 = f1.y; mf.clr2 = f2.x; mf.cld2 = f2.y;
-                    }
-                    double cfj[NGC], efj[NGC];
-#pragma unroll
-                    for (int j = 0; j < NGC; j++) { cfj[j] = cf; efj[j] = efcl; }
-                    if constexpr (MODE == 3) {          // rtrnmc: cloud fraction and effective emissivity per g-point
-#pragma unroll
-                        for (int k = 0; k < G; k++) {
-                            const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)(quad + k) * nlay + (lev - 1)) * ncb + colc) * 8);
-                            const float4 c4 = pc[0], e4 = pc[1];
-                            cfj[4 * k] = c4.x; cfj[4 * k + 1] = c4.y; cfj[4 * k + 2] = c4.z; cfj[4 * k + 3] = c4.w;
-                            efj[4 * k] = e4.x; efj[4 * k + 1] = e4.y; efj[4 * k + 2] = e4.z; efj[4 * k + 3] = e4.w;
-                        }
-                    }
-                    if constexpr (MODE == 4) {
-                        const unsigned bits = quad_bits(lev);
-                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
-#pragma unroll
-                        for (int j = 0; j < NGC; j++) { const bool on = (bits >> j) & 1u; cfj[j] = on ? 1.0 : 0.0; efj[j] = on ? ef : 0.0; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < NGC; j++) {
-                        double atr, frj, bbdj;
-                        cell(j, cg[j], eg[j], row, fpl, blay, dplankdn, atr, frj, bbdj);
-                        double atot, tftot;
-                        decode(cur.ct[j / 4].v[j % 4], RRLW_LUT_ENTRY(s_lut, code_index(cur.ct[j / 4].v[j % 4])), atot, tftot);
-                        const double bbdtot = frj * (blay + tftot * dplankdn);
-                        const double gassrc = bbdj * atr;
-                        if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
-                            // (explicit fused operations: the array and the mask flavour of rtrnmc must round identically, whatever the
-                            // compiler would contract in either instantiation)
-                            radld[j] = fma(cfj[j], fma(bbdtot, atot, -gassrc), fma(-radld[j], fma(efj[j], 1. - atr, atr), radld[j]) + gassrc);
-                        } else {            // rtrnmr :591-615
-                            if (first) {        // istcldd(lev) == 1
-                                cldrad[j] = cf * radld[j];
-                                clrrad[j] = radld[j] - cldrad[j];
-                                radmr[j] = 0.0;
-                            }
-                            const double ttot = 1. - atot;
-                            const double cldsrc = bbdtot * atot;
-                            cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                            clrrad[j] = clrrad[j] * (1. - atr) + (1. - cf) * gassrc;
-                            radld[j] = cldrad[j] + clrrad[j];
-                            const double radmod = radmr[j] * (mf.clr1 * (1. - atr) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
-                            const double oldcld = cldrad[j] - radmod;
-                            const double oldclr = clrrad[j] + radmod;
-                            radmr[j] = -radmod + mf.clr2 * oldclr - mf.cld2 * oldcld;
-                            cldrad[j] = cldrad[j] + radmr[j];
-                            clrrad[j] = clrrad[j] - radmr[j];
-                        }
-                        dsum = dsum + radld[j];
-                        radclrd[j] = radclrd[j] + (bbdj - radclrd[j]) * atr;
-                        dsumc = dsumc + radclrd[j];
-                    }
-                }
-            }
-            put_part(i, lev - 1, Part2{(dsum * 0.5) * wtdelw, (dsumc * 0.5) * wtdelw}, pdn);
-            advance();
-        }
-        reduce_round(pdn, top - 1, -1);
-    }
-
-    // ------------------------------------------------------------------ surface: rtrn :476-495
-    double radlu[NGC], radclru[NGC], drad[NGC], dradc[NGC];
-    Part2 surf{0.0, 0.0}, dsurf{0.0, 0.0};
-    {
-        const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
-        const double pb = W.percol[(size_t)(PC_PLANKBND + B - 1) * ncb + colc];
-        const double dpb = idrv ? W.percol[(size_t)(PC_DPLANKBND + B - 1) * ncb + colc] : 0.0;
-        double fpl1;                         // fracs(1,g): the surface emits with the lowest layer's Planck fractions
-        const double *row1 = frac_row(1, any_bin ? bload_u32(sFw, off4) : 0u, fpl1);
-        double usum = 0.0, usumc = 0.0, dusum = 0.0;
-#pragma unroll
-        for (int j = 0; j < NGC; j++) {
-            const double fr1j = frac_at(row1, fpl1, j);
-            const double rad0 = fr1j * pb;
-            radlu[j] = rad0 + reflect * radld[j];
-            radclru[j] = rad0 + reflect * radclrd[j];
-            usum = usum + radlu[j];
-            usumc = usumc + radclru[j];
-            drad[j] = idrv ? fr1j * dpb : 0.0;
-            dradc[j] = drad[j];
-            dusum = dusum + drad[j];
-        }
-        surf = Part2{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw};
-        dsurf = Part2{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusum * 0.5) * wtdelw) * T.fluxfac};
-    }
-#pragma unroll
-    for (int j = 0; j < NGC; j++) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
-
-    // ------------------------------------------------------------------ upward sweep: round r covers levels base .. base+LV-1,
-    // level 0 being the surface value computed above
-#pragma unroll
-    for (int i = 0; i < PF; i++) { fl[0][i] = ldflag(i); fl[1][i] = ldflag(PF + i); }
-#pragma unroll
-    for (int i = 0; i < PF; i++) fill(i, i, i + 1, fl[0][i], p[i], 3);
-    if constexpr (CODES2) { cq[0] = ldcodes(0); cq[1] = ldcodes(1); }
-    for (int base = 0; base <= ltop; base += LV) {
-        Part2 accd[idrv ? LV : 1];
-#pragma unroll
-        for (int i = 0; i < LV; i++) {
-            const int lev = base + i;
-            if constexpr (idrv) accd[i] = Part2{0.0, 0.0};
-            const int s = i % PF;
-            const SweepLev<G> &cur = p[s];
-            const bool cloudy = (fl[0][s] & 1u) != 0u;
-            auto advance_early = [&]() { if constexpr (EARLY) fill(lev + PF, lev + PF, lev + PF + 1, fl[1][s], p[s], 1); };
-            auto advance = [&]() {
-                fl[0][s] = fl[1][s];
-                fill(lev + PF, lev + PF, lev + PF + 1, fl[0][s], p[s], EARLY ? 2 : 3);
-                fl[1][s] = ldflag(lev + 2 * PF);
-            };
-            if (lev > ltop) { advance_early(); advance(); continue; }                            // uniform
-            if (lev == 0) {                                                     // uniform
-                put_part(i, 0, surf, pup);
-                if constexpr (idrv) accd[i] = dsurf;
-                if constexpr (CODES2) cq[i & 1] = ldcodes(lev + 2);
-                advance_early();
-                advance();
-                continue;
-            }
-            double fpl;
-            const double *row = frac_row(lev, cur.w, fpl);
-            const double blay = planck_at(tp0, tp0, cur.tl);
-            const double dplankup = planck_at(tp0, tp0, cur.tz) - blay;
-            scr_t cg[NGC];
-            float2 eg[NGC];
-#pragma unroll
-            for (int j = 0; j < NGC; j++) {
-                cg[j] = CODES2 ? cq[i & 1].q[j / 4].v[j % 4] : cur.c[j / 4].v[j % 4];
-                eg[j] = RRLW_LUT_ENTRY(s_lut, code_index(cg[j]));
-            }
-            if constexpr (CODES2) cq[i & 1] = ldcodes(lev + 2);
-            advance_early();
-            double usum = 0.0, usumc = 0.0, dusum = 0.0, dusumc = 0.0;
-            if (!cloudy) {
-#pragma unroll
-                for (int j = 0; j < NGC; j++) {
-                    double atr, fr, bbu;
-                    cell(j, cg[j], eg[j], row, fpl, blay, dplankup, atr, fr, bbu);
-                    radlu[j] = radlu[j] + (bbu - radlu[j]) * atr;
-                    usum = usum + radlu[j];
-                    if (idrv) { drad[j] = drad[j] * (1.0 - atr); dusum = dusum + drad[j]; }
-                    {
-                        const double upd = radclru[j] + (bbu - radclru[j]) * atr;
-                        radclru[j] = colcloud ? upd : radlu[j];
-                        if (idrv) { dradc[j] = colcloud ? dradc[j] * (1.0 - atr) : drad[j]; dusumc = dusumc + dradc[j]; }
-                        usumc = usumc + radclru[j];
-                    }
-                }
-            } else {
-                {
-                    const double cf = cur.cf;
-                    double efcl = 0.0;
-                    if constexpr (MODE == 1) efcl = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
-                    OvlFac mf{0, 0, 0, 0, 0, 0, false, false};
-                    bool first = false;
-                    if constexpr (MODE == 2) {      // (rtrnmr :347-425)
-                        first = (fl[0][s] & 4u) != 0u;
-                        const double2 *ov = W.ovl + ((size_t)((nlay + 1) + lev) * 3) * ncb;
-                        const double2 f0 = bload_f64x2(ov, off16), f1 = bload_f64x2(ov + ncb, off16), f2 = bload_f64x2(ov + 2 * ncb, off16);
-                        mf.clr1 = f0.x; mf.cld1 = f0.y; mf.cmb1 = f1.x; mf.cmb2 = f1.y; mf.clr2 = f2.x; mf.cld2 = f2.y;
-                    }
-                    double cfj[NGC], efj[NGC];
-#pragma unroll
-                    for (int j = 0; j < NGC; j++) { cfj[j] = cf; efj[j] = efcl; }
-                    if constexpr (MODE == 3) {
-#pragma unroll
-                        for (int k = 0; k < G; k++) {
-                            const float4 *pc = reinterpret_cast<const float4 *>(W.cfef + (((size_t)(quad + k) * nlay + (lev - 1)) * ncb + colc) * 8);
-                            const float4 c4 = pc[0], e4 = pc[1];
-                            cfj[4 * k] = c4.x; cfj[4 * k + 1] = c4.y; cfj[4 * k + 2] = c4.z; cfj[4 * k + 3] = c4.w;
-                            efj[4 * k] = e4.x; efj[4 * k + 1] = e4.y; efj[4 * k + 2] = e4.z; efj[4 * k + 3] = e4.w;
-                        }
-                    }
-                    if constexpr (MODE == 4) {
-                        const unsigned bits = quad_bits(lev);
-                        const double ef = W.efcl[((size_t)(B - 1) * nlay + (lev - 1)) * ncb + colc];
-#pragma unroll
-                        for (int j = 0; j < NGC; j++) { const bool on = (bits >> j) & 1u; cfj[j] = on ? 1.0 : 0.0; efj[j] = on ? ef : 0.0; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < NGC; j++) {
-                        double atr, frj, bbuj;
-                        cell(j, cg[j], eg[j], row, fpl, blay, dplankup, atr, frj, bbuj);
-                        double atot, tftot;
-                        decode(cur.ct[j / 4].v[j % 4], RRLW_LUT_ENTRY(s_lut, code_index(cur.ct[j / 4].v[j % 4])), atot, tftot);
-                        const double bbutot = frj * (blay + tftot * dplankup);
-                        const double gassrc = bbuj * atr;
-                        if constexpr (MODE == 1 || MODE == 3 || MODE == 4) {
-                            radlu[j] = fma(cfj[j], fma(bbutot, atot, -gassrc), fma(-radlu[j], fma(efj[j], 1. - atr, atr), radlu[j]) + gassrc);
-                        } else {            // rtrnmr :680-703
-                            if (first) {        // istcld(lev) == 1
-                                cldrad[j] = cf * radlu[j];
-                                clrrad[j] = radlu[j] - cldrad[j];
-                                radmr[j] = 0.0;
-                            }
-                            const double ttot = 1. - atot;
-                            const double cldsrc = bbutot * atot;
-                            cldrad[j] = cldrad[j] * ttot + cf * cldsrc;
-                            clrrad[j] = clrrad[j] * (1.0 - atr) + (1. - cf) * gassrc;
-                            radlu[j] = cldrad[j] + clrrad[j];
-                            const double radmod = radmr[j] * (mf.clr1 * (1.0 - atr) + mf.cld1 * ttot) - mf.cmb1 * gassrc + mf.cmb2 * cldsrc;
-                            const double oldcld = cldrad[j] - radmod;
-                            const double oldclr = clrrad[j] + radmod;
-                            radmr[j] = -radmod + mf.clr2 * oldclr - mf.cld2 * oldcld;
-                            cldrad[j] = cldrad[j] + radmr[j];
-                            clrrad[j] = clrrad[j] - radmr[j];
-                        }
-                        usum = usum + radlu[j];
-                        if (idrv) {
-                            drad[j] = drad[j] * cfj[j] * (1.0 - atot) + drad[j] * (1.0 - cfj[j]) * (1.0 - atr);
-                            dusum = dusum + drad[j];
-                            dradc[j] = dradc[j] * (1.0 - atr);
-                            dusumc = dusumc + dradc[j];
-                        }
-                        radclru[j] = radclru[j] + (bbuj - radclru[j]) * atr;
-                        usumc = usumc + radclru[j];
-                    }
-                }
-            }
-            put_part(i, lev, Part2{(usum * 0.5) * wtdelw, (usumc * 0.5) * wtdelw}, pup);
-            if constexpr (idrv) accd[i] = Part2{((dusum * 0.5) * wtdelw) * T.fluxfac, ((dusumc * 0.5) * wtdelw) * T.fluxfac};
-            advance();
-        }
-        reduce_round(pup, base, +1);
-        if constexpr (idrv) reduce_store(accd, dbase, base, +1);
-    }
-    {                                   // upward radiances at level ltop for k_sweepc<., 2>
-        if (incol) {
-            double2 *hand = hand_ptr();
-            const size_t hstream = (size_t)NQUAD * ncb * 2;
-#pragma unroll
-            for (int k = 0; k < G; k++) {
-                double2 *h = hand + (size_t)k * ncb * 2;
-                h[hstream] = make_double2(radlu[4 * k], radlu[4 * k + 1]);          h[hstream + 1] = make_double2(radlu[4 * k + 2], radlu[4 * k + 3]);
-                h[2 * hstream] = make_double2(radclru[4 * k], radclru[4 * k + 1]);  h[2 * hstream + 1] = make_double2(radclru[4 * k + 2], radclru[4 * k + 3]);
-                if constexpr (idrv) {
-                    h[3 * hstream] = make_double2(drad[4 * k], drad[4 * k + 1]);    h[3 * hstream + 1] = make_double2(drad[4 * k + 2], drad[4 * k + 3]);
-                    h[4 * hstream] = make_double2(dradc[4 * k], dradc[4 * k + 1]);  h[4 * hstream + 1] = make_double2(dradc[4 * k + 2], dradc[4 * k + 3]);
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_sweepc : the clear-sky recurrences (src/rrtmg_lw_rtrn.f90:437-466 downward, :497-540 upward; identical in rtrnmr / rtrnmc) with
 //            ALL g-points of a band in one thread: one thread = (column, band), no reduction across threads.  The work of a level that
@@ -3496,16 +2877,14 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_flux  : sum of the band / group partials (rtrn :549-574) and flux scaling (rtrn :580-594), one
-//           thread per (column, level).  clear_from_total: a cloud-free call, the clear-sky stream equals the
-//           total-sky stream.  Only bands in [istart, iend] were swept: the groups list exactly those.
+// k_flux  : sum of the group partials (rtrn :549-574) and flux scaling (rtrn :580-594), one thread per
+//           (column, level).  clear_from_total: a cloud-free call, the clear-sky stream equals the total-sky
+//           stream.  Only bands in [istart, iend] were swept: the groups hold exactly those.
 // k_rates : net flux and heating rate (rtrn :583-604; output copies src/rrtmg_lw_rad.nomcica.f90:563-583),
 //           one thread per (column, layer).
 // ------------------------------------------------------------------------------------------------
-struct FluxGroups { int n; int nb[NGROUP_MAX]; unsigned long long bands[NGROUP_MAX]; };      // k_sweepc's groups: band lists as nibbles (band - 1)
-
 __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut out, int ncol, int col0, int nct,
-                                              int idrv, int clear_from_total, int zone_groups, FluxGroups fg)
+                                              int idrv, int clear_from_total, int ngroups)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
@@ -3514,34 +2893,16 @@ __global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut 
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
-    // Where k_sweepc ran - downward at and above the batch's highest cloud, upward above it, everywhere in a cloud-free call - the
-    // partials arrive summed per group; in the cloud zone they arrive per band and are added here in the same order (the bands of a group
-    // in list order, then the groups), so a level's flux does not depend on which kernel swept it.
+    // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
+    // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
     const int ltop = *W.ltop;
-    const bool dn_g = clear_from_total || lev >= ltop, up_g = clear_from_total || lev > ltop;       // uniform over the workgroup
-    for (int g = 0; g < fg.n; g++) {
+    const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // uniform over the workgroup
+    for (int g = 0; g < ngroups; g++) {
         const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;
-        Part2 su{0.0, 0.0}, sd{0.0, 0.0}, sq{0.0, 0.0};
-        if (dn_g) { sd.a = W.gdn1[go]; sd.b = sd.a; }
-        if (up_g) {
-            if (clear_from_total) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
-            if (idrv == 1) sq = W.gdp[go];
-        }
-        if (zone_groups) {                          // (k_sweepz: the cloud zone's partials are per group as well)
-            if (!dn_g) sd = W.gdn[go];
-            if (!up_g) { su = W.gup[go]; if (idrv == 1) sq = W.gdp[go]; }
-        } else if (!dn_g || !up_g) {
-            for (int k = 0; k < fg.nb[g]; k++) {
-                const int b = (int)((fg.bands[g] >> (4 * k)) & 15ull);
-                const size_t po = ((size_t)b * (nlay + 1) + lev) * ncb + col;
-                if (!dn_g) { const Part2 p = W.pdn[po]; if (k == 0) sd = p; else { sd.a = sd.a + p.a; sd.b = sd.b + p.b; } }
-                if (!up_g) {
-                    const Part2 p = W.pup[po];
-                    if (k == 0) su = p; else { su.a = su.a + p.a; su.b = su.b + p.b; }
-                    if (idrv == 1) { const Part2 q = W.dpart[po]; if (k == 0) sq = q; else { sq.a = sq.a + q.a; sq.b = sq.b + q.b; } }
-                }
-            }
-        }
+        Part2 su, sd, sq{0.0, 0.0};
+        if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
+        if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
+        if (idrv == 1) sq = W.gdp[go];
         u = u + su.a; uc = uc + su.b;
         d = d + sd.a; dc = dc + sd.b;
         du = du + sq.a; duc = duc + sq.b;
