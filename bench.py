@@ -304,7 +304,7 @@ def main():
             path = dict(kernels_ms_per_step=round(ktot / args.steps, 3),
                         kernels={k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                         families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
-                                  for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweepc", "k_sweepz", "k_flux", "k_rates")})
+                                  for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweepc", "k_sweepz", "k_flux")})
             # instruction side: counts per column from the committed PMC pass of the same configuration, times from this run
             pc = os.path.join(ROOT, "profiles", "pmc_compute.json")
             key = f"{args.config}_L{nlay}" + (f"_mcica{args.mcica}" if args.mcica else "")

@@ -386,13 +386,12 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     return 0;
 }
 
-// vertical part of one batch: k_sweep launches, k_flux, k_rates
+// vertical part of one batch: the sweep launches and k_flux
 template <bool GCM>
 int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
               const GcmIn &g, const ColIn &c, const FluxOut &out, const McIn *mc = nullptr)
 {
     const dim3 block(BLOCK);
-    const unsigned gx = (nb + BLOCK - 1) / BLOCK;
     if (int rc = ensure_sweep_attrs()) return rc;
     // The four sweep launches of a batch (bands of 4, 3, 2, 1 quads) are independent.  Each workgroup owns a CU, so a launch ends with
     // a partly filled last round (1-quad bands: 2.5 rounds); on separate streams the other launches' workgroups fill those CUs.
@@ -511,9 +510,10 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             HIP_TRY(hipStreamWaitEvent(s_main, G.ev_swq_done[k], 0));
         }
     }
-    const dim3 fgrid(gx, nlay + 1), rgrid(gx, nlay);
-    LAUNCH("k_flux", k_flux, fgrid, block, s, G.D, Wk, out, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
-    LAUNCH("k_rates", k_rates, rgrid, block, s, G.D, out, GCM ? g.plev : c.pz, nb, col0, nct);
+    {
+        const dim3 fgrid2((nb + 63) / 64, (nlay + 1 + FLUX_LV - 1) / FLUX_LV), fblock(64, FLUX_LV + 1);
+        LAUNCH("k_flux", k_flux, fgrid2, fblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     return 0;

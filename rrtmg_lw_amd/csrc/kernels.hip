@@ -14,11 +14,11 @@
 //              staged in LDS for the 256 columns of a workgroup, which share the layer), then for each cell the decision
 //              rtrn takes on its optical depth (series / table index) as a 4-byte code
 //                                                                       1 thread / (column, layer)
-//   k_sweep    the only vertically serial part: the down/up recurrences of rtrn / rtrnmr / rtrnmc over the cell codes
-//              (transmittance table, the band's Planck integrals and fractions in LDS; rtrnmr overlap factors on the fly);
-//              workgroup = 64 x ns columns x the quads of one band, flux partials reduced over the band in LDS
-//                                                                       1 thread / (column, quad)
-//   k_flux     band slabs -> fluxes;  k_rates  net flux -> heating rates   1 thread / (column, level)
+//   k_sweepc / k_sweepz   the only vertically serial part: the down/up recurrences of rtrn / rtrnmr / rtrnmc over the cell codes
+//              (transmittance table, the bands' Planck integrals and fractions in LDS); k_sweepc above the batch's highest cloud and
+//              for cloud-free calls (1 thread / (column, band)), k_sweepz in the cloud zone (1 thread / (column, quad)); a workgroup =
+//              the bands of one group, flux partials added over the group in LDS
+//   k_flux     group partials -> fluxes, net fluxes, heating rates           1 thread / (column, level)
 //   k_subcol_* McICA sub-column generator (bit masks), k_alpha           see the section below
 //
 // Reference lines are cited per routine.  No CPU fallback exists anywhere in this file.
@@ -2877,58 +2877,62 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_flux  : sum of the group partials (rtrn :549-574) and flux scaling (rtrn :580-594), one thread per
-//           (column, level).  clear_from_total: a cloud-free call, the clear-sky stream equals the total-sky
-//           stream.  Only bands in [istart, iend] were swept: the groups hold exactly those.
-// k_rates : net flux and heating rate (rtrn :583-604; output copies src/rrtmg_lw_rad.nomcica.f90:563-583),
-//           one thread per (column, layer).
+// k_flux  : sum of the group partials (rtrn :549-574), flux scaling (rtrn :580-594), net flux and heating rate
+//           (rtrn :583-604), one thread per (column, level); a workgroup covers 8 levels of 64 columns and sums
+//           the level above them once more, so that no second pass over the flux arrays is needed.
+//           clear_from_total: a cloud-free call, the clear-sky stream equals the total-sky stream.  Only bands in
+//           [istart, iend] were swept: the groups hold exactly those.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flux(DevTables T, Workspace W, FluxOut out, int ncol, int col0, int nct,
-                                              int idrv, int clear_from_total, int ngroups)
+constexpr int FLUX_LV = 8;          // levels of a k_flux workgroup (+ 1: the level above, summed again for the heating rate of the last layer)
+
+__global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct,
+                                                             int idrv, int clear_from_total, int ngroups)
 {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncol) return;
-    const int lev = blockIdx.y;
-    const size_t gc = (size_t)col0 + col;
+    __shared__ double s_net[FLUX_LV + 1][64], s_netc[FLUX_LV + 1][64];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int col = blockIdx.x * 64 + tx;
     const int nlay = W.nlay;
+    const int lev = blockIdx.y * FLUX_LV + ty;              // ty = FLUX_LV: the first level of the next workgroup (sums only)
+    const bool on = col < ncol && lev <= nlay;
+    const size_t gc = (size_t)col0 + col;
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
-    // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
-    // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
-    const int ltop = *W.ltop;
-    const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // uniform over the workgroup
-    for (int g = 0; g < ngroups; g++) {
-        const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;
-        Part2 su, sd, sq{0.0, 0.0};
-        if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
-        if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
-        if (idrv == 1) sq = W.gdp[go];
-        u = u + su.a; uc = uc + su.b;
-        d = d + sd.a; dc = dc + sd.b;
-        du = du + sq.a; duc = duc + sq.b;
+    if (on) {
+        // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
+        // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
+        const int ltop = *W.ltop;
+        const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // uniform over the wave
+        for (int g = 0; g < ngroups; g++) {
+            const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;
+            Part2 su, sd, sq{0.0, 0.0};
+            if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
+            if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
+            if (idrv == 1) sq = W.gdp[go];
+            u = u + su.a; uc = uc + su.b;
+            d = d + sd.a; dc = dc + sd.b;
+            du = du + sq.a; duc = duc + sq.b;
+        }
+        u = u * T.fluxfac; d = d * T.fluxfac;
+        if (clear_from_total) { uc = u; dc = d; duc = du; }
+        else { uc = uc * T.fluxfac; dc = dc * T.fluxfac; }
+        if (ty < FLUX_LV) {
+            const size_t o = gc + (size_t)nct * lev;
+            out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = uc; out.dflxc[o] = dc;
+            if (idrv == 1) { out.duflx_dt[o] = du; out.duflxc_dt[o] = duc; }
+            if (out.fnet) { out.fnet[o] = u - d; out.fnetc[o] = uc - dc; }
+        }
     }
-    const size_t o = gc + (size_t)nct * lev;
-    u = u * T.fluxfac; d = d * T.fluxfac;
-    if (clear_from_total) { uc = u; dc = d; duc = du; }
-    else { uc = uc * T.fluxfac; dc = dc * T.fluxfac; }
-    out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = uc; out.dflxc[o] = dc;
-    if (idrv == 1) { out.duflx_dt[o] = du; out.duflxc_dt[o] = duc; }
-    if (out.fnet) { out.fnet[o] = u - d; out.fnetc[o] = uc - dc; }
+    // net flux and heating rate of the layer above each level (rtrn :583-604; output copies src/rrtmg_lw_rad.nomcica.f90:563-583)
+    s_net[ty][tx] = u - d;
+    s_netc[ty][tx] = uc - dc;
+    __syncthreads();
+    if (on && ty < FLUX_LV && lev < nlay) {
+        const size_t lo = gc + (size_t)nct * lev, hi = lo + (size_t)nct;
+        const double dp = pz[lo] - pz[hi];
+        out.hr[lo] = T.heatfac * (s_net[ty][tx] - s_net[ty + 1][tx]) / dp;
+        out.hrc[lo] = T.heatfac * (s_netc[ty][tx] - s_netc[ty + 1][tx]) / dp;
+    }
 }
-
-__global__ __launch_bounds__(256) void k_rates(DevTables T, FluxOut out, const double *pz, int ncol, int col0, int nct)
-{
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncol) return;
-    const int l = blockIdx.y;                  // layer index 0 .. nlay-1 (htr(l) between levels l and l+1)
-    const size_t lo = (size_t)col0 + col + (size_t)nct * l, hi = lo + (size_t)nct;
-    const double fnet_lo = out.uflx[lo] - out.dflx[lo], fnet_hi = out.uflx[hi] - out.dflx[hi];
-    const double fnetc_lo = out.uflxc[lo] - out.dflxc[lo], fnetc_hi = out.uflxc[hi] - out.dflxc[hi];
-    const double dp = pz[lo] - pz[hi];
-    out.hr[lo] = T.heatfac * (fnet_lo - fnet_hi) / dp;
-    out.hrc[lo] = T.heatfac * (fnetc_lo - fnetc_hi) / dp;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // k_calibrate : reads n 16-byte words per array with 16 B per lane and writes them back (known byte counts),
