@@ -50,7 +50,7 @@ struct State {
     // McICA sub-column masks of all columns of the current call
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
-    int batch = 262144;     // columns per internal batch: ~0.2 MB of workspace per column at 72 layers (54 GB of the 288); measured per 1e6 cloudy columns (round 2): 131072: 80.6 ms, 262144: 78.4 ms, 524288: 78.2 ms
+    int batch = 262144;     // columns per internal batch: ~0.19 MB of workspace per column at 72 layers (50 GB of the 288); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
     bool split_sweep = false;    // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: k_sweep
                                  // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -1 %)
     bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device
