@@ -2007,7 +2007,7 @@ __host__ __device__ constexpr int sweepc_lds_bytes(int PHASE, bool IDRV, int nb,
 #endif
 __host__ __device__ constexpr int sweepc_nt(int NQ, int PHASE, bool IDRV)
 {
-    return (RRLW_SWEEPC_SPLIT && NQ == 4 && (PHASE == 2 || (PHASE == 0 && IDRV))) ? 2 : 1;
+    return (RRLW_SWEEPC_SPLIT && NQ == 4 && (PHASE == 2 || PHASE == 0)) ? 2 : 1;
 }
 // bands per group: what fits the wave slots of the most register-hungry instantiation (phase 2 with d/dT)
 __host__ __device__ constexpr int sweepc_group_cap(int NQ)
