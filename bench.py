@@ -55,8 +55,8 @@ def main():
                     help="McICA flavour (BASELINE configs[3]): sub-column generator with overlap ICLD (5 = exponential-random) "
                          "+ cldprmc + rtrnmc through the fused device entry; 0 = non-McICA rtrn/rtrnmr")
     ap.add_argument("--batch", type=int, default=0, help="columns per internal batch (0 = library default)")
-    ap.add_argument("--no-overlap", action="store_true", help="serialise k_layer and k_sweep of consecutive batches (the library default)")
-    ap.add_argument("--overlap", action="store_true", help="run k_sweep of batch i beside k_layer of batch i+1 (tuning; second scratch set)")
+    ap.add_argument("--no-overlap", action="store_true", help="serialise k_layer and the sweeps of consecutive batches (the library default)")
+    ap.add_argument("--overlap", action="store_true", help="run the sweeps of batch i beside k_layer of batch i+1 (tuning; second scratch set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols-per-core", type=int, default=6000)
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N > 1)")
@@ -278,7 +278,7 @@ def main():
             ktot = sum(v[1] for v in kern.values())                 # summed kernel milliseconds of the timed steps (this rank)
             pach = bpc * ncol * args.steps / (ktot * 1e-3) / 1e9
             # dominant kernel of the critical path: k_colprep / k_cloudscan / k_cloudlay run on the auxiliary stream underneath the previous
-            # batch's k_layer / k_sweep (driver.hip: run_pipelined) and are left out of the choice
+            # batch's k_layer / sweeps (driver.hip: run_pipelined) and are left out of the choice
             crit = {k: v for k, v in kern.items() if not (k.startswith("k_colprep") or k in ("k_cloudscan", "k_cloudlay"))} or kern
             dom = max(crit, key=lambda k: crit[k][1])
             cnt, tot = kern[dom]

@@ -37,7 +37,7 @@ struct State {
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
     struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *ltop; double2 *ovl; } prep[2] = {};
-    // the per-cell scratch written by k_layer and read by k_sweep exists twice as well: k_sweep/k_flux of batch i (HBM-bound)
+    // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
     hipStream_t aux = nullptr, sw = nullptr;
@@ -51,9 +51,9 @@ struct State {
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
     int batch = 262144;     // columns per internal batch: ~0.19 MB of workspace per column at 72 layers (50 GB of the 288); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
-    bool split_sweep = false;    // run k_sweep/k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: k_sweep
-                                 // owns a CU (transmittance table in LDS) and is instruction-bound, so the two do not share a CU (measured -1 %)
-    bool sweep_attrs = false;    // k_sweep's dynamic-LDS limit has been raised on this device
+    bool split_sweep = false;    // run the sweeps / k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: a sweep
+                                 // workgroup owns a CU (transmittance table in LDS), so the two do not share a CU (measured: 1-2 % gain for twice the code scratch)
+    bool sweep_attrs = false;    // the sweeps' dynamic-LDS limit has been raised on this device
     bool n1 = false;             // RRTMG_LW_N1=1: cloud-free calls take the north-star-mapping prototype k_n1 (measurement only)
     bool ws_two_scr = false;     // the workspace holds the second scratch set that split_sweep needs
     // host-entry staging

@@ -56,13 +56,13 @@ enum Field {
 };
 // per-column doubles, each [ncolb]
 enum PerCol { PC_PLANKBND = 0, PC_DPLANKBND = 16, PC_SECDIFF = 32, NPERCOL = 48 };
-// per-cell transmittance codes handed from k_layer to k_sweep, each [NQUAD][nlay][ncolb][4] (see cell_code):
+// per-cell transmittance codes handed from k_layer to the sweeps, each [NQUAD][nlay][ncolb][4] (see cell_code):
 // gas optical depth of every cell, total (gas + cloud) optical depth of the cells of cloudy layers
 enum Scr { S_CODE, S_CODET, NSCR };
 // per-band partial fluxes, each [band][level][column] of {total-sky, clear-sky}: downward, upward, d(upward)/dT
 struct alignas(16) Part2 { double a, b; };
 
-// storage type of the per-cell codes handed from k_layer to k_sweep (all arithmetic stays float64)
+// storage type of the per-cell codes handed from k_layer to the sweeps (all arithmetic stays float64)
 typedef float scr_t;
 
 struct Workspace {
@@ -76,8 +76,8 @@ struct Workspace {
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcldd (first cloudy level of a block, downward sweep), bit2 istcld (upward); cflag[0] bit3 = column has cloud
     double2 *ovl;       // rtrnmr's overlap factors of the cloudy levels: [2: down, up][nlay+1][3][ncolb] {facclr1, faccld1} {faccmb1, faccmb2} {facclr2, faccld2}
     int *ltop;          // [1] highest layer of the batch that holds cloud in any column (0: none): above it every sweep is the clear-sky one
-    double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at level ltop: 0 downward (k_sweepc<.,1> -> k_sweep), 1 / 2 upward
-                        // total / clear (k_sweep -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
+    double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at level ltop: 0 downward (k_sweepc<.,1> -> k_sweepz), 1 / 2 upward
+                        // total / clear (k_sweepz -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
     unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
     // k_sweepc's partials, summed over the bands of a GROUP (bands with the same number of quads, swept by one workgroup and added in
@@ -661,7 +661,7 @@ struct Rows {
     unsigned off[N > 0 ? N : 1];   // element offsets into the packed k-table buffer (row start, g = 0)
     double w[N > 0 ? N : 1];
     unsigned fw;                   // binary-key regions: Planck fractions are interpolated between rows js-1 and js of fracrefa/b with
-                                   // weight fs (taumol :556-561, :692-693); packed (js << 28) | fs in 28-bit fixed point for k_sweep
+                                   // weight fs (taumol :556-561, :692-693); packed (js << 28) | fs in 28-bit fixed point for the sweeps
 };
 
 // binary-key bands get a slot in Workspace::fw (every band whose upper region is binary-key has a binary-key lower region too)
@@ -1043,7 +1043,7 @@ struct LayerArgs {
 
 struct alignas(16) scr4 { scr_t v[4]; };
 
-// The per-cell codes are written once by k_layer and read twice (down and up sweep) by k_sweep, gigabytes later: streaming
+// The per-cell codes are written once by k_layer and read twice (down and up sweep) by k_sweepc / k_sweepz, gigabytes later: streaming
 // (non-temporal) stores here and loads there (bload_scr4_nt) keep them from evicting the absorption tables from L2.
 typedef float scr_vec __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &v)
@@ -1058,10 +1058,10 @@ __device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &
 // transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
 __device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * fdiv(od, bpade + od) + 0.5); }
 
-// What k_layer hands to k_sweep for one cell is the DECISION the reference takes on its optical depth (rtrn :372-451), in 4 bytes:
+// What k_layer hands to the sweeps for one cell is the DECISION the reference takes on its optical depth (rtrn :372-451), in 4 bytes:
 //   code >= 0 : the optical depth itself (<= 0.06, or odtot < 0.06) - the series branch: atrans = od - od^2/2, tfac = od/6
 //   code <  0 : -(index into the 1e-4-quantised transmittance / tfn tables), formed here in float64 exactly as the reference forms it
-// k_sweep turns the code back into (transmittance, tfn factor) and forms the Planck source terms in float64 itself.  Compared with
+// The sweep turns the code back into (transmittance, tfn factor) and forms the Planck source terms in float64 itself.  Compared with
 // storing {atrans, bbd, bbu} as three floats this is a third of the bytes, and the table index never depends on a rounded value.
 __device__ __forceinline__ scr_t cell_code(double od, bool series, double bpade)
 {
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
         C.f[F_WX3] = c.wx[xi + (size_t)nct * 2]; C.f[F_WX4] = c.wx[xi + (size_t)nct * 3];
     }
 
-    // (the Planck functions of setcoef :173-269 are formed by k_sweep, which needs them per band and level)
+    // (the Planck functions of setcoef :173-269 are formed by the sweeps, which need them per band and level)
     // pressure / temperature interpolation: setcoef :276-306
     const double plog = log(pavel);
     const int jp = clampi((int)(36. - 5 * (plog + 0.04)), 1, 58);
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
         const double tband = FROMMASK ? g.taucld[(B - 1) + (size_t)NBND * cl] : 0.0;
         if constexpr (FROMMASK) {
             // every cloudy cell of this band and layer carries the same values (src/mcica_subcol_gen_lw.f90:664-680): one
-            // optical depth / emissivity per band; k_layer<..,3,..> and k_sweep<4,..> combine them with the mask bits
+            // optical depth / emissivity per band; k_layer<..,3,..> and k_sweepz<.,4> combine them with the mask bits
             const unsigned long long lo = mw[g0 >> 5], hi = (g0 >> 5) < 4 ? mw[(g0 >> 5) + 1] : 0u;
             const unsigned bits = (unsigned)(((lo | (hi << 32)) >> (g0 & 31)) & ((1ull << ng) - 1ull));
             double t = tband, od = 0.0, ef = 0.0;
@@ -1961,8 +1961,8 @@ __device__ __forceinline__ void sweep_stage_band(const DevTables &T, double (*s_
 //            recurrences in flight.
 //   PHASE 0  the whole column of a cloud-free call (icld = 0): downward, surface (rtrn :476-495), upward
 //   PHASE 1  layers ltop+1 .. nlay downward, for the cloudy modes: above the highest cloud of the batch (W.ltop) every column is clear and
-//            the clear-sky stream equals the total one; the radiances at level ltop go to k_sweep<1..4> through W.hand
-//   PHASE 2  layers ltop+1 .. nlay upward, total and clear-sky streams, starting from the radiances k_sweep<1..4> left in W.hand
+//            the clear-sky stream equals the total one; the radiances at level ltop go to k_sweepz through W.hand
+//   PHASE 2  layers ltop+1 .. nlay upward, total and clear-sky streams, starting from the radiances k_sweepz left in W.hand
 // ------------------------------------------------------------------------------------------------
 // waves per SIMD each instantiation is compiled for = what its registers allow without spilling (a spilled register is reloaded with a
 // scratch load, which counts as a vector-memory operation: its wait drains every prefetch in flight), at most 4 (one workgroup of
@@ -2262,7 +2262,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
         if (incol && ty == 0) bstore_f64(gdn1 + (size_t)nlay * ncb, so8, 0.0);
         if (any_bin) sweep(true_type{}, true_type{}); else sweep(false_type{}, true_type{});
     }
-    if constexpr (PHASE == 1) {                     // downward radiances at level ltop for k_sweep<1..4>
+    if constexpr (PHASE == 1) {                     // downward radiances at level ltop for k_sweepz
         if (incol) {
 #pragma unroll
             for (int k = 0; k < G; k++) {
@@ -2291,7 +2291,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
         red_put(0, 0, usum);
         if constexpr (IDRV) red_put(0, 1, dusum);
         round_end(false_type{}, 0, 1);              // level 0
-    } else {                                        // upward radiances at level ltop from k_sweep<1..4>
+    } else {                                        // upward radiances at level ltop from k_sweepz
 #pragma unroll
         for (int k = 0; k < G; k++) {
             const double2 *h = hand + (size_t)k * ncb * 2;
@@ -2317,9 +2317,9 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
 //            issued on every path (the cloudy level's extra inputs - total-optical-depth codes, cloud fraction, overlap factors - are
 //            read for every level of the zone) so that the waits are counted ones, partials added over the group in LDS every two
 //            levels, ONE barrier per round.  A wave none of whose 64 columns is cloudy at a level runs the clear-sky body; otherwise
-//            both updates are formed and selected per lane (what divergence does anyway).  k_sweep<2, ., false> did the same work at
+//            both updates are formed and selected per lane (what divergence does anyway).  Its predecessor k_sweep (one workgroup per band, removed) did the same work at
 //            1.9x the time per clear level (per-quad duplication of the level's Planck terms, conditional loads with full waits, two
-//            barriers per four levels).  The other modes (rtrn, rtrnmc, d/dT) stay with k_sweep.
+//            barriers per four levels).
 // ------------------------------------------------------------------------------------------------
 #ifndef RRLW_SWEEPZ_G2
 #define RRLW_SWEEPZ_G2 0          // 1: two quads per thread for bands of 4 and 2 quads (253 registers, two waves per SIMD: measured slower)
@@ -2364,7 +2364,7 @@ __host__ __device__ constexpr int sweepz_group_cap(int NQ, bool IDRV)
 
 struct SweepzLev { double tl, tz, cf; unsigned w, flag; };
 
-// MODE as k_sweep's: 1 rtrn (random overlap), 2 rtrnmr, 3 rtrnmc with per-g-point arrays, 4 rtrnmc with the generator's sub-column mask
+// MODE: 1 rtrn (random overlap), 2 rtrnmr, 3 rtrnmc with per-g-point arrays, 4 rtrnmc with the generator's sub-column mask
 // IDRV: d(upward flux)/dT carried along (idrv = 1), src/rrtmg_lw_rtrnmr.f90:655-703 and its siblings
 template <int NQ, int MODE, bool IDRV = false>
 __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV)) void k_sweepz(DevTables T, Workspace W, SweepArgs a)
@@ -2599,7 +2599,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                         cldrad[j] = cr + mr;
                         clrrad[j] = lr - mr;
                         radmr[j] = mr;
-                    } else {                        // rtrn :372-435 / rtrnmc: the same explicit fused form as k_sweep (the array and the mask
+                    } else {                        // rtrn :372-435 / rtrnmc: the same explicit fused form in both flavours (the array and the mask
                         double cfj = cf, efj = efcl;    // flavour of rtrnmc must round identically)
                         if constexpr (MODE == 4) { const bool on = (gbits >> j) & 1u; cfj = on ? 1.0 : 0.0; efj = on ? efcl : 0.0; }
                         if constexpr (MODE == 3) {
