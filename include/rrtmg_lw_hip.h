@@ -88,7 +88,9 @@ int rrtmg_lw_hip_check(void *stream);
  * Arrays are column-fastest: pavel,tavel,coldry,wbrodl,cldfrac,ciwp,clwp,rei,rel (ncol,nlayers);
  * pz,tz (ncol,0:nlayers); tbound,pwvcm (ncol); semiss (ncol,16); wkl (ncol,7,nlayers); wx (ncol,4,nlayers);
  * tauc (ncol,16,nlayers); taua (ncol,nlayers,16); outputs (ncol,0:nlayers).
- * istart..iend select the bands (1..16); istart==16 switches band 16 to the 2600-3250 cm-1 Planck table
+ * istart..iend select the bands (1..16), any range (the reference's own sweeps support one band, iout > 0, or a range from band 1:
+ * with iout = 0 their g-point counter starts at 1 whatever istart is, src/rrtmg_lw_rtrn.f90:354-360); istart==16 switches band 16 to the
+ * 2600-3250 cm-1 Planck table
  * exactly as setcoef does (src/rrtmg_lw_setcoef.f90:233-252).  icld==1 -> rtrn, otherwise rtrnmr. */
 int rrtmg_lw_hip_run_columns(
     int ncol, int nlayers, int istart, int iend, int icld, int idrv,

@@ -1,0 +1,63 @@
+"""Seeded random sweep over shapes, modes and band ranges - the launch shapes of the group workgroups (k_sweepc / k_sweepz) depend on the
+number of bands in range, on idrv and on the mode, the batch size on the column count: every combination below goes through the C ABI and
+is compared with the oracle at the regression bar."""
+import os
+
+import numpy as np
+import pytest
+
+from rrtmg_lw_amd.io_rrtm import read_input_rrtm
+from rrtmg_lw_amd.synth import make_gcm_inputs
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _cases(seed, n):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        config = ("clear", "cloudy", "aer_idrv")[rng.integers(0, 3)]
+        out.append(dict(config=config, nlay=int(rng.integers(2, 141)), ncol=int(rng.integers(1, 700)),
+                        icld=int(rng.integers(0, 4)) if config != "clear" else int(rng.integers(0, 2)),
+                        idrv=int(rng.integers(0, 2)), batch=int((64, 128, 256, 4096)[rng.integers(0, 4)]), col0=int(rng.integers(0, 10 ** 6))))
+    return out
+
+
+@pytest.mark.parametrize("c", _cases(20260104, 28), ids=lambda c: "%(config)s-L%(nlay)d-n%(ncol)d-icld%(icld)d-idrv%(idrv)d-b%(batch)d" % c)
+def test_random_gcm_calls(hip, oracle, c):
+    d = make_gcm_inputs(c["ncol"], c["nlay"], c["config"], col0=c["col0"])
+    hip.set_batch(c["batch"])
+    try:
+        got = hip.rrtmg_lw_from_dict(d, icld=c["icld"], idrv=c["idrv"])
+    finally:
+        hip.set_batch(262144)
+    ref = oracle.rrtmg_lw(c["ncol"], c["nlay"], c["icld"], c["idrv"], d)
+    keys = ("uflx", "dflx", "uflxc", "dflxc") + (("duflx_dt", "duflxc_dt") if c["idrv"] else ())
+    dflux = max(np.abs(got[k] - ref[k]).max() for k in keys)
+    scale = max(np.abs(ref[k]).max() for k in ("uflx", "dflx"))
+    assert dflux <= max(5e-5, 2.5e-7 * scale), dflux
+    # heating rates: the bar relative to the layer's own rate where layers get very thin (a 140-layer profile reaches 1e-3 hPa layers)
+    for k in ("hr", "hrc"):
+        assert (np.abs(got[k] - ref[k]) <= 5e-5 + 1e-6 * np.abs(ref[k])).all(), k
+    assert got["icld"] == ref["icld"]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_band_ranges(hip, oracle, seed):
+    """Prepared-column entry with a random band range, cloud file and idrv: the groups hold only the bands in range."""
+    rng = np.random.default_rng(100 + seed)
+    # (what the reference's sweeps accept: one band with iout > 0, or a range that starts at band 1 - with iout = 0 its g-point counter
+    # starts at 1 whatever istart is, src/rrtmg_lw_rtrn.f90:354-360)
+    if rng.integers(0, 2):
+        a = b = int(rng.integers(1, 17))
+    else:
+        a, b = 1, int(rng.integers(1, 17))
+    cloudy = bool(rng.integers(0, 2))
+    col = read_input_rrtm(os.path.join(G, "input_rrtm_MLS-cld-imca0-icld2" if cloudy else ("input_rrtm_MLS-clr-idrv1", "input_rrtm_TROP-clr")[rng.integers(0, 2)]),
+                          os.path.join(G, ("in_cld_rrtm-cld5", "in_cld_rrtm-cld7")[rng.integers(0, 2)]) if cloudy else None)
+    icld = int(rng.integers(1, 3)) if cloudy else int(col["icld"])
+    got = hip.run_columns([col] * int(rng.integers(1, 70)), a, b, icld=icld)
+    ref = oracle.column(col, a, b, 99 if a == b else 0, icld=icld)
+    for k in ("totuflux", "totdflux", "totuclfl", "totdclfl", "htr", "htrc") + (("dtotuflux_dt",) if int(col["idrv"]) == 1 else ()):
+        assert np.abs(got[k] - ref[k][None, :]).max() <= 5e-5, (a, b, k)
