@@ -303,7 +303,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
 
 int ensure_mask(int nlay, size_t ncol)
 {
-    const size_t bytes = (size_t)5 * nlay * ncol * sizeof(unsigned);
+    const size_t bytes = (size_t)KJ_NWORD * nlay * ncol * sizeof(unsigned);
     if (G.mask_bytes < bytes) {
         if (G.mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.mask)); G.mask = nullptr; G.mask_bytes = 0; }
         HIP_TRY(hipMalloc((void **)&G.mask, bytes));
@@ -551,6 +551,14 @@ int ensure_pipeline()
 
 // all batches of a device-resident call on the caller's stream `s`, the per-column kernels of batch i+1 overlapping the
 // heavy kernels of batch i on the auxiliary stream (two prep sets)
+// Build switch: hold the sub-column generator of batch i+1 back until k_layer of batch i is done, so that it runs beside the sweeps
+// instead of beside k_layer.  Measured per 1e6 McICA columns: beside k_layer the generator takes 19.3 ms and k_layer 35.7 (26.7 alone,
+// both VALU-bound), beside the sweeps the generator takes its 12.9 ms and k_sweepc 29.1 instead of 19.9 (a sweep work-group needs most
+// of a CU's LDS and waits for the generator's work-groups to leave) - 77.5 vs 77.7 ms a step either way, also with the auxiliary stream
+// at the lowest priority.  The generator's 12.9 ms are added work, not hidden work.
+#ifndef RRLW_GEN_BESIDE_SWEEP
+#define RRLW_GEN_BESIDE_SWEEP 0
+#endif
 int launch_kiss(hipStream_t s, const Workspace &Wk, int ncol, int col0, int nb, int nlay, int icld, int permuteseed, const SubcolIn &in);
 
 struct KissGen { bool on; int icld, permuteseed; const double *alpha; };      // kissvec generator folded into the per-batch prep
@@ -576,8 +584,12 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         // them about what the overlap saves - measured per 1e6 columns: k_layer 32.7 ms beside them, 28.3 alone, step 93.9 vs 96.0 on one
         // stream; held back until k_layer is done they slow the sweep instead, 94.4, and the McICA generator then costs 7 ms more.)
         if (int rc = run_prep<true>(aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
-        if (gen.on)
+        if (gen.on) {
+#if RRLW_GEN_BESIDE_SWEEP
+            if (i >= 1 && !split) HIP_TRY(hipStreamWaitEvent(aux, G.ev_layer[(i - 1) & 1], 0));
+#endif
             if (int rc = launch_kiss(aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha})) return rc;
+        }
         HIP_TRY(hipEventRecord(G.ev_ready[k], aux));
         HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
         if (split) {
@@ -591,6 +603,9 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
             HIP_TRY(hipEventRecord(G.ev_done[k], G.sw));
         } else {
             if (int rc = run_layer<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc)) return rc;
+#if RRLW_GEN_BESIDE_SWEEP
+            if (gen.on) HIP_TRY(hipEventRecord(G.ev_layer[k], s));
+#endif
             if (int rc = run_sweep<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc)) return rc;
             HIP_TRY(hipEventRecord(G.ev_done[k], s));
         }
@@ -773,20 +788,99 @@ struct MT19937 {
     }
 };
 
+// ---- jump-ahead constants of the kissvec stream (KissJump, kernels.hip) ---------------------------------------------------------
+// n-fold composition of a -> 69069 a + 1327217885 (mod 2^32), by squaring
+void kiss_lcg_pow(unsigned long long n, unsigned &A, unsigned &B)
+{
+    unsigned a = 69069u, b = 1327217885u;
+    A = 1u; B = 0u;
+    for (; n; n >>= 1) {
+        if (n & 1ull) { A = a * A; B = a * B + b; }          // x -> a (A x + B) + b
+        b = a * b + b; a = a * a;
+    }
+}
+// the xorshift 13/17/5 step as a 32 x 32 matrix over GF(2), held as the images of the unit vectors; products and powers of it
+struct Gf2 { unsigned col[32]; };
+unsigned gf2_apply(const Gf2 &M, unsigned v) { unsigned r = 0u; for (int i = 0; i < 32; i++) if ((v >> i) & 1u) r ^= M.col[i]; return r; }
+Gf2 gf2_mul(const Gf2 &A, const Gf2 &B) { Gf2 C; for (int i = 0; i < 32; i++) C.col[i] = gf2_apply(A, B.col[i]); return C; }
+Gf2 kiss_xorshift_pow(unsigned long long n)
+{
+    Gf2 R, S;
+    for (int i = 0; i < 32; i++) {
+        R.col[i] = 1u << i;
+        unsigned b = 1u << i;
+        b ^= b << 13; b ^= b >> 17; b ^= b << 5;
+        S.col[i] = b;
+    }
+    for (; n; n >>= 1) { if (n & 1ull) R = gf2_mul(S, R); S = gf2_mul(S, S); }
+    return R;
+}
+unsigned kiss_modpow(unsigned base, unsigned long long n, unsigned m)
+{
+    unsigned long long r = 1ull, b = base % m;
+    for (; n; n >>= 1) { if (n & 1ull) r = r * b % m; b = b * b % m; }
+    return (unsigned)r;
+}
+KissJump kiss_jump_entry(unsigned long long n)
+{
+    KissJump J{};
+    J.n = (unsigned)std::min<unsigned long long>(n, 0xffffffffull);
+    kiss_lcg_pow(n, J.A, J.B);
+    const Gf2 X = kiss_xorshift_pow(n);
+    for (int i = 0; i < 32; i++) J.X[i] = X.col[i];
+    J.Pc = n >= 2 ? kiss_modpow(18000u, n - 2, KISS_MC) : 1u;
+    J.Pd = n >= 2 ? kiss_modpow(30903u, n - 2, KISS_MD) : 1u;
+    return J;
+}
+// the table of one (draws per sub-column, permuteseed) pair: entries 0 .. KJ_NGROUP-1 jump from the seed to sub-column 8 g, the last one
+// by one sub-column.  Kept per stream slot so that concurrent calls do not share it.
+struct KissTable { unsigned long long stride = 0; long long seed = -1; KissJump host[KJ_NGROUP + 1]; KissJump *dev = nullptr; };
+KissTable g_kiss_table;
+
+int kiss_table(hipStream_t s, int stride, int permuteseed, const KissJump **dev, KissJump *jsub)
+{
+    KissTable &T = g_kiss_table;
+    const long long seed = std::max(permuteseed, 0);
+    if (!T.dev) HIP_TRY(hipMalloc((void **)&T.dev, sizeof(T.host)));
+    if (T.stride != (unsigned long long)stride || T.seed != seed) {
+        // an earlier launch on another stream may still be reading the table
+        HIP_TRY(hipDeviceSynchronize());
+        for (int g = 0; g < KJ_NGROUP; g++) T.host[g] = kiss_jump_entry((unsigned long long)seed + 8ull * g * (unsigned long long)stride);
+        T.host[KJ_NGROUP] = kiss_jump_entry((unsigned long long)stride);
+        T.stride = (unsigned long long)stride; T.seed = seed;
+        HIP_TRY(hipMemcpy(T.dev, T.host, sizeof(T.host), hipMemcpyHostToDevice));
+    }
+    (void)s;
+    *dev = T.dev;
+    *jsub = T.host[KJ_NGROUP];
+    return 0;
+}
+
+template <int RULE>
+void launch_kiss_rule(hipStream_t s, const Workspace &Wk, const SubcolIn &in, const KissJump *jt, const KissJump &jsub, int ncol, int col0, int nb, int nlay)
+{
+    const size_t lds = (size_t)nlay * KJ_COLS * sizeof(int4);
+    const dim3 grid((nb + KJ_COLS - 1) / KJ_COLS), block(KJ_BLOCK);
+    hipLaunchKernelGGL(k_subcol_kiss<RULE>, grid, block, lds, s, Wk, in, jt, jsub, ncol, col0, nb, nlay);
+}
+
 // kissvec masks of columns col0 .. col0+nb-1 (of ncol) on stream s; G.W.mask must be set up (prepare_mask)
 int launch_kiss(hipStream_t s, const Workspace &Wk, int ncol, int col0, int nb, int nlay, int icld, int permuteseed, const SubcolIn &in)
 {
-    const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned short);
-    const dim3 grid((nb + SUBCOL_BLOCK - 1) / SUBCOL_BLOCK), block(SUBCOL_BLOCK);
-    if (G.profile) {
-        State::ProfRec r{"k_subcol_kiss", get_event(), get_event()};
-        (void)hipEventRecord(r.a, s);
-        hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, Wk, in, ncol, col0, nb, nlay, icld, permuteseed);
-        (void)hipEventRecord(r.b, s);
-        G.prof.push_back(r);
-    } else {
-        hipLaunchKernelGGL(k_subcol_kiss, grid, block, lds, s, Wk, in, ncol, col0, nb, nlay, icld, permuteseed);
+    if (icld < 1 || icld > 5) return fail(RRTMG_LW_HIP_EARG, "the sub-column generator needs icld 1..5");
+    const int stride = icld == 3 ? 1 : ((icld == 4 || icld == 5) ? 2 * nlay : nlay);    // draws per sub-column (:475-530)
+    const KissJump *jt = nullptr;
+    KissJump jsub;
+    if (int rc = kiss_table(s, stride, permuteseed, &jt, &jsub)) return rc;
+    State::ProfRec r{"k_subcol_kiss", nullptr, nullptr};
+    if (G.profile) { r.a = get_event(); r.b = get_event(); (void)hipEventRecord(r.a, s); }
+    switch (icld) {
+    case 1: launch_kiss_rule<1>(s, Wk, in, jt, jsub, ncol, col0, nb, nlay); break;
+    case 2: launch_kiss_rule<2>(s, Wk, in, jt, jsub, ncol, col0, nb, nlay); break;
+    case 3: launch_kiss_rule<3>(s, Wk, in, jt, jsub, ncol, col0, nb, nlay); break;
+    default: launch_kiss_rule<4>(s, Wk, in, jt, jsub, ncol, col0, nb, nlay); break;
     }
+    if (G.profile) { (void)hipEventRecord(r.b, s); G.prof.push_back(r); }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "k_subcol_kiss launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -803,10 +897,14 @@ int prepare_mask(int ncol, int nlay, int icld, int irng, const double *alpha)
     G.W.mask_col0 = 0;
     G.W.err = G.d_err;
     if (irng == 0) {
-        const size_t lds = (size_t)nlay * SUBCOL_BLOCK * sizeof(unsigned short);
+        const size_t lds = (size_t)nlay * KJ_COLS * sizeof(int4);
         if (lds > 160 * 1024) return fail(RRTMG_LW_HIP_EARG, "nlay=%d exceeds the generator's LDS budget", nlay);
-        if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 48 * 1024) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
     }
     return 0;
 }
@@ -823,7 +921,7 @@ int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, 
         if (int rc = launch_kiss(s, G.W, ncol, 0, ncol, nlay, icld, permuteseed, in)) return rc;
     } else {
         // one stream over (sub-column, column, layer): drawn here, applied per sub-column slab on the device
-        HIP_TRY(hipMemsetAsync(G.mask, 0, (size_t)5 * nlay * ncol * sizeof(unsigned), s));
+        HIP_TRY(hipMemsetAsync(G.mask, 0, (size_t)KJ_NWORD * nlay * ncol * sizeof(unsigned), s));
         const int nd = (icld == 4 || icld == 5) ? 2 : 1;
         const size_t per = icld == 3 ? (size_t)ncol : (size_t)ncol * nlay * nd;
         std::vector<double> buf(per);
@@ -922,6 +1020,7 @@ void rrtmg_lw_hip_finalize(void)
     if (Q.pinned) { (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
     Q.chunks.clear(); Q.ncol = 0; Q.open = false;
     if (G.mask) (void)hipFree(G.mask);
+    if (g_kiss_table.dev) { (void)hipFree(g_kiss_table.dev); g_kiss_table = KissTable{}; }
     if (G.d_ktab) (void)hipFree(G.d_ktab);
     if (G.d_stat) (void)hipFree(G.d_stat);
     if (G.d_err) (void)hipFree(G.d_err);

@@ -1588,8 +1588,8 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
 // The GCM routine does not compile as shipped; the per-column semantics are those of its
 // compilable one-column statement, src/mcica_subcol_gen_lw.1col.f90:171-710.
 //   k_subcol_kiss  irng = 0: every column owns a KISS stream seeded from its four lowest layer pressures
-//                  (:460-474) and consumed in (sub-column, layer) order -> one thread per column, the 140 x nlay
-//                  decisions are accumulated as bit masks in LDS and written out coalesced.
+//                  (:460-474) and consumed in (sub-column, layer) order -> a thread per (column, 8 sub-columns), each
+//                  sub-column's stream reached by jump-ahead; the decisions leave as bytes of the bit mask.
 //   k_subcol_slab  irng = 1: the Mersenne-Twister stream is ONE sequence over (sub-column, column, layer)
 //                  (:497-503); the host draws it (driver.hip) and this kernel applies the overlap rules to
 //                  the slab of one sub-column.
@@ -1602,16 +1602,93 @@ struct SubcolIn { const double *play, *cldfrac, *alpha; };      // each (ncol_to
 
 struct Kiss { unsigned a, b, c, d; };
 
-__device__ __forceinline__ double kiss_next(Kiss &s)           // kissvec, src/mcica_subcol_gen_lw.f90:711-745
+// multiplier x (low half of s) + (high half of s): one v_mad_u32_u16, which reads the low halves of its factors (the compiler
+// masks the half out first and multiplies with v_mad_u32_u24)
+__device__ __forceinline__ unsigned kiss_mwc(unsigned s, unsigned mul)
+{
+    unsigned r;
+    const unsigned carry = s >> 16;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(s), "s"(mul), "v"(carry));
+    return r;
+}
+// 69069 a + 1327217885 (mod 2^32) from 24-bit multiplies, which run at full rate where the 32-bit v_mul_lo_u32 takes four issue
+// slots: 69069 x (low 24 bits of a) + the constant, plus (0xCD = 69069 mod 256) x (top byte of a) shifted to the top byte
+__device__ __forceinline__ unsigned kiss_lcg(unsigned a)
+{
+    unsigned h;
+    const unsigned top = a >> 24;
+    asm("v_mul_u32_u24_e32 %0, 0xcd, %1" : "=v"(h) : "v"(top));
+    return (h << 24) + (__umul24(a, 69069u) + 1327217885u);
+}
+__device__ __forceinline__ void kiss_step(Kiss &s)             // kissvec's state advance, src/mcica_subcol_gen_lw.f90:711-745
+{
+    s.a = kiss_lcg(s.a);
+    s.b ^= s.b << 13; s.b ^= s.b >> 17; s.b ^= s.b << 5;
+    s.c = kiss_mwc(s.c, 18000u);
+    s.d = kiss_mwc(s.d, 30903u);
+}
+__device__ __forceinline__ int kiss_int(Kiss &s)               // ... the integer it returns
+{
+    kiss_step(s);
+    return (int)(s.a + s.b + (s.c << 16) + s.d);
+}
+__device__ __forceinline__ double kiss_unit(int k)             // ... and the deviate the reference forms from it
 {
 #pragma clang fp contract(off)
-    s.a = 69069u * s.a + 1327217885u;
-    s.b ^= s.b << 13; s.b ^= s.b >> 17; s.b ^= s.b << 5;
-    s.c = 18000u * (s.c & 65535u) + (s.c >> 16);
-    s.d = 30903u * (s.d & 65535u) + (s.d >> 16);
-    const unsigned k = s.a + s.b + (s.c << 16) + s.d;
-    const double r = (double)(int)k * 2.328306e-10;
+    const double r = (double)k * 2.328306e-10;
     return r + 0.5;
+}
+__device__ __forceinline__ double kiss_next(Kiss &s) { return kiss_unit(kiss_int(s)); }
+
+// kiss_unit is strictly increasing in k (one step of k is 2.3e-10, an ulp of the sum at most 1.1e-16), so a comparison of a deviate
+// with a value v that does not depend on other deviates is a comparison of the integers: kiss_unit(k) >= v  <=>  k >= T(v) with
+// T(v) the smallest such k.  T = INT_MIN when every k qualifies, INT_MAX + 1 when none does (v = NaN included).
+__device__ __forceinline__ long long kiss_threshold(double v)
+{
+#pragma clang fp contract(off)
+    constexpr long long LO = -2147483648ll, HI = 2147483647ll;
+    if (!(kiss_unit((int)HI) >= v)) return HI + 1;
+    if (kiss_unit((int)LO) >= v) return LO;
+    double g = (v - 0.5) / 2.328306e-10;                        // within a step or two of the answer, which lies in (LO, HI]
+    g = g < -2147483647. ? -2147483647. : (g > 2147483647. ? 2147483647. : g);
+    long long t = (long long)g;
+    for (int it = 0; it < 64 && t > LO + 1 && kiss_unit((int)(t - 1)) >= v; it++) t--;
+    for (int it = 0; it < 64 && t < HI && !(kiss_unit((int)t) >= v); it++) t++;
+    return t;
+}
+
+// Jump-ahead of the stream by n draws.  The four component generators are each a linear map of their own state:
+//   a  (congruential, mod 2^32)      a -> A a + B with (A, B) the n-fold composition;
+//   b  (xorshift 13/17/5)            linear over GF(2): the images X[i] of the 32 unit vectors under n steps;
+//   c, d (multiply-with-carry, multipliers 18000 / 30903, base 2^16)   the 32-bit word s = carry 2^16 + value satisfies
+//        2^16 s' = s (mod m), m = multiplier 2^16 - 1, i.e. s' = multiplier s (mod m).  Two real steps bring any 32-bit word into
+//        [0, m]; 0 and m are fixed points and every other word stays in [1, m-1], where the residue names the word.  So n >= 2 steps
+//        are two steps and a multiplication by P = multiplier^(n-2) mod m.
+// The host fills the constants (driver.hip, kiss_jump_entry).
+struct KissJump { unsigned n, A, B, Pc, Pd, pad[3]; unsigned X[32]; };
+constexpr unsigned KISS_MC = 18000u * 65536u - 1u, KISS_MD = 30903u * 65536u - 1u;
+
+template <unsigned M>
+__device__ __forceinline__ unsigned kiss_mwc_mul(unsigned s, unsigned P)
+{
+    const unsigned r = (unsigned)(((unsigned long long)s * (unsigned long long)P) % (unsigned long long)M);
+    return s == M ? M : r;
+}
+__device__ __forceinline__ void kiss_jump(Kiss &s, const KissJump &J)
+{
+    if (J.n < 2u) { if (J.n == 1u) kiss_step(s); return; }
+    s.a = J.A * s.a + J.B;
+    unsigned b = 0u;
+#pragma unroll
+    for (int i = 0; i < 32; i++) b ^= (0u - ((s.b >> i) & 1u)) & J.X[i];
+    s.b = b;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        s.c = 18000u * (s.c & 65535u) + (s.c >> 16);
+        s.d = 30903u * (s.d & 65535u) + (s.d >> 16);
+    }
+    s.c = kiss_mwc_mul<KISS_MC>(s.c, J.Pc);
+    s.d = kiss_mwc_mul<KISS_MD>(s.d, J.Pd);
 }
 
 // overlap rule applied to the deviate of (sub-column, layer l) given the final deviate of layer l-1
@@ -1630,73 +1707,113 @@ __device__ __forceinline__ double overlap_rule(int icld, int l, double x, double
     return x;
 }
 
-constexpr int SUBCOL_BLOCK = 64;
+// k_subcol_kiss: a work-group is KJ_COLS columns x all sub-columns; a thread owns 8 consecutive sub-columns of one column (one byte
+// of the mask) and walks the layers once, with the eight streams side by side: each was brought to its place in the column's stream
+// by jump-ahead (the reference draws sub-column after sub-column, layer after layer - :475-530 - so sub-column s starts
+// permuteseed + s x (draws per sub-column) draws into the stream).  What a decision is compared with depends on (column, layer)
+// only: the work-group forms those values once, into LDS, as integer thresholds where the rule allows it (random, maximum,
+// exponential: 1, 3, 4/5) and as 1 - cldfrac for the maximum-random rule, whose deviates are rescaled in floating point.
+// Lanes 4 c .. 4 c + 3 of a wave hold the four bytes of one column's mask word and neighbouring columns follow, so one byte
+// store per layer writes 64 contiguous bytes.  (The first version - a thread per column walking its 140 x nlay decisions in stream
+// order with cldfrac / alpha re-read for every sub-column - moved 161 GB per 1e6 columns through HBM: 73 KB per wave of re-read
+// working set, sixteen waves a CU, against 128 KB of L2 a CU.)
+constexpr int KJ_COLS = 16;
+constexpr int KJ_NWORD = (NGPT + 31) / 32;          // mask words of a column = waves of a work-group
+constexpr int KJ_BLOCK = 64 * KJ_NWORD;
+constexpr int KJ_NGROUP = 4 * KJ_NWORD;             // 8-sub-column groups, the last ones possibly short or empty
 
-// columns col0 .. col0 + nb - 1 of the call's ncol columns (ncol is the column stride of the inputs and of the mask)
-__global__ __launch_bounds__(SUBCOL_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn in, int ncol, int col0, int nb, int nlay, int icld, int permuteseed)
+// RULE 1 random, 2 maximum-random, 3 maximum, 4 exponential / exponential-random (icld 4 and 5 differ in alpha only).
+// jt[g]: jump from the seed to the first sub-column of group g; jsub: jump by one sub-column.
+template <int RULE>
+__global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn in, const KissJump *jt, KissJump jsub, int ncol, int col0, int nb, int nlay)
 {
 #pragma clang fp contract(off)
-    // the masks of 16 sub-columns at a time, [nlay][SUBCOL_BLOCK] halfwords: 9 KB per wave at 72 layers (32 sub-columns in words took
-    // 18 KB and left two waves per SIMD for a kernel that is one dependent integer chain per lane)
-    extern __shared__ unsigned short acc[];
+    extern __shared__ int4 kj_thr[];                             // [nlay][KJ_COLS]
     const int tid = threadIdx.x;
-    if (blockIdx.x * SUBCOL_BLOCK + tid >= nb) return;
-    const size_t gc = (size_t)col0 + (size_t)blockIdx.x * SUBCOL_BLOCK + tid;
+    const int cl = (tid >> 2) & (KJ_COLS - 1);
+    const int g = (tid >> 6) * 4 + (tid & 3);                    // sub-columns 8 g .. 8 g + 7 = byte g & 3 of mask word g >> 2
+    const int cb = blockIdx.x * KJ_COLS;
     const double cldmin = 1.0e-20;
-    Kiss s;
+    for (int e = tid; e < nlay * KJ_COLS; e += KJ_BLOCK) {
+        const int c = e & (KJ_COLS - 1), l = e / KJ_COLS;
+        int4 t = make_int4(0, (int)0x80000000, 0, 0);
+        if (cb + c < nb) {
+            const size_t cell = (size_t)col0 + (size_t)(cb + c) + (size_t)ncol * l;
+            double cf = in.cldfrac[cell];
+            if (cf < cldmin) cf = 0.0;
+            const double v = 1. - cf;                            // cloudy: deviate >= v (:655-661)
+            if (RULE == 2) {
+                t.x = __double2loint(v); t.y = __double2hiint(v);
+            } else {
+                const long long T = kiss_threshold(v);
+                t.x = T > 2147483647ll ? 2147483647 : (int)T;
+                t.w = T > 2147483647ll ? 0 : 0xff;               // no integer reaches v: the byte is cleared after the compare
+                if (RULE == 4 && l > 0) {                        // deviate2 < alpha keeps the deviate of the layer below (:492-496)
+                    const double al = in.alpha[cell];
+                    const long long Ta = al != al ? -2147483648ll : kiss_threshold(al);
+                    t.y = Ta > 2147483647ll ? 2147483647 : (int)Ta;
+                    t.z = Ta > 2147483647ll ? 1 : 0;             // every integer is below alpha
+                }
+            }
+        }
+        kj_thr[e] = t;
+    }
+    __syncthreads();
+    if (cb + cl >= nb) return;
+    const size_t gc = (size_t)col0 + (size_t)(cb + cl);
+    Kiss s[8];
     {
         const double p1 = in.play[gc] * 1.e2, p2 = in.play[gc + (size_t)ncol] * 1.e2;
         const double p3 = in.play[gc + (size_t)ncol * 2] * 1.e2, p4 = in.play[gc + (size_t)ncol * 3] * 1.e2;
         if (p1 < p2) { atomicCAS(W.err, 0, (int)E_KISS_PMID); return; }            // :463-466
-        s.a = (unsigned)(int)((p1 - (double)(long long)p1) * 1000000000.);
-        s.b = (unsigned)(int)((p2 - (double)(long long)p2) * 1000000000.);
-        s.c = (unsigned)(int)((p3 - (double)(long long)p3) * 1000000000.);
-        s.d = (unsigned)(int)((p4 - (double)(long long)p4) * 1000000000.);
+        s[0].a = (unsigned)(int)((p1 - (double)(long long)p1) * 1000000000.);
+        s[0].b = (unsigned)(int)((p2 - (double)(long long)p2) * 1000000000.);
+        s[0].c = (unsigned)(int)((p3 - (double)(long long)p3) * 1000000000.);
+        s[0].d = (unsigned)(int)((p4 - (double)(long long)p4) * 1000000000.);
     }
-    for (int q = 0; q < permuteseed; q++) (void)kiss_next(s);                       // :471-474
-    const bool two = icld == 4 || icld == 5;
-#pragma unroll 1
-    for (int w = 0; w < (NGPT + 15) / 16; w++) {
-        for (int l = 0; l < nlay; l++) acc[l * SUBCOL_BLOCK + tid] = (unsigned short)0;
-        const int nb = min(16, NGPT - 16 * w);
-#pragma unroll 1
-        for (int k = 0; k < nb; k++) {
-            double r3 = 0.0;
-            if (icld == 3) r3 = kiss_next(s);
-            double prev = 0.0, cf_below = 0.0;
-            // layers in chunks of 8: the chunk's cloud fractions / overlap parameters are loaded together (independent of the
-            // serial random stream), then the eight dependent steps run from registers
-#pragma unroll 1
-            for (int l0 = 0; l0 < nlay; l0 += 8) {
-                double cfc[8], alc[8];
+    // sub-columns past NGPT in the last word: their streams run along (no divergence in the loop below), their bits are cleared
+    const int nv = min(8, max(0, NGPT - 8 * g));
+    const unsigned live = (1u << nv) - 1u;
+    kiss_jump(s[0], jt[g]);
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int l = l0 + i < nlay ? l0 + i : nlay - 1;
-                    cfc[i] = in.cldfrac[gc + (size_t)ncol * l];
-                    alc[i] = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
-                }
+    for (int j = 1; j < 8; j++) { s[j] = s[j - 1]; kiss_jump(s[j], jsub); }
+    unsigned char *out = reinterpret_cast<unsigned char *>(W.mask + ((size_t)(g >> 2) * nlay) * W.mask_stride + gc) + (g & 3);
+    const size_t ostep = W.mask_stride * sizeof(unsigned);
+    int kx[8];
+    double px[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int l = l0 + i;
-                    if (l < nlay) {
-                        double x, x2 = 0.0;
-                        if (icld == 3) x = r3;
-                        else { x = kiss_next(s); if (two) x2 = kiss_next(s); }
-                        double cf = cfc[i];
-                        if (cf < cldmin) cf = 0.0;
-                        x = overlap_rule(icld, l, x, x2, prev, cf_below, alc[i]);
-                        prev = x; cf_below = cf;
-                        if (x >= 1. - cf) acc[l * SUBCOL_BLOCK + tid] |= (unsigned short)(1u << k);    // :655-661
-                    }
-                }
+    for (int j = 0; j < 8; j++) { kx[j] = RULE == 3 ? kiss_int(s[j]) : 0; px[j] = 0.0; }
+    double one_m = 1.0;
+    int4 t = kj_thr[cl];
+#pragma unroll 1
+    for (int l = 0; l < nlay; l++) {
+        const int4 tn = kj_thr[min(l + 1, nlay - 1) * KJ_COLS + cl];
+        unsigned bits = 0u;
+        if (RULE == 2) {                                         // maximum-random, .1col :440-448
+            const double v = __hiloint2double(t.y, t.x);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                double x = kiss_next(s[j]);
+                if (l > 0) x = px[j] > one_m ? px[j] : x * one_m;
+                px[j] = x;
+                bits |= x >= v ? 1u << j : 0u;
             }
+            one_m = v;
+        } else {
+            const bool below = t.z != 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (RULE == 1) kx[j] = kiss_int(s[j]);
+                if (RULE == 4) {
+                    const int k = kiss_int(s[j]), k2 = kiss_int(s[j]);
+                    kx[j] = ((k2 < t.y) | below) ? kx[j] : k;
+                }
+                bits |= kx[j] >= t.x ? 1u << j : 0u;
+            }
+            bits &= (unsigned)t.w;
         }
-        // halfword (w & 1) of mask word w / 2 (little endian: sub-column 16 w + k = bit 16 (w & 1) + k)
-        for (int l = 0; l < nlay; l++) {
-            unsigned short *m = reinterpret_cast<unsigned short *>(&W.mask[((size_t)(w >> 1) * nlay + l) * W.mask_stride + gc]);
-            m[w & 1] = acc[l * SUBCOL_BLOCK + tid];
-            if (w == (NGPT + 15) / 16 - 1 && (w & 1) == 0) m[1] = (unsigned short)0;        // (the unused upper half of the last word)
-        }
+        out[(size_t)l * ostep] = (unsigned char)(bits & live);
+        t = tn;
     }
 }
 

@@ -66,6 +66,28 @@ def test_subcolumn_generator_is_bit_exact(hip, oracle, icld, irng):
         assert got["irng"] == ref["irng"]
 
 
+@pytest.mark.parametrize("icld", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("ncol,nlay,permuteseed", [(37, 4, 0), (21, 72, 1), (16, 9, 2), (53, 137, 7 * 140)])
+def test_subcolumn_generator_edge_values(hip, oracle, icld, ncol, nlay, permuteseed):
+    """The kissvec kernel reaches every sub-column's place in the column's stream by jump-ahead and compares integers with
+    thresholds instead of deviates with 1 - cldfrac / alpha: cloud fractions and overlap parameters at and next to the ends of the
+    deviates' range (0, below cldmin, 5e-8, 1 - 5e-8, 1; alpha 0, 1e-9, 0.99999995, 1), seeds 0 / 1 / 2 (sequential start of the
+    jump), column counts that do not fill a work-group, the shortest column the generator accepts."""
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=5)
+    rng = np.random.default_rng(100 * icld + nlay)
+    special = np.array([0.0, 1e-21, 5e-8, 9.3e-8, 1.1e-7, 0.3, 0.5, 1 - 1.1e-7, 1 - 9.3e-8, 1 - 5e-8, 1.0])
+    cf = np.where(rng.random((ncol, nlay)) < 0.6, special[rng.integers(0, special.size, (ncol, nlay))], rng.random((ncol, nlay)))
+    d["cldfr"] = np.asfortranarray(cf)
+    aspecial = np.array([0.0, 1e-9, 9.3e-8, 0.2, 0.9, 1 - 1.1e-7, 0.99999995, 1 - 1e-9, 1.0])
+    alpha = np.where(rng.random((ncol, nlay)) < 0.6, aspecial[rng.integers(0, aspecial.size, (ncol, nlay))], rng.random((ncol, nlay)))
+    alpha = np.asfortranarray(alpha)
+    got = hip.mcica_subcol_lw(ncol, nlay, icld, permuteseed, 0, *_gen_args(d), alpha)
+    ref = oracle.mcica_subcol(ncol, nlay, icld, permuteseed, 0, *_gen_args(d), alpha)
+    assert 0.05 < ref["cldfmcl"].mean() < 0.95
+    for k in SUB:
+        assert np.array_equal(got[k], ref[k]), (k, icld, ncol, nlay, permuteseed)
+
+
 def test_subcolumn_generator_flags(hip, oracle):
     ncol, nlay = 64, 33
     d = make_gcm_inputs(ncol, nlay, "cloudy")
