@@ -35,6 +35,15 @@ for cfg in clear; do
   python3 tools/pmc_summarize.py $Q --md $O/pmc_$cfg.md > $Q/summarize.log 2>&1
 done
 echo "pmc clear done"
+# McICA shape (generator + cldprmc + rtrnmc): HBM bytes and the instruction counters
+Q=$O/pmc_mcica; mkdir -p $Q
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $Q/fetch -f csv -- python3 tools/pmc_run.py --mcica 5 > $Q/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $Q/write -f csv -- python3 tools/pmc_run.py --mcica 5 > $Q/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $Q/sq1 -f csv -- python3 tools/pmc_run.py --mcica 5 > $Q/sq1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $Q/sq2 -f csv -- python3 tools/pmc_run.py --mcica 5 > $Q/sq2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --kernel-trace -d $Q/sq3 -f csv -- python3 tools/pmc_run.py --mcica 5 > $Q/sq3.log 2>&1
+python3 tools/pmc_summarize.py $Q --md $O/pmc_mcica.md > $Q/summarize.log 2>&1
+echo "pmc mcica done"
 # keep what is merged back small: the raw counter CSVs are large
 find $O -name "*counter_collection.csv" -size +4M -delete
 ls $O | head -40
