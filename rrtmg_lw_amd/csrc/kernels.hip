@@ -1729,7 +1729,11 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
 {
 #pragma clang fp contract(off)
     extern __shared__ int4 kj_thr[];                             // [nlay][KJ_COLS]
+    __shared__ int kj_top;                                       // highest layer with cloud in any of the work-group's columns
     const int tid = threadIdx.x;
+    if (tid == 0) kj_top = -1;
+    __syncthreads();
+    int top = -1;
     const int cl = (tid >> 2) & (KJ_COLS - 1);
     const int g = (tid >> 6) * 4 + (tid & 3);                    // sub-columns 8 g .. 8 g + 7 = byte g & 3 of mask word g >> 2
     const int cb = blockIdx.x * KJ_COLS;
@@ -1741,6 +1745,7 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
             const size_t cell = (size_t)col0 + (size_t)(cb + c) + (size_t)ncol * l;
             double cf = in.cldfrac[cell];
             if (cf < cldmin) cf = 0.0;
+            if (cf > 0.0) top = l;                               // (e ascends with l)
             const double v = 1. - cf;                            // cloudy: deviate >= v (:655-661)
             if (RULE == 2) {
                 t.x = __double2loint(v); t.y = __double2hiint(v);
@@ -1758,7 +1763,11 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
         }
         kj_thr[e] = t;
     }
+    if (top >= 0) atomicMax(&kj_top, top);
     __syncthreads();
+    // Every sub-column's stream is positioned on its own, so nothing depends on the draws of the layers above the highest cloud:
+    // no deviate reaches 1 - 0 there and the walk ends at `ltop` (the stratosphere of every column, most of the troposphere of many).
+    const int ltop = kj_top;
     if (cb + cl >= nb) return;
     const size_t gc = (size_t)col0 + (size_t)(cb + cl);
     Kiss s[8];
@@ -1774,11 +1783,15 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
     // sub-columns past NGPT in the last word: their streams run along (no divergence in the loop below), their bits are cleared
     const int nv = min(8, max(0, NGPT - 8 * g));
     const unsigned live = (1u << nv) - 1u;
+    unsigned char *out = reinterpret_cast<unsigned char *>(W.mask + ((size_t)(g >> 2) * nlay) * W.mask_stride + gc) + (g & 3);
+    const size_t ostep = W.mask_stride * sizeof(unsigned);
+    if (ltop < 0) {                                              // sixteen cloud-free columns
+        for (int l = 0; l < nlay; l++) out[(size_t)l * ostep] = (unsigned char)0;
+        return;
+    }
     kiss_jump(s[0], jt[g]);
 #pragma unroll
     for (int j = 1; j < 8; j++) { s[j] = s[j - 1]; kiss_jump(s[j], jsub); }
-    unsigned char *out = reinterpret_cast<unsigned char *>(W.mask + ((size_t)(g >> 2) * nlay) * W.mask_stride + gc) + (g & 3);
-    const size_t ostep = W.mask_stride * sizeof(unsigned);
     int kx[8];
     double px[8];
 #pragma unroll
@@ -1786,7 +1799,7 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
     double one_m = 1.0;
     int4 t = kj_thr[cl];
 #pragma unroll 1
-    for (int l = 0; l < nlay; l++) {
+    for (int l = 0; l <= ltop; l++) {
         const int4 tn = kj_thr[min(l + 1, nlay - 1) * KJ_COLS + cl];
         unsigned bits = 0u;
         if (RULE == 2) {                                         // maximum-random, .1col :440-448
@@ -1815,6 +1828,7 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
         out[(size_t)l * ostep] = (unsigned char)(bits & live);
         t = tn;
     }
+    for (int l = ltop + 1; l < nlay; l++) out[(size_t)l * ostep] = (unsigned char)0;
 }
 
 // rnd: the deviates of sub-column `isub` for all columns in stream order: icld == 3: [ncol]; otherwise
