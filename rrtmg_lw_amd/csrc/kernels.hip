@@ -1738,14 +1738,23 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
     const int g = (tid >> 6) * 4 + (tid & 3);                    // sub-columns 8 g .. 8 g + 7 = byte g & 3 of mask word g >> 2
     const int cb = blockIdx.x * KJ_COLS;
     const double cldmin = 1.0e-20;
+    // pass 1: the highest layer with cloud in any of the work-group's columns.  Every sub-column's stream is positioned on its own, so
+    // nothing depends on the draws of the layers above it: no deviate reaches 1 - 0 there, the walk ends at `ltop` (the stratosphere
+    // of every column, most of the troposphere of many) and thresholds are formed up to it only.
     for (int e = tid; e < nlay * KJ_COLS; e += KJ_BLOCK) {
+        const int c = e & (KJ_COLS - 1), l = e / KJ_COLS;
+        if (cb + c < nb && in.cldfrac[(size_t)col0 + (size_t)(cb + c) + (size_t)ncol * l] >= cldmin) top = l;       // (e ascends with l)
+    }
+    if (top >= 0) atomicMax(&kj_top, top);
+    __syncthreads();
+    const int ltop = kj_top;
+    for (int e = tid; e < (ltop + 1) * KJ_COLS; e += KJ_BLOCK) {
         const int c = e & (KJ_COLS - 1), l = e / KJ_COLS;
         int4 t = make_int4(0, (int)0x80000000, 0, 0);
         if (cb + c < nb) {
             const size_t cell = (size_t)col0 + (size_t)(cb + c) + (size_t)ncol * l;
             double cf = in.cldfrac[cell];
             if (cf < cldmin) cf = 0.0;
-            if (cf > 0.0) top = l;                               // (e ascends with l)
             const double v = 1. - cf;                            // cloudy: deviate >= v (:655-661)
             if (RULE == 2) {
                 t.x = __double2loint(v); t.y = __double2hiint(v);
@@ -1763,11 +1772,7 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
         }
         kj_thr[e] = t;
     }
-    if (top >= 0) atomicMax(&kj_top, top);
     __syncthreads();
-    // Every sub-column's stream is positioned on its own, so nothing depends on the draws of the layers above the highest cloud:
-    // no deviate reaches 1 - 0 there and the walk ends at `ltop` (the stratosphere of every column, most of the troposphere of many).
-    const int ltop = kj_top;
     if (cb + cl >= nb) return;
     const size_t gc = (size_t)col0 + (size_t)(cb + cl);
     Kiss s[8];
@@ -1800,7 +1805,7 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
     int4 t = kj_thr[cl];
 #pragma unroll 1
     for (int l = 0; l <= ltop; l++) {
-        const int4 tn = kj_thr[min(l + 1, nlay - 1) * KJ_COLS + cl];
+        const int4 tn = kj_thr[min(l + 1, ltop) * KJ_COLS + cl];
         unsigned bits = 0u;
         if (RULE == 2) {                                         // maximum-random, .1col :440-448
             const double v = __hiloint2double(t.y, t.x);
