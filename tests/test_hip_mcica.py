@@ -67,16 +67,20 @@ def test_subcolumn_generator_is_bit_exact(hip, oracle, icld, irng):
 
 
 @pytest.mark.parametrize("icld", [1, 2, 3, 4, 5])
-@pytest.mark.parametrize("ncol,nlay,permuteseed", [(37, 4, 0), (21, 72, 1), (16, 9, 2), (53, 137, 7 * 140)])
+@pytest.mark.parametrize("ncol,nlay,permuteseed", [(37, 4, 0), (21, 72, 1), (16, 9, 2), (53, 137, 7 * 140), (20, 203, 3)])
 def test_subcolumn_generator_edge_values(hip, oracle, icld, ncol, nlay, permuteseed):
     """The kissvec kernel reaches every sub-column's place in the column's stream by jump-ahead and compares integers with
     thresholds instead of deviates with 1 - cldfrac / alpha: cloud fractions and overlap parameters at and next to the ends of the
     deviates' range (0, below cldmin, 5e-8, 1 - 5e-8, 1; alpha 0, 1e-9, 0.99999995, 1), seeds 0 / 1 / 2 (sequential start of the
-    jump), column counts that do not fill a work-group, the shortest column the generator accepts."""
+    jump), column counts that do not fill a work-group, the shortest column the generator accepts and the reference's tallest
+    (mxlay = 203, modules/parrrtm.f90: more than 48 KB of thresholds in LDS)."""
     d = make_gcm_inputs(ncol, nlay, "cloudy", col0=5)
     rng = np.random.default_rng(100 * icld + nlay)
     special = np.array([0.0, 1e-21, 5e-8, 9.3e-8, 1.1e-7, 0.3, 0.5, 1 - 1.1e-7, 1 - 9.3e-8, 1 - 5e-8, 1.0])
     cf = np.where(rng.random((ncol, nlay)) < 0.6, special[rng.integers(0, special.size, (ncol, nlay))], rng.random((ncol, nlay)))
+    if ncol > 32:
+        cf[:16] = 0.0                      # a work-group of cloud-free columns (no jump, no draws) ...
+        cf[16:32, nlay // 3:] = 0.0        # ... and one whose walk ends a third of the way up
     d["cldfr"] = np.asfortranarray(cf)
     aspecial = np.array([0.0, 1e-9, 9.3e-8, 0.2, 0.9, 1 - 1.1e-7, 0.99999995, 1 - 1e-9, 1.0])
     alpha = np.where(rng.random((ncol, nlay)) < 0.6, aspecial[rng.integers(0, aspecial.size, (ncol, nlay))], rng.random((ncol, nlay)))
