@@ -61,3 +61,37 @@ def test_random_band_ranges(hip, oracle, seed):
     ref = oracle.column(col, a, b, 99 if a == b else 0, icld=icld)
     for k in ("totuflux", "totdflux", "totuclfl", "totdclfl", "htr", "htrc") + (("dtotuflux_dt",) if int(col["idrv"]) == 1 else ()):
         assert np.abs(got[k] - ref[k][None, :]).max() <= 5e-5, (a, b, k)
+
+
+def _mc_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    return [dict(nlay=int(rng.integers(4, 120)), ncol=int(rng.integers(1, 300)), icld=int(rng.integers(1, 6)), idrv=int(rng.integers(0, 2)),
+                 seed=int(rng.integers(0, 5000)), batch=int((64, 256, 4096)[rng.integers(0, 3)]), col0=int(rng.integers(0, 10 ** 6)),
+                 config=("cloudy", "aer_idrv")[rng.integers(0, 2)]) for _ in range(n)]
+
+
+@pytest.mark.parametrize("c", _mc_cases(20260105, 12), ids=lambda c: "%(config)s-L%(nlay)d-n%(ncol)d-icld%(icld)d-idrv%(idrv)d-seed%(seed)d-b%(batch)d" % c)
+def test_random_mcica_calls(hip, oracle, c):
+    """The fused entry (kissvec generator by jump-ahead -> cldprmc -> rtrnmc) against the oracle's generator + McICA solver: random
+    overlap rule, seed (= how far the jump tables reach), layer count (= draws per sub-column), batch size."""
+    ncol, nlay = c["ncol"], c["nlay"]
+    d = make_gcm_inputs(ncol, nlay, c["config"], col0=c["col0"])
+    d["idrv"] = c["idrv"]
+    rng = np.random.default_rng(c["seed"])
+    alpha = np.asfortranarray(rng.random((ncol, nlay)))
+    hip.set_batch(c["batch"])
+    try:
+        got = hip.rrtmg_lw_mcica_subcol_from_dict(d, c["seed"], 0, alpha=alpha, icld=c["icld"])
+    finally:
+        hip.set_batch(262144)
+    sc = oracle.mcica_subcol(ncol, nlay, c["icld"], c["seed"], 0, d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"], d["reliq"],
+                             d["taucld"], alpha)
+    dd = dict(d)
+    dd.update({k: sc[k] for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")})
+    ref = oracle.rrtmg_lw(ncol, nlay, c["icld"], c["idrv"], dd, mcica=True)
+    keys = ("uflx", "dflx", "uflxc", "dflxc") + (("duflx_dt", "duflxc_dt") if c["idrv"] else ())
+    dflux = max(np.abs(got[k] - ref[k]).max() for k in keys)
+    scale = max(np.abs(ref[k]).max() for k in ("uflx", "dflx"))
+    assert dflux <= max(5e-5, 2.5e-7 * scale), dflux
+    for k in ("hr", "hrc"):
+        assert (np.abs(got[k] - ref[k]) <= 5e-5 + 1e-6 * np.abs(ref[k])).all(), k
