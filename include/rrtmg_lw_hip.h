@@ -164,7 +164,8 @@ int rrtmg_lw_hip_mcica_subcol(
     const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
     double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl);
 
-/* DEVICE-pointer variant (enqueue on `stream`; the irng = 1 stream is drawn on the host and synchronises). */
+/* DEVICE-pointer variant (enqueue on `stream`; the irng = 1 stream is drawn on the device as well: chunk-parallel by jump-ahead of
+ * MT19937, the chunk states cached per (permuteseed, ncol * nlay), a new seed costs one device synchronisation and 10-30 ms). */
 int rrtmg_lw_hip_mcica_subcol_device(
     int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
     const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,

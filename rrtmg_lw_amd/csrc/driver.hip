@@ -14,6 +14,7 @@
 
 #include "../../include/rrtmg_lw_hip.h"
 #include "kernels.hip"
+#include "mtjump.hpp"
 
 namespace {
 
@@ -50,6 +51,8 @@ struct State {
     // McICA sub-column masks of all columns of the current call
     unsigned *mask = nullptr;
     size_t mask_bytes = 0;
+    double *d_rnd = nullptr;   // one slab of Mersenne-Twister deviates (irng = 1)
+    size_t rnd_bytes = 0;
     int batch = 262144;     // columns per internal batch: ~0.19 MB of workspace per column at 72 layers (50 GB of the 288); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
     bool split_sweep = false;    // run the sweeps / k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: a sweep
                                  // workgroup owns a CU (transmittance table in LDS), so the two do not share a CU (measured: 1-2 % gain for twice the code scratch)
@@ -788,6 +791,80 @@ struct MT19937 {
     }
 };
 
+// ---- chunk-start states of the Mersenne-Twister stream (k_mt_jump, mtjump.hpp) ---------------------------------------------------
+// The stream of a call is NGPT slabs of `per` deviates (one sub-column each), every slab cut into M chunks of C: state (isub, m) is the
+// MT19937 state isub per + m C deviates into the stream.  Two levels of doubling rounds seat them: slab starts (x^(per 2^k) applied to
+// the 2^k slabs that exist), then chunk starts inside all slabs at once (x^(C 2^k)).  Cached per (seed, per): a host model that keeps
+// its permuteseed pays for the jumps once.
+struct MtStates {
+    long long seed = -1;
+    unsigned long long per = 0, C = 0;
+    int M = 0;
+    unsigned *dev = nullptr;            // [NGPT * M][624]
+    size_t cap = 0;                     // states allocated
+    unsigned long long *polys = nullptr;   // [32][MT_PW]
+    mtj::Poly phi{};
+    bool have_phi = false;
+};
+MtStates g_mt;
+
+int mt_states(hipStream_t s, uint32_t seed, unsigned long long per, int *M_out, unsigned long long *C_out, unsigned **dev_out)
+{
+    MtStates &T = g_mt;
+    const int M = (int)std::min<unsigned long long>(512ull, std::max<unsigned long long>(1ull, (per + 65535ull) / 65536ull));   // a wavefront per chunk
+    const unsigned long long C = (per + (unsigned long long)M - 1ull) / (unsigned long long)M;
+    *M_out = M; *C_out = C;
+    if (T.dev && T.seed == (long long)seed && T.per == per && T.M == M) { *dev_out = T.dev; return 0; }
+    HIP_TRY(hipDeviceSynchronize());                                // an earlier call may still be reading the states
+    if (!T.have_phi) {
+        T.phi = mtj::char_poly();
+        if (!mtj::bit(T.phi.data(), mtj::DEG)) return fail(RRTMG_LW_HIP_EHIP, "MT19937: characteristic polynomial not found");
+        T.have_phi = true;
+    }
+    const size_t need = (size_t)NGPT * M;
+    if (T.cap < need) {
+        if (T.dev) HIP_TRY(hipFree(T.dev));
+        T.dev = nullptr; T.cap = 0;
+        HIP_TRY(hipMalloc((void **)&T.dev, need * MT_NW * sizeof(unsigned)));
+        T.cap = need;
+    }
+    if (!T.polys) HIP_TRY(hipMalloc((void **)&T.polys, (size_t)32 * MT_PW * sizeof(unsigned long long)));
+    T.seed = -1;
+    // polynomials: slab level k = 0 .. K1-1 (2^K1 >= NGPT), chunk level k = 0 .. K2-1 (2^K2 >= M)
+    int K1 = 0, K2 = 0;
+    while ((1 << K1) < NGPT) K1++;
+    while ((1 << K2) < M) K2++;
+    std::vector<unsigned long long> host((size_t)(K1 + K2) * MT_PW);
+    {
+        mtj::Poly p = mtj::pow_x(per, T.phi);
+        for (int k = 0; k < K1; k++) { std::memcpy(&host[(size_t)k * MT_PW], p.data(), sizeof(p)); p = mtj::sqr_mod(p, T.phi); }
+        if (K2) {
+            p = mtj::pow_x(C, T.phi);
+            for (int k = 0; k < K2; k++) { std::memcpy(&host[(size_t)(K1 + k) * MT_PW], p.data(), sizeof(p)); p = mtj::sqr_mod(p, T.phi); }
+        }
+    }
+    HIP_TRY(hipMemcpy(T.polys, host.data(), host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    {
+        MT19937 mt(seed);                                           // init_genrand (src/mcica_random_numbers.f90:157-169)
+        HIP_TRY(hipMemcpy(T.dev, mt.st, sizeof(mt.st), hipMemcpyHostToDevice));
+    }
+    for (int k = 0; k < K1; k++) {
+        const int have = 1 << k, n = std::min(have, NGPT - have);
+        if (n <= 0) break;
+        hipLaunchKernelGGL(k_mt_jump, dim3(n, 1), dim3(MT_BLOCK), 0, s, T.dev, (const unsigned long long *)(T.polys + (size_t)k * MT_PW), 0, M, 0, have * M);
+    }
+    for (int k = 0; k < K2; k++) {
+        const int have = 1 << k, n = std::min(have, M - have);
+        if (n <= 0) break;
+        hipLaunchKernelGGL(k_mt_jump, dim3(n, NGPT), dim3(MT_BLOCK), 0, s, T.dev, (const unsigned long long *)(T.polys + (size_t)(K1 + k) * MT_PW), 0, 1, M, have);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "k_mt_jump launch failed: %s", hipGetErrorString(e));
+    T.seed = (long long)seed; T.per = per; T.C = C; T.M = M;
+    *dev_out = T.dev;
+    return 0;
+}
+
 // ---- jump-ahead constants of the kissvec stream (KissJump, kernels.hip) ---------------------------------------------------------
 // n-fold composition of a -> 69069 a + 1327217885 (mod 2^32), by squaring
 void kiss_lcg_pow(unsigned long long n, unsigned &A, unsigned &B)
@@ -920,27 +997,29 @@ int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, 
     if (irng == 0) {
         if (int rc = launch_kiss(s, G.W, ncol, 0, ncol, nlay, icld, permuteseed, in)) return rc;
     } else {
-        // one stream over (sub-column, column, layer): drawn here, applied per sub-column slab on the device
+        // one stream over (sub-column, column, layer): drawn chunk-parallel on the device (mt_states), applied per sub-column slab
         HIP_TRY(hipMemsetAsync(G.mask, 0, (size_t)KJ_NWORD * nlay * ncol * sizeof(unsigned), s));
         const int nd = (icld == 4 || icld == 5) ? 2 : 1;
-        const size_t per = icld == 3 ? (size_t)ncol : (size_t)ncol * nlay * nd;
-        std::vector<double> buf(per);
-        double *d_rnd = nullptr;
-        HIP_TRY(hipMalloc((void **)&d_rnd, per * 8));
-        MT19937 mt((uint32_t)permuteseed);
-        const dim3 grid((ncol + BLOCK - 1) / BLOCK), block(BLOCK);
-        int rc = 0;
-        for (int isub = 0; isub < NGPT && rc == 0; isub++) {
-            for (size_t k = 0; k < per; k++) buf[k] = mt.real1();
-            hipError_t e = hipMemcpyAsync(d_rnd, buf.data(), per * 8, hipMemcpyHostToDevice, s);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_subcol_slab, grid, block, 0, s, G.W, in, (const double *)d_rnd, ncol, nlay, icld, isub);
-                e = hipStreamSynchronize(s);
-            }
-            if (e != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "sub-column slab %d: %s", isub, hipGetErrorString(e));
+        const unsigned long long per = icld == 3 ? (unsigned long long)ncol : (unsigned long long)ncol * nlay * nd;
+        int M = 0;
+        unsigned long long C = 0;
+        unsigned *states = nullptr;
+        if (int rc = mt_states(s, (uint32_t)permuteseed, per, &M, &C, &states)) return rc;
+        // as many slabs per launch as fit a 4 GiB buffer of deviates: a small call's 140 slabs are a few launches instead of 140, a large
+        // one's launches hold enough chunks (one wavefront each) to fill the device
+        const int ns = (int)std::max<unsigned long long>(1ull, std::min<unsigned long long>((unsigned long long)NGPT, (4ull << 30) / (per * 8ull)));
+        const size_t need = (size_t)ns * per * 8;
+        if (G.rnd_bytes < need) {
+            if (G.d_rnd) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.d_rnd)); G.d_rnd = nullptr; G.rnd_bytes = 0; }
+            HIP_TRY(hipMalloc((void **)&G.d_rnd, need));
+            G.rnd_bytes = need;
         }
-        (void)hipFree(d_rnd);
-        if (rc) return rc;
+        const dim3 block(BLOCK);
+        for (int isub = 0; isub < NGPT; isub += ns) {
+            const int n = std::min(ns, NGPT - isub);
+            hipLaunchKernelGGL(k_mt_fill, dim3(M, n), dim3(MT_BLOCK), 0, s, (const unsigned *)states, G.d_rnd, isub * M, M, C, per);
+            hipLaunchKernelGGL(k_subcol_slab, dim3((ncol + BLOCK - 1) / BLOCK, n), block, 0, s, G.W, in, (const double *)G.d_rnd, ncol, nlay, icld, isub, per);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "generator launch failed: %s", hipGetErrorString(e));
@@ -1021,6 +1100,10 @@ void rrtmg_lw_hip_finalize(void)
     Q.chunks.clear(); Q.ncol = 0; Q.open = false;
     if (G.mask) (void)hipFree(G.mask);
     if (g_kiss_table.dev) { (void)hipFree(g_kiss_table.dev); g_kiss_table = KissTable{}; }
+    if (g_mt.dev) (void)hipFree(g_mt.dev);
+    if (g_mt.polys) (void)hipFree(g_mt.polys);
+    { const mtj::Poly phi = g_mt.phi; const bool hp = g_mt.have_phi; g_mt = MtStates{}; g_mt.phi = phi; g_mt.have_phi = hp; }
+    if (G.d_rnd) { (void)hipFree(G.d_rnd); G.d_rnd = nullptr; G.rnd_bytes = 0; }
     if (G.d_ktab) (void)hipFree(G.d_ktab);
     if (G.d_stat) (void)hipFree(G.d_stat);
     if (G.d_err) (void)hipFree(G.d_err);

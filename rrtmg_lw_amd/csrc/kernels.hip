@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
 //                  (:460-474) and consumed in (sub-column, layer) order -> a thread per (column, 8 sub-columns), each
 //                  sub-column's stream reached by jump-ahead; the decisions leave as bytes of the bit mask.
 //   k_subcol_slab  irng = 1: the Mersenne-Twister stream is ONE sequence over (sub-column, column, layer)
-//                  (:497-503); the host draws it (driver.hip) and this kernel applies the overlap rules to
+//                  (:497-503); k_mt_jump / k_mt_fill draw it chunk-parallel and this kernel applies the overlap rules to
 //                  the slab of one sub-column.
 //   k_subcol_expand  mask -> the (140,ncol,nlay) arrays of the reference interface (:664-680).
 //   k_alpha        get_alpha (src/mcica_subcol_gen_lw.f90:68-180).
@@ -1836,33 +1836,178 @@ __global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn 
     for (int l = ltop + 1; l < nlay; l++) out[(size_t)l * ostep] = (unsigned char)0;
 }
 
+// ---- Mersenne Twister on the device (irng = 1) ----------------------------------------------------------------------------------
+// The stream is ONE MT19937 sequence over (sub-column, column, layer) (src/mcica_subcol_gen_lw.f90:497-503).  It is cut into chunks,
+// the state at the start of every chunk is reached by jump-ahead (k_mt_jump applies g(x) = x^n mod phi(x) to a state by Horner's
+// scheme; mtjump.hpp builds the polynomials and has the references), and k_mt_fill regenerates each chunk's deviates from its state.
+// A state is 624 words in canonical order: st[0] = x_k (only its top bit matters) ... st[623] = x_{k+623}; deviate number t of the
+// stream is the tempered x_{t+624}.
+constexpr int MT_NW = 624, MT_BLOCK = 64, MT_PW = 312, MT_R = (MT_NW + 63) / 64;
+// (One wavefront per state: with ten waves the two barriers around every XOR pass of k_mt_jump cost 11 ms per round of 19 937 steps and
+// the four per block of k_mt_fill 1 us; a single wave needs no barrier beyond its own LDS ordering - 2 ms and 0.25 us.)
+
+__device__ __forceinline__ unsigned mt_next(unsigned x0, unsigned x1, unsigned x397)
+{
+    const unsigned y = (x0 & 0x80000000u) | (x1 & 0x7fffffffu);
+    return x397 ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// dst state = g(A) src state.  Work-group (x, y): src = st[src0 + y ystride + x xstride], dst = src + doff.
+// Horner's scheme acc <- A acc ^ g_i s, taken 64 coefficients at a time (A is linear):
+//      acc <- A^64 acc  ^  sum_{t=0..63} g_{i-t} A^(63-t) s.
+// A^64 on a state is 64 new words, each a function of old words only (64 < 227): one word per lane.  A^m s is the window m .. m+623 of
+// the source's own word sequence, so the sum is, for every word j, an XOR of ext[j + 63 - t] over the set coefficients - reads of a
+// static LDS array, with the ring `acc` (logical word j at (h + j) mod 624) touched once per 64 coefficients.  (Coefficient by
+// coefficient, with a barrier pair around every XOR pass, a round of jumps took 12 ms; this form 0.2 ms.)
+__global__ __launch_bounds__(MT_BLOCK) void k_mt_jump(unsigned *st, const unsigned long long *g, int src0, int xstride, int ystride, int doff)
+{
+    __shared__ unsigned acc[MT_NW], ext[MT_NW + 64 + 16];
+    __shared__ unsigned long long gs[MT_PW];
+    const int tid = threadIdx.x;
+    const size_t si = (size_t)src0 + (size_t)blockIdx.y * ystride + (size_t)blockIdx.x * xstride;
+    const unsigned *sp = st + si * MT_NW;
+    unsigned *dp = st + (si + (size_t)doff) * MT_NW;
+#pragma unroll
+    for (int r = 0; r < MT_R; r++) {
+        const int j = tid + 64 * r;
+        if (j < MT_NW) { ext[j] = sp[j]; acc[j] = 0u; }
+    }
+    for (int j = tid; j < MT_PW; j += 64) gs[j] = g[j];
+    __syncthreads();
+    ext[MT_NW + tid] = mt_next(ext[tid], ext[tid + 1], ext[tid + 397]);       // words 624 .. 687 of the source's sequence
+    __syncthreads();
+    // the XOR pass: lane `tid` owns the ten consecutive words 10 tid .. 10 tid + 9 (lane 62 four, lane 63 none).  Going through the 64
+    // coefficients from offset 63 down, the window ext[j0 + b .. j0 + b + 9] slides by one word per coefficient: one LDS read each,
+    // kept in a ring of ten registers whose slot numbers are compile-time constants in the unrolled loop.
+    const int j0 = 10 * tid;
+    const int nk = tid < 62 ? 10 : (tid == 62 ? 4 : 0);
+    int h = 0;
+    bool zero = true;                                                         // acc is still all zero (leading zero coefficients)
+    for (int w = MT_PW - 1; w >= 0; w--) {
+        const unsigned long long mv = gs[w];                                  // coefficients 64 w + 63 (offset 63) ... 64 w (offset 0)
+        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mv), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mv >> 32));
+        if (zero && (mlo | mhi) == 0u) continue;
+        if (!zero) {                                                          // acc <- A^64 acc
+            const int p0 = h + tid < MT_NW ? h + tid : h + tid - MT_NW;
+            const int p1 = p0 + 1 < MT_NW ? p0 + 1 : 0;
+            const int p397 = p0 + 397 < MT_NW ? p0 + 397 : p0 + 397 - MT_NW;
+            const unsigned nw = mt_next(acc[p0], acc[p1], acc[p397]);
+            __syncthreads();
+            acc[p0] = nw;                                                     // the 64 oldest words make room for the 64 newest
+            h = h + 64 < MT_NW ? h + 64 : h + 64 - MT_NW;
+            __syncthreads();
+        }
+        if ((mlo | mhi) != 0u) {
+            unsigned v[10], P[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) { v[k] = 0u; P[(63 + k) % 10] = ext[j0 + 63 + k]; }
+#pragma unroll
+            for (int b = 63; b >= 0; b--) {
+                const bool on = b >= 32 ? ((mhi >> (b - 32)) & 1u) != 0u : ((mlo >> b) & 1u) != 0u;       // (uniform)
+                if (on) {
+#pragma unroll
+                    for (int k = 0; k < 10; k++) v[k] ^= P[(b + k) % 10];
+                }
+                if (b > 0) P[(b - 1) % 10] = ext[j0 + b - 1];                 // replaces word j0 + b + 9, which has the same slot
+            }
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                if (k < nk) { const int j = j0 + k; const int p = h + j < MT_NW ? h + j : h + j - MT_NW; acc[p] ^= v[k]; }
+            }
+            zero = false;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MT_R; r++) {
+        const int j = tid + 64 * r;
+        if (j < MT_NW) { const int p = h + j < MT_NW ? h + j : h + j - MT_NW; dp[j] = acc[p]; }
+    }
+}
+
+// Deviates of chunk blockIdx.x of slab blockIdx.y: rnd[y per + m C .. y per + min((m+1) C, per)) from the state st[state0 + y M + m].  A block of 624 new words
+// depends on the previous 624 in three waves of the recurrence (i < 227 on old words only, 227 <= i < 454 on the first wave's words,
+// the rest on the second's; word 623 needs the new word 0).  genrand_real1: tempered word / (2^32 - 1) (src/mcica_random_numbers.f90:262-295).
+__global__ __launch_bounds__(MT_BLOCK) void k_mt_fill(const unsigned *st, double *rnd, int state0, int M, unsigned long long C, unsigned long long per)
+{
+#pragma clang fp contract(off)
+    __shared__ unsigned a[MT_NW], b[MT_NW];
+    const int tid = threadIdx.x;
+    const unsigned long long lo = (unsigned long long)blockIdx.x * C;
+    if (lo >= per) return;
+    const unsigned long long len = (per - lo < C) ? per - lo : C;
+    rnd += (size_t)blockIdx.y * per;                             // slab blockIdx.y of this launch: states state0 + y M ...
+    for (int j = tid; j < MT_NW; j += 64) a[j] = st[((size_t)state0 + (size_t)blockIdx.y * M + blockIdx.x) * MT_NW + j];
+    __syncthreads();
+    unsigned *o = a, *n = b;
+    for (unsigned long long base = 0; base < len; base += MT_NW) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int i = tid + 64 * r; if (i < 227) n[i] = mt_next(o[i], o[i + 1], o[i + 397]); }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int i = 227 + tid + 64 * r; if (i < 454) n[i] = mt_next(o[i], o[i + 1], n[i - 227]); }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; r++) { const int i = 454 + tid + 64 * r; if (i < 623) n[i] = mt_next(o[i], o[i + 1], n[i - 227]); }
+        if (tid == 0) n[623] = mt_next(o[623], n[0], n[396]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MT_R; r++) {
+            const int i = tid + 64 * r;
+            if (i < MT_NW && base + i < len) {
+                unsigned y = n[i];
+                y ^= y >> 11;
+                y ^= (y << 7) & 0x9d2c5680u;
+                y ^= (y << 15) & 0xefc60000u;
+                y ^= y >> 18;
+                rnd[lo + base + i] = (double)y / 4294967295.0;
+            }
+        }
+        unsigned *t = o; o = n; n = t;
+    }
+}
+
 // rnd: the deviates of sub-column `isub` for all columns in stream order: icld == 3: [ncol]; otherwise
 // [ncol][nlay][nd] with nd = 2 for icld 4/5 (CDF, CDF2), else 1.  The mask must have been zeroed.
-__global__ __launch_bounds__(256) void k_subcol_slab(Workspace W, SubcolIn in, const double *rnd, int ncol, int nlay, int icld, int isub)
+__global__ __launch_bounds__(256) void k_subcol_slab(Workspace W, SubcolIn in, const double *rnd, int ncol, int nlay, int icld, int isub0, unsigned long long per)
 {
 #pragma clang fp contract(off)
     const size_t gc = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gc >= (size_t)ncol) return;
+    const int isub = isub0 + blockIdx.y;                         // several slabs per launch: the bits of a mask word come from different
+    rnd += (size_t)blockIdx.y * per;                             // work-groups, hence the atomic OR
     const double cldmin = 1.0e-20;
     const bool two = icld == 4 || icld == 5;
     const int nd = two ? 2 : 1;
     const int w = isub >> 5;
     const unsigned bit = 1u << (isub & 31);
     double prev = 0.0, cf_below = 0.0;
-    for (int l = 0; l < nlay; l++) {
-        double x, x2 = 0.0;
-        if (icld == 3) x = rnd[gc];
-        else {
+    const double r3 = icld == 3 ? rnd[gc] : 0.0;
+    // layers in chunks of 8: the chunk's deviates (contiguous per column in stream order), cloud fractions and overlap parameters are
+    // requested together, then the eight dependent steps run from registers
+#pragma unroll 1
+    for (int l0 = 0; l0 < nlay; l0 += 8) {
+        double xs[8], x2s[8], cfc[8], alc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int l = l0 + i < nlay ? l0 + i : nlay - 1;
             const size_t o = (gc * nlay + l) * nd;
-            x = rnd[o];
-            if (two) x2 = rnd[o + 1];
+            xs[i] = icld == 3 ? r3 : rnd[o];
+            x2s[i] = two ? rnd[o + 1] : 0.0;
+            cfc[i] = in.cldfrac[gc + (size_t)ncol * l];
+            alc[i] = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
         }
-        double cf = in.cldfrac[gc + (size_t)ncol * l];
-        if (cf < cldmin) cf = 0.0;
-        const double al = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
-        x = overlap_rule(icld, l, x, x2, prev, cf_below, al);
-        prev = x; cf_below = cf;
-        if (x >= 1. - cf) W.mask[((size_t)w * nlay + l) * W.mask_stride + gc] |= bit;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int l = l0 + i;
+            if (l < nlay) {
+                double cf = cfc[i];
+                if (cf < cldmin) cf = 0.0;
+                const double x = overlap_rule(icld, l, xs[i], x2s[i], prev, cf_below, alc[i]);
+                prev = x; cf_below = cf;
+                if (x >= 1. - cf) atomicOr(&W.mask[((size_t)w * nlay + l) * W.mask_stride + gc], bit);
+            }
+        }
     }
 }
 

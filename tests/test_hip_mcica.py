@@ -92,6 +92,24 @@ def test_subcolumn_generator_edge_values(hip, oracle, icld, ncol, nlay, permutes
         assert np.array_equal(got[k], ref[k]), (k, icld, ncol, nlay, permuteseed)
 
 
+@pytest.mark.parametrize("icld,ncol,nlay,seed", [(2, 2100, 70, 11), (5, 1500, 60, 4357), (3, 70000, 5, 1), (1, 2400, 55, 11)])
+def test_mersenne_twister_stream_in_chunks(hip, oracle, icld, ncol, nlay, seed):
+    """irng = 1 is ONE MT19937 stream over (sub-column, column, layer).  The device cuts every sub-column's slab into chunks of
+    >= 65 536 deviates and reaches the state at each chunk's start by jump-ahead (k_mt_jump): slabs of 2 - 3 chunks
+    (and, at icld = 3, a slab of one deviate per column), against the oracle's serial stream."""
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=3)
+    rng = np.random.default_rng(seed)
+    alpha = np.asfortranarray(rng.random((ncol, nlay)))
+    got = hip.mcica_subcol_lw(ncol, nlay, icld, seed, 1, *_gen_args(d), alpha)
+    ref = oracle.mcica_subcol(ncol, nlay, icld, seed, 1, *_gen_args(d), alpha)
+    assert got["irng"] == ref["irng"] == 1
+    for k in ("cldfmcl", "ciwpmcl", "clwpmcl"):
+        assert np.array_equal(got[k], ref[k]), (k, icld, ncol, nlay, seed)
+    # the same seed again (cached chunk states), then another one
+    again = hip.mcica_subcol_lw(ncol, nlay, icld, seed, 1, *_gen_args(d), alpha)
+    assert np.array_equal(again["cldfmcl"], ref["cldfmcl"])
+
+
 def test_subcolumn_generator_flags(hip, oracle):
     ncol, nlay = 64, 33
     d = make_gcm_inputs(ncol, nlay, "cloudy")
