@@ -865,50 +865,6 @@ int mt_states(hipStream_t s, uint32_t seed, unsigned long long per, int *M_out, 
     return 0;
 }
 
-// ---- jump-ahead constants of the kissvec stream (KissJump, kernels.hip) ---------------------------------------------------------
-// n-fold composition of a -> 69069 a + 1327217885 (mod 2^32), by squaring
-void kiss_lcg_pow(unsigned long long n, unsigned &A, unsigned &B)
-{
-    unsigned a = 69069u, b = 1327217885u;
-    A = 1u; B = 0u;
-    for (; n; n >>= 1) {
-        if (n & 1ull) { A = a * A; B = a * B + b; }          // x -> a (A x + B) + b
-        b = a * b + b; a = a * a;
-    }
-}
-// the xorshift 13/17/5 step as a 32 x 32 matrix over GF(2), held as the images of the unit vectors; products and powers of it
-struct Gf2 { unsigned col[32]; };
-unsigned gf2_apply(const Gf2 &M, unsigned v) { unsigned r = 0u; for (int i = 0; i < 32; i++) if ((v >> i) & 1u) r ^= M.col[i]; return r; }
-Gf2 gf2_mul(const Gf2 &A, const Gf2 &B) { Gf2 C; for (int i = 0; i < 32; i++) C.col[i] = gf2_apply(A, B.col[i]); return C; }
-Gf2 kiss_xorshift_pow(unsigned long long n)
-{
-    Gf2 R, S;
-    for (int i = 0; i < 32; i++) {
-        R.col[i] = 1u << i;
-        unsigned b = 1u << i;
-        b ^= b << 13; b ^= b >> 17; b ^= b << 5;
-        S.col[i] = b;
-    }
-    for (; n; n >>= 1) { if (n & 1ull) R = gf2_mul(S, R); S = gf2_mul(S, S); }
-    return R;
-}
-unsigned kiss_modpow(unsigned base, unsigned long long n, unsigned m)
-{
-    unsigned long long r = 1ull, b = base % m;
-    for (; n; n >>= 1) { if (n & 1ull) r = r * b % m; b = b * b % m; }
-    return (unsigned)r;
-}
-KissJump kiss_jump_entry(unsigned long long n)
-{
-    KissJump J{};
-    J.n = (unsigned)std::min<unsigned long long>(n, 0xffffffffull);
-    kiss_lcg_pow(n, J.A, J.B);
-    const Gf2 X = kiss_xorshift_pow(n);
-    for (int i = 0; i < 32; i++) J.X[i] = X.col[i];
-    J.Pc = n >= 2 ? kiss_modpow(18000u, n - 2, KISS_MC) : 1u;
-    J.Pd = n >= 2 ? kiss_modpow(30903u, n - 2, KISS_MD) : 1u;
-    return J;
-}
 // the table of one (draws per sub-column, permuteseed) pair: entries 0 .. KJ_NGROUP-1 jump from the seed to sub-column 8 g, the last one
 // by one sub-column.  Kept per stream slot so that concurrent calls do not share it.
 struct KissTable { unsigned long long stride = 0; long long seed = -1; KissJump host[KJ_NGROUP + 1]; KissJump *dev = nullptr; };

@@ -23,6 +23,7 @@
 //
 // Reference lines are cited per routine.  No CPU fallback exists anywhere in this file.
 #include <hip/hip_runtime.h>
+#include "kissjump.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -1664,9 +1665,8 @@ __device__ __forceinline__ long long kiss_threshold(double v)
 //        2^16 s' = s (mod m), m = multiplier 2^16 - 1, i.e. s' = multiplier s (mod m).  Two real steps bring any 32-bit word into
 //        [0, m]; 0 and m are fixed points and every other word stays in [1, m-1], where the residue names the word.  So n >= 2 steps
 //        are two steps and a multiplication by P = multiplier^(n-2) mod m.
-// The host fills the constants (driver.hip, kiss_jump_entry).
-struct KissJump { unsigned n, A, B, Pc, Pd, pad[3]; unsigned X[32]; };
-constexpr unsigned KISS_MC = 18000u * 65536u - 1u, KISS_MD = 30903u * 65536u - 1u;
+// The host fills the constants (kissjump.hpp, kiss_jump_entry).
+// (struct KissJump and the moduli KISS_MC / KISS_MD: kissjump.hpp)
 
 template <unsigned M>
 __device__ __forceinline__ unsigned kiss_mwc_mul(unsigned s, unsigned P)

@@ -15,7 +15,6 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
-#include <cstdio>
 #include <vector>
 
 namespace mtj {
@@ -70,7 +69,7 @@ inline Poly char_poly()
         R[0] = (R[0] << 1) | sn;
     }
     Poly phi{};
-    if (L != DEG) { fprintf(stderr, "BM: L = %d\n", L); return phi; }                                      // (all zero: the caller reports it)
+    if (L != DEG) return phi;                                       // (all zero: the caller reports it)
     for (int i = 0; i <= DEG; i++) if (bit(C.data(), L - i)) flip(phi.data(), i);     // phi_i = c_{L-i}
     return phi;
 }
