@@ -974,7 +974,7 @@ int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, 
         for (int isub = 0; isub < NGPT; isub += ns) {
             const int n = std::min(ns, NGPT - isub);
             hipLaunchKernelGGL(k_mt_fill, dim3(M, n), dim3(MT_BLOCK), 0, s, (const unsigned *)states, G.d_rnd, isub * M, M, C, per);
-            hipLaunchKernelGGL(k_subcol_slab, dim3((ncol + BLOCK - 1) / BLOCK, n), block, 0, s, G.W, in, (const double *)G.d_rnd, ncol, nlay, icld, isub, per);
+            hipLaunchKernelGGL(k_subcol_slab, dim3((ncol + BLOCK - 1) / BLOCK, (n + SLAB_GROUP - 1) / SLAB_GROUP), block, 0, s, G.W, in, (const double *)G.d_rnd, ncol, nlay, icld, isub, n, per);
         }
     }
     hipError_t e = hipGetLastError();

@@ -1969,45 +1969,66 @@ __global__ __launch_bounds__(MT_BLOCK) void k_mt_fill(const unsigned *st, double
 
 // rnd: the deviates of sub-column `isub` for all columns in stream order: icld == 3: [ncol]; otherwise
 // [ncol][nlay][nd] with nd = 2 for icld 4/5 (CDF, CDF2), else 1.  The mask must have been zeroed.
-__global__ __launch_bounds__(256) void k_subcol_slab(Workspace W, SubcolIn in, const double *rnd, int ncol, int nlay, int icld, int isub0, unsigned long long per)
+constexpr int SLAB_GROUP = 8;       // slabs a thread takes through a chunk of layers on one load of cldfrac / alpha
+__global__ __launch_bounds__(256) void k_subcol_slab(Workspace W, SubcolIn in, const double *rnd, int ncol, int nlay, int icld, int isub0, int nslab,
+                                                     unsigned long long per)
 {
 #pragma clang fp contract(off)
     const size_t gc = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gc >= (size_t)ncol) return;
-    const int isub = isub0 + blockIdx.y;                         // several slabs per launch: the bits of a mask word come from different
-    rnd += (size_t)blockIdx.y * per;                             // work-groups, hence the atomic OR
+    // several slabs per launch: the bits of a mask word come from different work-groups, hence the atomic OR
+    const int s0 = blockIdx.y * SLAB_GROUP, ns = min(SLAB_GROUP, nslab - s0);
+    rnd += (size_t)s0 * per;
     const double cldmin = 1.0e-20;
     const bool two = icld == 4 || icld == 5;
     const int nd = two ? 2 : 1;
-    const int w = isub >> 5;
-    const unsigned bit = 1u << (isub & 31);
-    double prev = 0.0, cf_below = 0.0;
-    const double r3 = icld == 3 ? rnd[gc] : 0.0;
-    // layers in chunks of 8: the chunk's deviates (contiguous per column in stream order), cloud fractions and overlap parameters are
-    // requested together, then the eight dependent steps run from registers
+    double prev[SLAB_GROUP], r3[SLAB_GROUP];
+#pragma unroll
+    for (int j = 0; j < SLAB_GROUP; j++) { prev[j] = 0.0; r3[j] = (icld == 3 && j < ns) ? rnd[(size_t)j * per + gc] : 0.0; }
+    double cf_below = 0.0;
+    // layers in chunks of 8: cloud fractions and overlap parameters are requested once for the group's slabs, each slab's deviates of the
+    // chunk (contiguous per column in stream order) together, then the eight dependent steps run from registers
 #pragma unroll 1
     for (int l0 = 0; l0 < nlay; l0 += 8) {
-        double xs[8], x2s[8], cfc[8], alc[8];
+        double cfc[8], alc[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int l = l0 + i < nlay ? l0 + i : nlay - 1;
-            const size_t o = (gc * nlay + l) * nd;
-            xs[i] = icld == 3 ? r3 : rnd[o];
-            x2s[i] = two ? rnd[o + 1] : 0.0;
-            cfc[i] = in.cldfrac[gc + (size_t)ncol * l];
+            double cf = in.cldfrac[gc + (size_t)ncol * l];
+            cfc[i] = cf < cldmin ? 0.0 : cf;
             alc[i] = two ? in.alpha[gc + (size_t)ncol * l] : 0.0;
         }
+#pragma unroll 1
+        for (int j = 0; j < ns; j++) {
+            const double *rj = rnd + (size_t)j * per;
+            double xs[8], x2s[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int l = l0 + i;
-            if (l < nlay) {
-                double cf = cfc[i];
-                if (cf < cldmin) cf = 0.0;
-                const double x = overlap_rule(icld, l, xs[i], x2s[i], prev, cf_below, alc[i]);
-                prev = x; cf_below = cf;
-                if (x >= 1. - cf) atomicOr(&W.mask[((size_t)w * nlay + l) * W.mask_stride + gc], bit);
+            for (int i = 0; i < 8; i++) {
+                const int l = l0 + i < nlay ? l0 + i : nlay - 1;
+                const size_t o = (gc * nlay + l) * nd;
+                xs[i] = icld == 3 ? 0.0 : rj[o];
+                x2s[i] = two ? rj[o + 1] : 0.0;
             }
+            const int isub = isub0 + s0 + j;
+            const int w = isub >> 5;
+            const unsigned bit = 1u << (isub & 31);
+            double pv = 0.0, r3j = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < SLAB_GROUP; jj++) if (jj == j) { pv = prev[jj]; r3j = r3[jj]; }
+            double below = cf_below;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int l = l0 + i;
+                if (l < nlay) {
+                    const double x = overlap_rule(icld, l, icld == 3 ? r3j : xs[i], x2s[i], pv, below, alc[i]);
+                    pv = x; below = cfc[i];
+                    if (x >= 1. - cfc[i]) atomicOr(&W.mask[((size_t)w * nlay + l) * W.mask_stride + gc], bit);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < SLAB_GROUP; jj++) if (jj == j) prev[jj] = pv;
         }
+        cf_below = cfc[7];                                    // (a short last chunk ends the loop)
     }
 }
 
