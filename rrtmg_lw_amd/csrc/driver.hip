@@ -866,7 +866,8 @@ int mt_states(hipStream_t s, uint32_t seed, unsigned long long per, int *M_out, 
 }
 
 // the table of one (draws per sub-column, permuteseed) pair: entries 0 .. KJ_NGROUP-1 jump from the seed to sub-column 8 g, the last one
-// by one sub-column.  Kept per stream slot so that concurrent calls do not share it.
+// by one sub-column.  One table, rebuilt (after a device synchronisation: an earlier call may still read it) when the pair changes - a host
+// model keeps its permuteseed per call site, so in steady state this is a comparison.
 struct KissTable { unsigned long long stride = 0; long long seed = -1; KissJump host[KJ_NGROUP + 1]; KissJump *dev = nullptr; };
 KissTable g_kiss_table;
 
