@@ -157,7 +157,7 @@ int rrtmg_lw_hip_get_alpha(int ncol, int nlay, int icld, int idcor, double decor
  * exponential-random overlap (alpha may be NULL unless icld is 4 or 5); icld 0 returns without touching the
  * outputs.  irng is in/out (any non-zero value becomes 1): 0 = kissvec, one stream per column seeded from
  * its four lowest layer pressures; 1 = one Mersenne-Twister stream seeded with permuteseed, consumed in
- * (sub-column, column, layer) order.  kissvec: 4 <= nlay <= 640 (the reference's mxlay is 203); a permuteseed that differs
+ * (sub-column, column, layer) order.  kissvec: 4 <= nlay <= 639 (the reference's mxlay is 203); a permuteseed that differs
  * from the previous call's rebuilds a small jump-ahead table on the host (one device synchronisation). */
 int rrtmg_lw_hip_mcica_subcol(
     int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,

@@ -932,8 +932,9 @@ int prepare_mask(int ncol, int nlay, int icld, int irng, const double *alpha)
     G.W.err = G.d_err;
     if (irng == 0) {
         const size_t lds = (size_t)nlay * KJ_COLS * sizeof(int4);
-        if (lds > 160 * 1024) return fail(RRTMG_LW_HIP_EARG, "nlay=%d exceeds the generator's LDS budget", nlay);
-        if (lds > 48 * 1024) {
+        // (+ 64: the kernel's few bytes of static LDS count against the same limits)
+        if (lds + 64 > 160 * 1024) return fail(RRTMG_LW_HIP_EARG, "nlay=%d exceeds the generator's LDS budget", nlay);
+        if (lds + 64 > 48 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIP_TRY(hipFuncSetAttribute((const void *)k_subcol_kiss<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -67,13 +67,13 @@ def test_subcolumn_generator_is_bit_exact(hip, oracle, icld, irng):
 
 
 @pytest.mark.parametrize("icld", [1, 2, 3, 4, 5])
-@pytest.mark.parametrize("ncol,nlay,permuteseed", [(37, 4, 0), (21, 72, 1), (16, 9, 2), (53, 137, 7 * 140), (20, 203, 3)])
+@pytest.mark.parametrize("ncol,nlay,permuteseed", [(37, 4, 0), (21, 72, 1), (16, 9, 2), (53, 137, 7 * 140), (20, 203, 3), (17, 192, 5)])
 def test_subcolumn_generator_edge_values(hip, oracle, icld, ncol, nlay, permuteseed):
     """The kissvec kernel reaches every sub-column's place in the column's stream by jump-ahead and compares integers with
     thresholds instead of deviates with 1 - cldfrac / alpha: cloud fractions and overlap parameters at and next to the ends of the
     deviates' range (0, below cldmin, 5e-8, 1 - 5e-8, 1; alpha 0, 1e-9, 0.99999995, 1), seeds 0 / 1 / 2 (sequential start of the
     jump), column counts that do not fill a work-group, the shortest column the generator accepts and the reference's tallest
-    (mxlay = 203, modules/parrrtm.f90: more than 48 KB of thresholds in LDS)."""
+    (mxlay = 203, modules/parrrtm.f90: more than 48 KB of thresholds in LDS; 192 layers are exactly 48 KB)."""
     d = make_gcm_inputs(ncol, nlay, "cloudy", col0=5)
     rng = np.random.default_rng(100 * icld + nlay)
     special = np.array([0.0, 1e-21, 5e-8, 9.3e-8, 1.1e-7, 0.3, 0.5, 1 - 1.1e-7, 1 - 9.3e-8, 1 - 5e-8, 1.0])
