@@ -794,8 +794,9 @@ struct MT19937 {
 // ---- chunk-start states of the Mersenne-Twister stream (k_mt_jump, mtjump.hpp) ---------------------------------------------------
 // The stream of a call is NGPT slabs of `per` deviates (one sub-column each), every slab cut into M chunks of C: state (isub, m) is the
 // MT19937 state isub per + m C deviates into the stream.  Two levels of doubling rounds seat them: slab starts (x^(per 2^k) applied to
-// the 2^k slabs that exist), then chunk starts inside all slabs at once (x^(C 2^k)).  Cached per (seed, per): a host model that keeps
-// its permuteseed pays for the jumps once.
+// the 2^k slabs that exist), then chunk starts inside all slabs at once (x^(C 2^k)).  Cached per (seed, per), two sets (a host model that
+// keeps its permuteseed pays for the jumps once; one that hands its columns over in blocks with a shorter last block alternates between
+// two values of `per`).
 struct MtStates {
     long long seed = -1;
     unsigned long long per = 0, C = 0;
@@ -803,24 +804,29 @@ struct MtStates {
     unsigned *dev = nullptr;            // [NGPT * M][624]
     size_t cap = 0;                     // states allocated
     unsigned long long *polys = nullptr;   // [32][MT_PW]
-    mtj::Poly phi{};
-    bool have_phi = false;
+    unsigned long long used = 0;        // last use (the older set makes room)
 };
-MtStates g_mt;
+MtStates g_mt[2];
+mtj::Poly g_mt_phi{};
+bool g_mt_have_phi = false;
+unsigned long long g_mt_clock = 0;
 
 int mt_states(hipStream_t s, uint32_t seed, unsigned long long per, int *M_out, unsigned long long *C_out, unsigned **dev_out)
 {
-    MtStates &T = g_mt;
     const int M = (int)std::min<unsigned long long>(512ull, std::max<unsigned long long>(1ull, (per + 65535ull) / 65536ull));   // a wavefront per chunk
     const unsigned long long C = (per + (unsigned long long)M - 1ull) / (unsigned long long)M;
     *M_out = M; *C_out = C;
-    if (T.dev && T.seed == (long long)seed && T.per == per && T.M == M) { *dev_out = T.dev; return 0; }
+    for (MtStates &S : g_mt)
+        if (S.dev && S.seed == (long long)seed && S.per == per && S.M == M) { S.used = ++g_mt_clock; *dev_out = S.dev; return 0; }
+    MtStates &T = g_mt[0].used <= g_mt[1].used ? g_mt[0] : g_mt[1];
+    T.used = ++g_mt_clock;
     HIP_TRY(hipDeviceSynchronize());                                // an earlier call may still be reading the states
-    if (!T.have_phi) {
-        T.phi = mtj::char_poly();
-        if (!mtj::bit(T.phi.data(), mtj::DEG)) return fail(RRTMG_LW_HIP_EHIP, "MT19937: characteristic polynomial not found");
-        T.have_phi = true;
+    if (!g_mt_have_phi) {
+        g_mt_phi = mtj::char_poly();
+        if (!mtj::bit(g_mt_phi.data(), mtj::DEG)) return fail(RRTMG_LW_HIP_EHIP, "MT19937: characteristic polynomial not found");
+        g_mt_have_phi = true;
     }
+    const mtj::Poly &phi = g_mt_phi;
     const size_t need = (size_t)NGPT * M;
     if (T.cap < need) {
         if (T.dev) HIP_TRY(hipFree(T.dev));
@@ -836,11 +842,11 @@ int mt_states(hipStream_t s, uint32_t seed, unsigned long long per, int *M_out, 
     while ((1 << K2) < M) K2++;
     std::vector<unsigned long long> host((size_t)(K1 + K2) * MT_PW);
     {
-        mtj::Poly p = mtj::pow_x(per, T.phi);
-        for (int k = 0; k < K1; k++) { std::memcpy(&host[(size_t)k * MT_PW], p.data(), sizeof(p)); p = mtj::sqr_mod(p, T.phi); }
+        mtj::Poly p = mtj::pow_x(per, phi);
+        for (int k = 0; k < K1; k++) { std::memcpy(&host[(size_t)k * MT_PW], p.data(), sizeof(p)); p = mtj::sqr_mod(p, phi); }
         if (K2) {
-            p = mtj::pow_x(C, T.phi);
-            for (int k = 0; k < K2; k++) { std::memcpy(&host[(size_t)(K1 + k) * MT_PW], p.data(), sizeof(p)); p = mtj::sqr_mod(p, T.phi); }
+            p = mtj::pow_x(C, phi);
+            for (int k = 0; k < K2; k++) { std::memcpy(&host[(size_t)(K1 + k) * MT_PW], p.data(), sizeof(p)); p = mtj::sqr_mod(p, phi); }
         }
     }
     HIP_TRY(hipMemcpy(T.polys, host.data(), host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
@@ -1058,9 +1064,11 @@ void rrtmg_lw_hip_finalize(void)
     Q.chunks.clear(); Q.ncol = 0; Q.open = false;
     if (G.mask) (void)hipFree(G.mask);
     if (g_kiss_table.dev) { (void)hipFree(g_kiss_table.dev); g_kiss_table = KissTable{}; }
-    if (g_mt.dev) (void)hipFree(g_mt.dev);
-    if (g_mt.polys) (void)hipFree(g_mt.polys);
-    { const mtj::Poly phi = g_mt.phi; const bool hp = g_mt.have_phi; g_mt = MtStates{}; g_mt.phi = phi; g_mt.have_phi = hp; }
+    for (MtStates &S : g_mt) {
+        if (S.dev) (void)hipFree(S.dev);
+        if (S.polys) (void)hipFree(S.polys);
+        S = MtStates{};
+    }
     if (G.d_rnd) { (void)hipFree(G.d_rnd); G.d_rnd = nullptr; G.rnd_bytes = 0; }
     if (G.d_ktab) (void)hipFree(G.d_ktab);
     if (G.d_stat) (void)hipFree(G.d_stat);

@@ -100,14 +100,19 @@ def test_mersenne_twister_stream_in_chunks(hip, oracle, icld, ncol, nlay, seed):
     d = make_gcm_inputs(ncol, nlay, "cloudy", col0=3)
     rng = np.random.default_rng(seed)
     alpha = np.asfortranarray(rng.random((ncol, nlay)))
+    d["cldfr"] = np.asfortranarray(np.where(rng.random((ncol, nlay)) < 0.5, rng.random((ncol, nlay)), 0.0))      # (cloud in short columns too)
     got = hip.mcica_subcol_lw(ncol, nlay, icld, seed, 1, *_gen_args(d), alpha)
     ref = oracle.mcica_subcol(ncol, nlay, icld, seed, 1, *_gen_args(d), alpha)
-    assert got["irng"] == ref["irng"] == 1
+    assert got["irng"] == ref["irng"] == 1 and 0.05 < ref["cldfmcl"].mean() < 0.95
     for k in ("cldfmcl", "ciwpmcl", "clwpmcl"):
         assert np.array_equal(got[k], ref[k]), (k, icld, ncol, nlay, seed)
     # the same seed again (cached chunk states), then another one
     again = hip.mcica_subcol_lw(ncol, nlay, icld, seed, 1, *_gen_args(d), alpha)
     assert np.array_equal(again["cldfmcl"], ref["cldfmcl"])
+    other = hip.mcica_subcol_lw(ncol, nlay, icld, seed + 1, 1, *_gen_args(d), alpha)      # the second cached set
+    assert not np.array_equal(other["cldfmcl"], ref["cldfmcl"])
+    third = hip.mcica_subcol_lw(ncol, nlay, icld, seed, 1, *_gen_args(d), alpha)
+    assert np.array_equal(third["cldfmcl"], ref["cldfmcl"])
 
 
 def test_subcolumn_generator_flags(hip, oracle):
