@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncol", type=int, default=1_000_000, help="total columns over all GPUs")
     ap.add_argument("--nlay", type=int, default=72)
-    ap.add_argument("--config", default="cloudy", choices=["clear", "cloudy", "aer_idrv"])
+    ap.add_argument("--config", default="cloudy", choices=["clear", "cloudy", "aer_idrv", "cloudy_deep", "cloudy_towers", "cloudy_scatter"])
     ap.add_argument("--mcica", type=int, default=0, metavar="ICLD",
                     help="McICA flavour (BASELINE configs[3]): sub-column generator with overlap ICLD (5 = exponential-random) "
                          "+ cldprmc + rtrnmc through the fused device entry; 0 = non-McICA rtrn/rtrnmr")

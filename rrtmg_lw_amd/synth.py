@@ -11,6 +11,13 @@ configs
   "cloudy"   perturbed columns, clouds in layers 6-14, icld = 2,
              inflag 2 / iceflag 3 / liqflag 1                                (config 3)
   "aer_idrv" cloudy + aerosol optical depth in layers 1-12, idrv = 1        (config 5, usually nlay = 137)
+Cloud-field variants of "cloudy" (same columns, other vertical extents; they measure how the step time depends on where
+the clouds are - the sweeps treat the layers above a column block's highest cloud as clear sky):
+  "cloudy_deep"     every cloudy column's deck reaches from layer 6 to a top drawn uniformly from layers 14 .. 45
+  "cloudy_towers"   2 % of the columns reach layer 45, in runs of 32 consecutive columns (a convective system ~800 km wide on
+                    a 0.25-degree grid whose columns are stored longitude-fastest); the rest as "cloudy" (layers 6-14)
+  "cloudy_scatter"  the same 2 %, each tower column on its own (no spatial coherence at all: the worst case for any
+                    per-block treatment)
 """
 from __future__ import annotations
 
@@ -22,6 +29,9 @@ from .blob import read_blob
 
 NBND = 16
 SEED = 20240607
+CLOUDY_CONFIGS = ("cloudy", "aer_idrv", "cloudy_deep", "cloudy_towers", "cloudy_scatter")
+TOWER_TOP = 45          # highest cloud layer (1-based) of the deep / tower variants
+TOWER_RUN = 32          # consecutive columns of one tower system ("cloudy_towers")
 _BASE = None
 
 
@@ -78,6 +88,9 @@ class _NP:
     def where(self, c, a, b):
         return np.where(c, a, b)
 
+    def floor(self, a):
+        return np.floor(a)
+
     def col_major(self, a):
         """(ncol, ...) logical array -> Fortran-contiguous storage"""
         return np.asfortranarray(a)
@@ -118,6 +131,9 @@ class _Torch:
     def where(self, c, a, b):
         return self.t.where(c, a, b)
 
+    def floor(self, a):
+        return self.t.floor(a)
+
     def col_major(self, a):
         # store so that the first logical index is fastest in memory: permute-reverse, make contiguous
         nd = a.dim()
@@ -131,7 +147,7 @@ def make_gcm_inputs(ncol, nlay, config="clear", col0=0, backend="numpy", device=
     (src/rrtmg_lw_rad.nomcica.f90:219-276) and stored column-fastest, plus icld/idrv/inflglw/iceflglw/liqflglw."""
     xp = _NP() if backend == "numpy" else _Torch(device)
     bp = base_profile(nlay)
-    perturbed = config in ("cloudy", "aer_idrv")
+    perturbed = config in CLOUDY_CONFIGS
     col = xp.arange(col0, col0 + ncol)                      # global column ids
 
     def u(stream, lay=None):
@@ -180,8 +196,22 @@ def make_gcm_inputs(ncol, nlay, config="clear", col0=0, backend="numpy", device=
     if perturbed:
         lo, hi = 5, min(14, nlay)                         # layers 6..14 (1-based)
         cloudy_col = (u(6) >= 0.30)[:, None]
-        n = hi - lo
+        top = None                                        # per-column top (number of layers below it) where it differs from `hi`
+        if config in ("cloudy_deep", "cloudy_towers", "cloudy_scatter"):
+            hmax = min(TOWER_TOP, nlay)
+            if config == "cloudy_deep":
+                top = hi + xp.floor(u(15) * (hmax - hi + 1))
+            else:
+                key = xp.arange(col0, col0 + ncol)
+                if config == "cloudy_towers":
+                    key = key // TOWER_RUN
+                tower = xp.uniform(key * 65536 + 16) < 0.02
+                top = xp.where(tower, xp.zeros((ncol,)) + hmax, xp.zeros((ncol,)) + hi)
+            hi = hmax
         cf = u(7, nlay)[:, lo:hi]
+        if top is not None:                               # layers at or above the column's top stay clear
+            lays = xp.asarray(np.arange(lo, hi, dtype=np.float64))
+            cf = xp.where(lays[None, :] < top[:, None], cf, cf * 0.0)
         # half of the cloudy cells are zeroed so clear gaps occur inside the cloud deck (exercises istcld)
         cf = xp.where(u(8, nlay)[:, lo:hi] < 0.25, cf * 0.0, cf)
         cf = xp.where(cloudy_col, cf, cf * 0.0)
