@@ -37,7 +37,7 @@ struct State {
     bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *ltop; double2 *ovl; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk; double2 *ovl; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -266,7 +266,11 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         items.push_back({(void **)&ps.laytrop, n * 4});
         items.push_back({(void **)&ps.ncbands, n * 4});
         items.push_back({(void **)&ps.cflag, (L + 2) * n * 4});
-        items.push_back({(void **)&ps.ltop, 256});
+        const size_t nblk = (n + 63) / 64, nslot = (size_t)sort_slots((int)nblk);
+        items.push_back({(void **)&ps.btop, nblk * 4});
+        items.push_back({(void **)&ps.hblk, nblk * 4});
+        items.push_back({(void **)&ps.order, nslot * 4});
+        items.push_back({(void **)&ps.hgrp, (nslot / SORT_GROUP) * 4});
     }
     if (cloud) items.push_back({(void **)&W.hand, (size_t)5 * NQUAD * 4 * n * 8});
     if (cloud) {
@@ -293,7 +297,8 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     {   // G.W itself carries prep set 0 and scratch set 0
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
-        W.odcld = ps.odcld; W.efcl = ps.efcl; W.ltop = ps.ltop; W.ovl = ps.ovl;
+        W.odcld = ps.odcld; W.efcl = ps.efcl; W.ovl = ps.ovl;
+        W.btop = ps.btop; W.order = ps.order; W.hgrp = ps.hgrp; W.hblk = ps.hblk;
     }
     G.ws_bytes = total;
     G.ws_nlay = nlay;
@@ -321,7 +326,8 @@ Workspace ws_for(int k)
     Workspace w = G.W;
     const State::PrepSet &ps = G.prep[k];
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
-    w.odcld = ps.odcld; w.efcl = ps.efcl; w.ltop = ps.ltop; w.ovl = ps.ovl;
+    w.odcld = ps.odcld; w.efcl = ps.efcl; w.ovl = ps.ovl;
+    w.btop = ps.btop; w.order = ps.order; w.hgrp = ps.hgrp; w.hblk = ps.hblk;
     const State::ScrSet &ss = G.scrset[G.ws_two_scr ? k : 0];
     for (int a = 0; a < NSCR; a++) w.scr[a] = ss.scr[a];
     w.fw = ss.fw;
@@ -341,6 +347,7 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
         LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag, mode);
         const dim3 lgrid((nb + BLOCK - 1) / BLOCK, Wk.nlay), lblock(BLOCK);
         LAUNCH("k_cloudlay", (k_cloudlay<GCM>), lgrid, lblock, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
+        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(1024), s, Wk, (nb + 63) / 64);      // the blocks by cloud top, hand-off levels
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -358,6 +365,7 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         const dim3 cgrid((nb + BLOCK - 1) / BLOCK, nlay);
         if (mc) LAUNCH("k_cloudmc<arrays>", (k_cloudmc<false>), cgrid, block, s, G.D, Wk, *mc, g, nb, col0, nct, inflag, iceflag, liqflag);
         else LAUNCH("k_cloudmc<mask>", (k_cloudmc<true>), cgrid, block, s, G.D, Wk, McIn{}, g, nb, col0, nct, inflag, iceflag, liqflag);
+        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(1024), s, Wk, (nb + 63) / 64);
     }
     LayerArgs la;
     la.ncol = nb; la.col0 = col0; la.nct = nct; la.idrv = idrv; la.istart = istart; la.iend = iend;
@@ -1096,6 +1104,7 @@ void rrtmg_lw_hip_finalize(void)
 int rrtmg_lw_hip_set_batch(int ncol_batch)
 {
     if (ncol_batch < 64) return fail(RRTMG_LW_HIP_EARG, "batch must be >= 64 columns");
+    if (ncol_batch > 64 * SORT_MAXBLK) return fail(RRTMG_LW_HIP_EARG, "batch must be <= %d columns", 64 * SORT_MAXBLK);      // k_blocksort orders a batch's 64-column blocks in LDS
     G.batch = ncol_batch;
     return 0;
 }

@@ -76,8 +76,15 @@ struct Workspace {
     double *efcl;       // [16][nlay][ncolb]   rtrn: (1 - exp(-odcld)) * cldfrac
     int *cflag;         // [nlay+2][ncolb]  bit0 icldlyr, bit1 istcldd (first cloudy level of a block, downward sweep), bit2 istcld (upward); cflag[0] bit3 = column has cloud
     double2 *ovl;       // rtrnmr's overlap factors of the cloudy levels: [2: down, up][nlay+1][3][ncolb] {facclr1, faccld1} {faccmb1, faccmb2} {facclr2, faccld2}
-    int *ltop;          // [1] highest layer of the batch that holds cloud in any column (0: none): above it every sweep is the clear-sky one
-    double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at level ltop: 0 downward (k_sweepc<.,1> -> k_sweepz), 1 / 2 upward
+    // Where the clouds end.  A sweep wave works on a BLOCK of 64 consecutive columns; above the highest cloud of its block every layer is
+    // clear in every column and the cheap clear-sky sweep (k_sweepc) serves.  k_cloudscan / k_cloudmc record the top per block, k_blocksort
+    // orders the blocks by it (deepest first) and gives every group of SORT_GROUP consecutive sorted blocks ONE hand-off level, the
+    // group's highest top: a sweep workgroup takes 1, 2, 3, 4, 6 or 12 consecutive sorted blocks of one group, whatever the kernel.
+    int *btop;          // [nblk]  highest layer that holds cloud in any column of the block (0: none)
+    int *order;         // [nslot] sorted position -> block (positions past the last block: nblk, i.e. columns past the end)
+    int *hgrp;          // [nslot / SORT_GROUP] hand-off level of the group
+    int *hblk;          // [nblk]  hand-off level of the block's group (k_flux)
+    double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at the block's hand-off level: 0 downward (k_sweepc<.,1> -> k_sweepz), 1 / 2 upward
                         // total / clear (k_sweepz -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
     scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
     unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
     }
     W.ncbands[col] = 1;
     W.cflag[col] = 0;
-    if (col == 0) *W.ltop = 0;          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
+    if ((col & 63) == 0) W.btop[col >> 6] = 0;          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
             } else prevcld = false;
         }
     }
-    if (top > *reinterpret_cast<volatile int *>(W.ltop)) atomicMax(W.ltop, top);      // (few columns get past the test once the first waves have reported)
+    if (top > 0) atomicMax(&W.btop[col >> 6], top);       // (the 64 columns of a block are one wave of this kernel)
     W.ncbands[col] = ncbands;
     W.cflag[col] = anycloud ? 8 : 0;
     W.cflag[(size_t)(nlay + 1) * W.ncolb + col] = 0;
@@ -460,6 +467,57 @@ __global__ __launch_bounds__(256) void k_cloudlay(DevTables T, Workspace W, GcmI
             if (mode == 1) W.efcl[o] = ef;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_blocksort : orders the 64-column blocks of a batch by their highest cloudy layer, deepest first (a counting sort, equal tops in
+//               block order: the result does not depend on timing), pads the order to whole groups of SORT_GROUP with the block number
+//               "one past the last" (columns past the end: every sweep lane of such a block is masked), and gives every group the
+//               top of its first = deepest block as hand-off level.  The reference decides clear / cloudy per (column, layer)
+//               (icldlyr, src/rrtmg_lw_rtrnmr.f90:509-704); this is that decision at the granularity of a wavefront's 64 columns:
+//               above a block's hand-off level the total-sky stream IS the clear-sky stream.  One workgroup; nblk <= SORT_MAXBLK.
+// ------------------------------------------------------------------------------------------------
+constexpr int SORT_GROUP = 12;                  // divisible by every column-block count of a sweep workgroup (nsb_fit)
+constexpr int SORT_MAXBLK = 16384;              // 1 048 576 columns per batch
+constexpr int SORT_MAXLAY = 603;                // parrrtm.f90:31 mxlay
+__host__ __device__ constexpr int nsb_fit(int n) { return n >= 12 ? 12 : n >= 6 ? 6 : n >= 4 ? 4 : n >= 3 ? 3 : n >= 2 ? 2 : 1; }
+__host__ __device__ constexpr int sort_slots(int nblk) { return (nblk + SORT_GROUP - 1) / SORT_GROUP * SORT_GROUP; }
+
+__global__ __launch_bounds__(1024) void k_blocksort(Workspace W, int nblk)
+{
+    __shared__ unsigned short s_top[SORT_MAXBLK];
+    __shared__ int s_cnt[SORT_MAXLAY + 1], s_start[SORT_MAXLAY + 1], s_gtop[SORT_MAXBLK / SORT_GROUP + 1];
+    const int tid = threadIdx.x, nlay = W.nlay, nslot = sort_slots(nblk), ngrp = nslot / SORT_GROUP;
+    for (int v = tid; v <= nlay; v += 1024) s_cnt[v] = 0;
+    __syncthreads();
+    for (int b = tid; b < nblk; b += 1024) {
+        const int t = min(max(W.btop[b], 0), nlay);
+        s_top[b] = (unsigned short)t;
+        atomicAdd(&s_cnt[t], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int v = nlay; v >= 0; v--) { s_start[v] = pos; pos += s_cnt[v]; }
+    }
+    __syncthreads();
+    // top of the first block of every group: the value v whose run [start, start + count) holds position SORT_GROUP g
+    for (int g = tid; g < ngrp; g += 1024) {
+        const int q = SORT_GROUP * g;
+        int t = 0;
+        for (int v = nlay; v >= 0; v--) if (s_cnt[v] > 0 && q >= s_start[v] && q < s_start[v] + s_cnt[v]) t = v;
+        s_gtop[g] = t;              // (q >= nblk cannot happen: the last group starts below nblk)
+        W.hgrp[g] = t;
+    }
+    __syncthreads();
+    for (int v = tid; v <= nlay; v += 1024) {          // thread v places the blocks whose top is v, in block order
+        if (s_cnt[v] == 0) continue;
+        int p = s_start[v];
+        for (int b = 0; b < nblk; b++) {
+            if ((int)s_top[b] == v) { W.order[p] = b; W.hblk[b] = s_gtop[p / SORT_GROUP]; p++; }
+        }
+    }
+    for (int p = nblk + tid; p < nslot; p += 1024) W.order[p] = nblk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1579,7 +1637,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
     }
     W.cflag[(size_t)lay * ncb + col] = any;
     if (any) atomicOr(&W.cflag[col], 8);
-    if (any && lay > *reinterpret_cast<volatile int *>(W.ltop)) atomicMax(W.ltop, lay);
+    if (any && lay > *reinterpret_cast<volatile int *>(&W.btop[col >> 6])) atomicMax(&W.btop[col >> 6], lay);
     if (lay == 1) W.cflag[(size_t)(nlay + 1) * ncb + col] = 0;
     if (err) atomicCAS(W.err, 0, err);
 }
@@ -2262,8 +2320,8 @@ __device__ __forceinline__ void sweep_stage_band(const DevTables &T, double (*s_
 //            loop control) is done once for up to 16 g-points instead of once per quad, and the wave has up to 16 independent
 //            recurrences in flight.
 //   PHASE 0  the whole column of a cloud-free call (icld = 0): downward, surface (rtrn :476-495), upward
-//   PHASE 1  layers ltop+1 .. nlay downward, for the cloudy modes: above the highest cloud of the batch (W.ltop) every column is clear and
-//            the clear-sky stream equals the total one; the radiances at level ltop go to k_sweepz through W.hand
+//   PHASE 1  layers ltop+1 .. nlay downward, for the cloudy modes: above its block's hand-off level ltop (W.hgrp, k_blocksort) every column
+//            of a wave is clear and the clear-sky stream equals the total one; the radiances at level ltop go to k_sweepz through W.hand
 //   PHASE 2  layers ltop+1 .. nlay upward, total and clear-sky streams, starting from the radiances k_sweepz left in W.hand
 // ------------------------------------------------------------------------------------------------
 // waves per SIMD each instantiation is compiled for = what its registers allow without spilling (a spilled register is reloaded with a
@@ -2329,9 +2387,8 @@ __host__ __device__ constexpr int sweepc_group_cap(int NQ)
 __host__ __device__ constexpr int sweepc_nsb(int NQ, int PHASE, bool IDRV, int nb)
 {
     const int nt = sweepc_nt(NQ, PHASE, IDRV);
-    int nsb = 4 * sweepc_waves(NQ / nt, PHASE, IDRV) / (nb * nt);
-    if (nsb < 1) nsb = 1;
-    while (nsb > 1 && sweepc_lds_bytes(PHASE, IDRV, nb, nsb, nt) > SWEEPC_LDS_MAX) nsb--;
+    int nsb = nsb_fit(4 * sweepc_waves(NQ / nt, PHASE, IDRV) / (nb * nt));         // (a divisor of SORT_GROUP: workgroups never straddle hand-off groups)
+    while (nsb > 1 && sweepc_lds_bytes(PHASE, IDRV, nb, nsb, nt) > SWEEPC_LDS_MAX) nsb = nsb_fit(nsb - 1);
     return nsb;
 }
 
@@ -2360,8 +2417,11 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES);
     double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES + SWEEP_PL_BYTES);
     double *red = reinterpret_cast<double *>(smem + SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES);      // [2][NVAL][nb][NC][ncw]
-    const int cblock = blockIdx.x;
-    const int col = (cblock * nsb + sub) * 64 + tx;
+    // the wave's 64-column block: position (workgroup, sub-block) of the order k_blocksort left (deepest clouds first); a cloud-free call
+    // (PHASE 0) has no order and takes the blocks as they come
+    const int slot = blockIdx.x * nsb + sub;
+    const int cblock = PHASE == 0 ? slot : __builtin_amdgcn_readfirstlane(W.order[slot]);
+    const int col = cblock * 64 + tx;
     const int B = (int)((a.bands >> (4 * bi)) & 15ull) + 1;
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;
@@ -2377,7 +2437,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     sweep_stage_lut(T, smem, (sub * ny + ty) * 64 + tx, 64 * ny * nsb);
     sweep_stage_band(T, s_pl, s_fr, B, alt16, lo_bin, up_bin, (sub * NT + part) * 64 + tx, NT * ncw);
     __syncthreads();
-    const int lo = PHASE == 0 ? 1 : __builtin_amdgcn_readfirstlane(*W.ltop) + 1;       // layers lo .. nlay
+    const int lo = PHASE == 0 ? 1 : __builtin_amdgcn_readfirstlane(W.hgrp[(blockIdx.x * nsb) / SORT_GROUP]) + 1;       // layers lo .. nlay (uniform over the workgroup)
     const size_t qstride = (size_t)nlay * ncb;
     const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)quad * qstride;
     const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
@@ -2648,9 +2708,8 @@ __host__ __device__ constexpr int sweepz_lds_bytes(int nb, int nsb, int NT, bool
 __host__ __device__ constexpr int sweepz_nsb(int NQ, int nb, bool IDRV = false)
 {
     const int nt = sweepz_nt(NQ);
-    int nsb = 4 * sweepz_waves(NQ, IDRV) / (nb * nt);
-    if (nsb < 1) nsb = 1;
-    while (nsb > 1 && sweepz_lds_bytes(nb, nsb, nt, IDRV) > SWEEPC_LDS_MAX) nsb--;
+    int nsb = nsb_fit(4 * sweepz_waves(NQ, IDRV) / (nb * nt));
+    while (nsb > 1 && sweepz_lds_bytes(nb, nsb, nt, IDRV) > SWEEPC_LDS_MAX) nsb = nsb_fit(nsb - 1);
     return nsb;
 }
 
@@ -2683,8 +2742,8 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     double (*s_pl)[184] = reinterpret_cast<double (*)[184]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES);
     double (*s_fr)[16] = reinterpret_cast<double (*)[16]>(smem + SWEEP_LUT_BYTES + bi * SWEEPC_BAND_BYTES + SWEEP_PL_BYTES);
     double *red = reinterpret_cast<double *>(smem + SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES);      // [2][NVAL][ny][NC][ncw]
-    const int cblock = blockIdx.x;
-    const int col = (cblock * nsb + sub) * 64 + tx;
+    const int cblock = __builtin_amdgcn_readfirstlane(W.order[blockIdx.x * nsb + sub]);       // the wave's 64-column block (see k_sweepc)
+    const int col = cblock * 64 + tx;
     const int B = (int)((a.bands >> (4 * bi)) & 15ull) + 1;
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;
@@ -2700,7 +2759,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     sweep_stage_lut(T, smem, (sub * ny + ty) * 64 + tx, 64 * ny * nsb);
     sweep_stage_band(T, s_pl, s_fr, B, alt16, lo_bin, up_bin, (sub * NT + part) * 64 + tx, NT * ncw);
     __syncthreads();
-    const int ltop = __builtin_amdgcn_readfirstlane(*W.ltop);                  // layers 1 .. ltop
+    const int ltop = __builtin_amdgcn_readfirstlane(W.hgrp[(blockIdx.x * nsb) / SORT_GROUP]);       // layers 1 .. ltop (uniform over the workgroup)
     const size_t qstride = (size_t)nlay * ncb;
     const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)quad * qstride;
     const scr4 *__restrict__ sCt = reinterpret_cast<const scr4 *>(W.scr[S_CODET]) + (size_t)quad * qstride;
@@ -2764,9 +2823,12 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                 const double *r = red + (bufoff + val * vstride + (unsigned)(c * ncw) + rlane);
                 double sum = 0.0;
                 for (int q = 0; q < nb; q++) {
+                    // (the band's quads in k_sweepc's order - pairs first: a level's partial must not depend on which of the two kernels swept it,
+                    // i.e. on the hand-off level its block happened to get)
                     double pq = r[(unsigned)(q * NT * NC * ncw)];
-#pragma unroll
-                    for (int t = 1; t < NT; t++) pq = pq + r[(unsigned)((q * NT + t) * NC * ncw)];
+                    if constexpr (NT >= 2) pq = pq + r[(unsigned)((q * NT + 1) * NC * ncw)];
+                    if constexpr (NT == 3) pq = pq + r[(unsigned)((q * NT + 2) * NC * ncw)];
+                    if constexpr (NT == 4) pq = pq + (r[(unsigned)((q * NT + 2) * NC * ncw)] + r[(unsigned)((q * NT + 3) * NC * ncw)]);
                     double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
                     if (val >= 2) v = v * T.fluxfac;
                     sum = q == 0 ? v : sum + v;
@@ -3202,7 +3264,7 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
     if (on) {
         // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
         // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
-        const int ltop = *W.ltop;
+        const int ltop = clear_from_total ? 0 : W.hblk[blockIdx.x];                          // hand-off level of this 64-column block
         const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // uniform over the wave
         for (int g = 0; g < ngroups; g++) {
             const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;

@@ -261,6 +261,52 @@ def test_special_cloud_configurations(hip, oracle, kind, icld):
         assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
 
 
+def _block_top_inputs(ncol, nlay, tops, seed=5):
+    """Cloud decks whose top layer changes from one 64-column block to the next: block b reaches layer tops[b % len(tops)] (0 = the
+    block holds no cloud), a third of its columns cloud-free, gaps inside the decks."""
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=17)
+    rng = np.random.default_rng(seed)
+    top = np.array([tops[(c // 64) % len(tops)] for c in range(ncol)])
+    lay = np.arange(1, nlay + 1)[None, :]
+    inside = (lay <= top[:, None]) & (rng.random((ncol, 1)) < 0.67) & (rng.random((ncol, nlay)) < 0.8)
+    # one column per cloudy block reaches the block's top for certain
+    for b in range((ncol + 63) // 64):
+        t = tops[b % len(tops)]
+        if t > 0:
+            inside[min(64 * b + 5, ncol - 1), t - 1] = True
+            top[min(64 * b + 5, ncol - 1)] = t
+    inside &= lay <= top[:, None]
+    d["cldfr"] = np.asfortranarray(np.where(inside, 0.05 + 0.9 * rng.random((ncol, nlay)), 0.0))
+    d["cliqwp"] = np.asfortranarray(np.where(inside, 60.0 * rng.random((ncol, nlay)), 0.0))
+    d["cicewp"] = np.asfortranarray(np.where(inside, 20.0 * rng.random((ncol, nlay)), 0.0))
+    d["reliq"] = np.asfortranarray(5.0 + 15.0 * rng.random((ncol, nlay)))
+    d["reice"] = np.asfortranarray(15.0 + 85.0 * rng.random((ncol, nlay)))
+    return d
+
+
+@pytest.mark.parametrize("icld", [1, 2])
+@pytest.mark.parametrize("idrv", [0, 1])
+def test_cloud_top_changes_from_block_to_block(hip, oracle, icld, idrv):
+    """The sweeps hand over between the clear-sky kernels and the cloud-zone kernel at a level chosen per group of 64-column blocks
+    (k_blocksort): neighbouring blocks with tops 0 / 14 / nlay / 1 / ..., more blocks than one hand-off group, a ragged last block."""
+    nlay = 60
+    ncol = 64 * 41 + 23
+    d = _block_top_inputs(ncol, nlay, [0, 14, nlay, 1, 30, 0, 14, 59, 2, 45, 14, 14, 7])
+    got = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, idrv, d)
+    _compare(got, ref, idrv, f"block tops icld={icld} idrv={idrv}")
+    assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
+
+
+@pytest.mark.parametrize("config", ["cloudy_deep", "cloudy_towers", "cloudy_scatter"])
+def test_cloud_field_variants(hip, oracle, config):
+    ncol, nlay = 1500, 72
+    d = make_gcm_inputs(ncol, nlay, config, col0=31 * 1000)
+    got = hip.rrtmg_lw_from_dict(d)
+    ref = oracle.rrtmg_lw(ncol, nlay, d["icld"], d["idrv"], d)
+    _compare(got, ref, d["idrv"], config)
+
+
 def test_device_entry_from_two_streams(hip, oracle):
     """Two callers enqueue device-resident work on different streams without synchronising in between: the driver orders the
     second call after the first (they share the workspace)."""
