@@ -174,7 +174,7 @@ def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld):
     """rtrnmc through the array entry and through the fused generator entry on cloud decks whose top differs from one 64-column
     block to the next (0 / 14 / nlay / 1 ...): the hand-off level between the clear-sky sweeps and the cloud-zone sweep is per group
     of blocks (k_blocksort), the generator's own walk ends per 16 columns."""
-    from test_hip_parity import _block_top_inputs
+    from test_hip_parity import _block_top_inputs, _compare_thin_layers
     nlay = 60
     ncol = 64 * 27 + 9
     d = _block_top_inputs(ncol, nlay, [0, 14, nlay, 1, 30, 0, 14, 59, 2, 45, 14, 14, 7], seed=9)
@@ -183,14 +183,7 @@ def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld):
     dd = _with_subcolumns(oracle, d, icld, alpha=alpha)
     ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
     got = hip.rrtmg_lw_mcica_from_dict(dd, icld=icld)
-    # (a cloud in the 0.03 hPa thick top layer: that layer's heating rate is its flux divergence x 280 K d-1 per W m-2, so the float32
-    # transmittance shows there as ~1e-5 of the rate itself - fluxes at the usual bar, the rates of the top layers relative; see
-    # test_special_cloud_configurations[toplayer])
-    dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
-    rel = max((np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1.0)).max() for k in ("hr", "hrc"))
-    dlow = max(np.abs(got[k][:, :-3] - ref[k][:, :-3]).max() for k in ("hr", "hrc"))
-    print(f"mcica block tops icld={icld}: max|dflux|={dflux:.3e} W/m2  max relative dhr={rel:.3e}  max|dhr| below the top three layers={dlow:.3e}")
-    assert dflux <= 5e-5 and rel <= 1e-4 and dlow <= 5e-5
+    _compare_thin_layers(got, ref, d, d["idrv"], f"mcica block tops, arrays, icld{icld}")
     fused = hip.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0, icld=icld, alpha=alpha)
     for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
         assert np.array_equal(got[k], fused[k]), k
