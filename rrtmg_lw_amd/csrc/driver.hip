@@ -182,16 +182,24 @@ hipEvent_t get_event()
 template <int Q>
 int sweepc_attr_one()
 {
+#ifndef RRLW_TUNE
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, false, sweepc_nt(Q, 0, false)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 0, true, sweepc_nt(Q, 0, true)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true, sweepc_nt(Q, 2, true)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+#endif
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 1, false, sweepc_nt(Q, 1, false)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, false, sweepc_nt(Q, 2, false)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepc<Q, 2, true, sweepc_nt(Q, 2, true)>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     return 0;
 }
 int ensure_sweep_attrs()
 {
     if (G.sweep_attrs) return 0;
+#ifdef RRLW_TUNE
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+#else
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
@@ -224,6 +232,7 @@ int ensure_sweep_attrs()
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
     HIP_TRY(hipFuncSetAttribute((const void *)k_sweepz<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEPC_LDS_MAX));
+#endif
     if (int rc = sweepc_attr_one<1>()) return rc;
     if (int rc = sweepc_attr_one<2>()) return rc;
     if (int rc = sweepc_attr_one<3>()) return rc;
@@ -347,7 +356,7 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
         LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag, mode);
         const dim3 lgrid((nb + BLOCK - 1) / BLOCK, Wk.nlay), lblock(BLOCK);
         LAUNCH("k_cloudlay", (k_cloudlay<GCM>), lgrid, lblock, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
-        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(1024), s, Wk, (nb + 63) / 64);      // the blocks by cloud top, hand-off levels
+        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(256), s, Wk, (nb + 63) / 64);      // the blocks by cloud top, hand-off levels
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -365,7 +374,7 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         const dim3 cgrid((nb + BLOCK - 1) / BLOCK, nlay);
         if (mc) LAUNCH("k_cloudmc<arrays>", (k_cloudmc<false>), cgrid, block, s, G.D, Wk, *mc, g, nb, col0, nct, inflag, iceflag, liqflag);
         else LAUNCH("k_cloudmc<mask>", (k_cloudmc<true>), cgrid, block, s, G.D, Wk, McIn{}, g, nb, col0, nct, inflag, iceflag, liqflag);
-        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(1024), s, Wk, (nb + 63) / 64);
+        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(256), s, Wk, (nb + 63) / 64);
     }
     LayerArgs la;
     la.ncol = nb; la.col0 = col0; la.nct = nct; la.idrv = idrv; la.istart = istart; la.iend = iend;
@@ -373,11 +382,20 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     la.tauaer = GCM ? g.tauaer : c.taua;
     const unsigned gx = (nb + LAYER_BLOCK - 1) / LAYER_BLOCK;
     const dim3 lgrid(gx, nlay), lblock(LAYER_BLOCK);
+#ifdef RRLW_TUNE
+    // tuning builds (tools/build_variant.sh name -DRRLW_TUNE ...): only the kernels of the benchmark's default workload - GCM entry,
+    // rtrn / rtrnmr, idrv = 0 - are instantiated (a quarter of the compile time); every other call shape is refused
+#define LAYER_GROUP(GR)                                                                                              \
+    if constexpr (GCM) { if (mode == 1 || mode == 2) LAUNCH("k_layer<cloud," #GR ">", (k_layer<true, 1, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); \
+                         else return fail(RRTMG_LW_HIP_EARG, "tuning build: cloudy non-McICA calls only"); }          \
+    else return fail(RRTMG_LW_HIP_EARG, "tuning build: GCM entry only");
+#else
 #define LAYER_GROUP(GR)                                                                                              \
     if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, lblock, s, G.D, Wk, g, c, la);         \
     else if (mode == 3) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<GCM, 2, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); \
                           else if constexpr (GCM) LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); } \
     else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, lblock, s, G.D, Wk, g, c, la);
+#endif
     LAYER_GROUP(0)
 #if RRLW_LAYER_GROUPS > 1
     LAYER_GROUP(1)
@@ -423,6 +441,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         for (int k = 0; k < 3; k++) HIP_TRY(hipStreamWaitEvent(G.swq[k], G.ev_swq_go, 0));
     }
     const hipStream_t s_main = s;
+#ifndef RRLW_TUNE
     if (G.n1 && mode == 0 && GCM && istart == 1 && iend == 16 && idrv == 0 && n1_lds_bytes(nlay) <= 160 * 1024) {
         // prototype of the north-star mapping (one column per wavefront): replaces the sweeps, k_flux and k_rates of a cloud-free call
         SweepArgs sa{};
@@ -436,6 +455,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
         return 0;
     }
+#endif
     SweepArgs sa;
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
     sa.emis = GCM ? g.emis : c.semiss;
@@ -475,7 +495,11 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands * nt, nsb);                                         \
         LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I, nt>), sgrid, sblock, sweepc_lds_bytes(PH, I, sa.nbands, nsb, nt), s, G.D, Wk, sa); \
     } while (0)
+#ifdef RRLW_TUNE
+#define SWEEPC(Q, PH) do { if (idrv == 1) return fail(RRTMG_LW_HIP_EARG, "tuning build: idrv = 0 only"); else SWEEPC_I(Q, PH, false); } while (0)
+#else
 #define SWEEPC(Q, PH) do { if (idrv == 1 && PH != 1) SWEEPC_I(Q, PH, true); else SWEEPC_I(Q, PH, false); } while (0)
+#endif
 #define SWEEPC_Q(PH) do { if (nq == 4) SWEEPC(4, PH); else if (nq == 3) SWEEPC(3, PH); else if (nq == 2) SWEEPC(2, PH); else SWEEPC(1, PH); } while (0)
     for (int phase = 0; phase < 3; phase++) {
         if (phase == 1) {                           // cloud zone: k_sweepz, one launch per group
@@ -494,8 +518,13 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands * nt, nsb);                                         \
         LAUNCH_LDS("k_sweepz<" #Q "," #M ">", (k_sweepz<Q, M, I>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt, I), s, G.D, Wk, sa); \
     } while (0)
+#ifdef RRLW_TUNE
+#define SWEEPZ_M(Q, M) do { if (idrv == 1) return fail(RRTMG_LW_HIP_EARG, "tuning build: idrv = 0 only"); else SWEEPZ_I(Q, M, false); } while (0)
+#define SWEEPZ(Q) do { if (mode == 2) SWEEPZ_M(Q, 2); else return fail(RRTMG_LW_HIP_EARG, "tuning build: rtrnmr only"); } while (0)
+#else
 #define SWEEPZ_M(Q, M) do { if (idrv == 1) SWEEPZ_I(Q, M, true); else SWEEPZ_I(Q, M, false); } while (0)
 #define SWEEPZ(Q) do { if (mode == 1) SWEEPZ_M(Q, 1); else if (mode == 3 && mc) SWEEPZ_M(Q, 3); else if (mode == 3) SWEEPZ_M(Q, 4); else SWEEPZ_M(Q, 2); } while (0)
+#endif
                 if (nq == 4) SWEEPZ(4); else if (nq == 3) SWEEPZ(3); else if (nq == 2) SWEEPZ(2); else SWEEPZ(1);
 #undef SWEEPZ_I
 #undef SWEEPZ_M
@@ -510,7 +539,11 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             sa.nbands = fg.nb[g];
             sa.group = g;
             const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;
+#ifdef RRLW_TUNE
+            if (mode == 0) return fail(RRTMG_LW_HIP_EARG, "tuning build: cloudy calls only");
+#else
             if (mode == 0) SWEEPC_Q(0);
+#endif
             else if (phase == 0) SWEEPC_Q(1);
             else SWEEPC_Q(2);
         }
@@ -1108,6 +1141,21 @@ int rrtmg_lw_hip_set_batch(int ncol_batch)
     G.batch = ncol_batch;
     return 0;
 }
+
+#ifdef RRLW_LAYER_STAMPS
+// diagnostic build only: the cycle sums of k_layer's segments (kernels.hip, STAMP) since the last call; out[NSTAMP] = waves counted
+int rrtmg_lw_hip_debug_stamps(unsigned long long *out, int n)
+{
+    ENTRY_LOCK;
+    unsigned long long h[NSTAMP + 1] = {};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h));
+    for (int i = 0; i < n && i <= NSTAMP; i++) out[i] = h[i];
+    unsigned long long z[NSTAMP + 1] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z));
+    return 0;
+}
+#endif
 
 int rrtmg_lw_hip_set_overlap(int on)
 {

@@ -483,41 +483,70 @@ constexpr int SORT_MAXLAY = 603;                // parrrtm.f90:31 mxlay
 __host__ __device__ constexpr int nsb_fit(int n) { return n >= 12 ? 12 : n >= 6 ? 6 : n >= 4 ? 4 : n >= 3 ? 3 : n >= 2 ? 2 : 1; }
 __host__ __device__ constexpr int sort_slots(int nblk) { return (nblk + SORT_GROUP - 1) / SORT_GROUP * SORT_GROUP; }
 
-__global__ __launch_bounds__(1024) void k_blocksort(Workspace W, int nblk)
+__global__ __launch_bounds__(256) void k_blocksort(Workspace W, int nblk)
 {
     __shared__ unsigned short s_top[SORT_MAXBLK];
     __shared__ int s_cnt[SORT_MAXLAY + 1], s_start[SORT_MAXLAY + 1], s_gtop[SORT_MAXBLK / SORT_GROUP + 1];
-    const int tid = threadIdx.x, nlay = W.nlay, nslot = sort_slots(nblk), ngrp = nslot / SORT_GROUP;
-    for (int v = tid; v <= nlay; v += 1024) s_cnt[v] = 0;
+    const int tid = threadIdx.x, nth = blockDim.x, nlay = W.nlay, nslot = sort_slots(nblk), ngrp = nslot / SORT_GROUP;
+    for (int v = tid; v <= nlay; v += nth) s_cnt[v] = 0;
     __syncthreads();
-    for (int b = tid; b < nblk; b += 1024) {
+    for (int b = tid; b < nblk; b += nth) {
         const int t = min(max(W.btop[b], 0), nlay);
         s_top[b] = (unsigned short)t;
         atomicAdd(&s_cnt[t], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        int pos = 0;
-        for (int v = nlay; v >= 0; v--) { s_start[v] = pos; pos += s_cnt[v]; }
+    // first position of every value, deepest first: an exclusive prefix sum over u = nlay - v by the first wave (each lane a run of values)
+    if (tid < 64) {
+        const int per = (nlay + 64) / 64, u0 = tid * per;
+        int sum = 0;
+        for (int u = u0; u < u0 + per && u <= nlay; u++) sum += s_cnt[nlay - u];
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (tid >= o) incl += t; }
+        int pos = incl - sum;
+        for (int u = u0; u < u0 + per && u <= nlay; u++) { s_start[nlay - u] = pos; pos += s_cnt[nlay - u]; }
     }
     __syncthreads();
-    // top of the first block of every group: the value v whose run [start, start + count) holds position SORT_GROUP g
-    for (int g = tid; g < ngrp; g += 1024) {
-        const int q = SORT_GROUP * g;
-        int t = 0;
-        for (int v = nlay; v >= 0; v--) if (s_cnt[v] > 0 && q >= s_start[v] && q < s_start[v] + s_cnt[v]) t = v;
-        s_gtop[g] = t;              // (q >= nblk cannot happen: the last group starts below nblk)
-        W.hgrp[g] = t;
+    // top of the first block of every group: the value whose run [start, start + count) holds position SORT_GROUP g (the starts grow with
+    // u = nlay - v: binary search for the last u with start <= q; runs of count 0 share their start with the next non-empty one, which the
+    // search passes over because it looks for the LAST such u ... of a non-empty run: step back over empty ones)
+    for (int g = tid; g < ngrp; g += nth) {
+        const int q = SORT_GROUP * g;           // (< nblk: the last group starts below nblk)
+        int lo = 0, hi = nlay;                  // largest u with s_start[nlay - u] <= q
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[nlay - mid] <= q) lo = mid; else hi = mid - 1; }
+        while (lo > 0 && s_cnt[nlay - lo] == 0) lo--;      // (an empty run at the end of equal starts)
+        s_gtop[g] = nlay - lo;
+        W.hgrp[g] = nlay - lo;
     }
     __syncthreads();
-    for (int v = tid; v <= nlay; v += 1024) {          // thread v places the blocks whose top is v, in block order
-        if (s_cnt[v] == 0) continue;
-        int p = s_start[v];
-        for (int b = 0; b < nblk; b++) {
-            if ((int)s_top[b] == v) { W.order[p] = b; W.hblk[b] = s_gtop[p / SORT_GROUP]; p++; }
+    // placement by the first wave, 64 blocks at a time in block order: the lanes that hold the same value as the first unplaced lane take
+    // consecutive positions of that value's run (a handful of distinct values per 64 blocks)
+    if (tid < 64) {
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + tid;
+            const bool in = b < nblk;
+            const int v = in ? (int)s_top[b] : -1;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
+            while (todo) {
+                const int lead = __builtin_ctzll(todo);
+                const int lv = __shfl(v, lead, 64);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(in && v == lv) & todo;
+                const int base = s_start[lv];
+                if (in && v == lv) {
+                    const int p = base + __builtin_popcountll(m & ((1ull << tid) - 1ull));
+                    W.order[p] = b;
+                    W.hblk[b] = s_gtop[p / SORT_GROUP];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (tid == lead) s_start[lv] = base + __builtin_popcountll(m);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~m;
+            }
         }
     }
-    for (int p = nblk + tid; p < nslot; p += 1024) W.order[p] = nblk;
+    for (int p = nblk + tid; p < nslot; p += nth) W.order[p] = nblk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -890,6 +919,43 @@ __device__ __forceinline__ double2 ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned ele
 // the same 16 bytes from the band's tables staged in LDS (element offset into the staging buffer)
 __device__ __forceinline__ double2 ldl(const double2 *lds, unsigned elem_off) { return lds[elem_off >> 1]; }
 
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() is a workgroup-scope release / acquire over ALL address spaces: on
+// gfx950 that puts `s_waitcnt vmcnt(0)` in front of the barrier, and k_layer's waves then sit out the acknowledgement of every code
+// store of the band they have just finished (stores count in vmcnt) sixteen times per layer although no other wave reads those codes.
+__device__ __forceinline__ void lds_barrier()
+{
+#if defined(RRLW_LAYER_SYNCTHREADS)
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
+// In-kernel stamps (diagnostic build -DRRLW_LAYER_STAMPS only: where a k_layer wave spends its cycles; the build's run time means
+// nothing, its SHARES do).  Segment sums per wave in LDS, added to g_stamps at the end of the kernel; rrtmg_lw_hip_debug_stamps reads them.
+#ifdef RRLW_LAYER_STAMPS
+constexpr int NSTAMP = 8;
+__device__ unsigned long long g_stamps[NSTAMP + 1];
+__shared__ unsigned long long s_stamp[16 * (NSTAMP + 1)];
+__device__ __forceinline__ void stamp(int seg)
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long *w = s_stamp + (threadIdx.x >> 6) * (NSTAMP + 1);
+        if (seg >= 0) w[seg] += t - w[NSTAMP];
+        w[NSTAMP] = t;
+    }
+}
+#define STAMP(seg) stamp(seg)
+#else
+#define STAMP(seg) ((void)0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Staging of a band's tables in LDS.  The table evaluation returns ~15 KB of table rows per (layer, column) to registers; through the
 // vector L1 that is bound by its 64 B/clk return path (measured: 90 % of it), LDS returns 256 B/clk.  All threads of a k_layer
@@ -1154,6 +1220,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     }
 #pragma unroll
     for (int j = 0; j < NP; j++) asm volatile("" : "+v"(od[j]));   // pin: the values exist here (LLVM's Sink pass may not move their FMA chains past this point)
+    STAMP(3);
     if constexpr (R.key == K_BINARY) { if (incol) W.fw[((size_t)fw_slot(B) * nlay + (lay - 1)) * ncb + col] = rw.fw; }
     const size_t so0 = ((size_t)QS * nlay + (lay - 1)) * ncb + col;     // scratch cell of the band's first quad
     const size_t qstride = (size_t)nlay * ncb;
@@ -1233,6 +1300,9 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     }
 }
 
+#ifndef RRLW_NOSTAGE_MASK
+#define RRLW_NOSTAGE_MASK 0       // bit B-1: band B evaluates from global memory, without staging
+#endif
 #ifndef RRLW_LAYER_WAVES
 #define RRLW_LAYER_WAVES 3        // waves per SIMD k_layer is compiled for (168 VGPRs; three workgroups of 256 threads and 41 KB of LDS per CU)
 #endif
@@ -1251,13 +1321,23 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
     unsigned delta[NROLE];
 #pragma unroll
     for (int r = 0; r < NROLE; r++) delta[r] = 0u;
-    if ((wg.lower ? Stage<B, true>::total : Stage<B, false>::total) > 0) {      // uniform; regions without tables stage nothing
-        __syncthreads();                // the previous band's readers are done with the staging buffer
+    STAMP(4);                                                                   // (cells of the previous band)
+    // bands with few g-points read little: they take their rows through the vector L1 and skip the staging round trip and its barriers
+    constexpr bool staged = ((RRLW_NOSTAGE_MASK >> (B - 1)) & 1) == 0;
+#ifdef RRLW_KO_STAGE_MASK       // knock-out (timing only, wrong results): these bands evaluate from whatever the staging buffer holds
+    constexpr bool ko = ((RRLW_KO_STAGE_MASK >> (B - 1)) & 1) != 0;
+#else
+    constexpr bool ko = false;
+#endif
+    if (!ko && staged && (wg.lower ? Stage<B, true>::total : Stage<B, false>::total) > 0) {      // uniform; regions without tables stage nothing
+        lds_barrier();                  // the previous band's readers are done with the staging buffer
+        STAMP(0);
         if (wg.lower) stage_band<B, true>(T, kt, wg.lds, wg.jp0, wg.tid, wg.nth, delta);
         else stage_band<B, false>(T, kt, wg.lds, wg.jp0, wg.tid, wg.nth, delta);
-        __syncthreads();
+        lds_barrier();
+        STAMP(1);
     }
-    const bool use_lds = __builtin_amdgcn_ballot_w64(!wg.ok) == 0ull;       // wave-uniform: every cell of the wave lies in the staged window
+    const bool use_lds = staged && __builtin_amdgcn_ballot_w64(!wg.ok) == 0ull;       // wave-uniform: every cell of the wave lies in the staged window
     const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
     double odcld = 0.0;
     if constexpr (CLOUD == 1 || CLOUD == 3) { if (cloudy) odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col]; }   // (written for cloudy layers only)
@@ -1275,6 +1355,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         rows_prep<B, true, N>(T, C, rw);
         if (use_lds) {
             rows_to_lds<B, true, N>(rw, delta);
+            STAMP(2);
             band_cells<B, CLOUD, true, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
         } else {
             band_cells<B, CLOUD, true, N, false>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
@@ -1285,6 +1366,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         rows_prep<B, false, N>(T, C, rw);
         if (use_lds) {
             rows_to_lds<B, false, N>(rw, delta);
+            STAMP(2);
             band_cells<B, CLOUD, false, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
         } else {
             band_cells<B, CLOUD, false, N, false>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
@@ -1448,6 +1530,10 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
         }
     }
     using GB = GroupBands<NLGROUP, GROUP>;
+#ifdef RRLW_LAYER_STAMPS
+    if ((threadIdx.x & 63) == 0) { for (int i = 0; i < NSTAMP; i++) s_stamp[(threadIdx.x >> 6) * (NSTAMP + 1) + i] = 0ull; }
+    STAMP(-1);
+#endif
     // staging window of the workgroup: the region of its first thread, the smallest jp among the cells of that region
     for (int i = threadIdx.x; i < NRATCHI; i += LAYER_BLOCK) s_ratchi[i] = S[T.sl.rat + i];
     if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; }
@@ -1459,7 +1545,15 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
     __syncthreads();
     wg.jp0 = s_wg[1];
     wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= 1u;
+    STAMP(5);                       // set-up of the workgroup's staging window
     group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
+#ifdef RRLW_LAYER_STAMPS
+    STAMP(4);
+    if ((threadIdx.x & 63) == 0) {
+        for (int i = 0; i < NSTAMP; i++) atomicAdd(&g_stamps[i], s_stamp[(threadIdx.x >> 6) * (NSTAMP + 1) + i]);
+        atomicAdd(&g_stamps[NSTAMP], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
