@@ -397,18 +397,6 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, lblock, s, G.D, Wk, g, c, la);
 #endif
     LAYER_GROUP(0)
-#if RRLW_LAYER_GROUPS > 1
-    LAYER_GROUP(1)
-#endif
-#if RRLW_LAYER_GROUPS > 2
-    LAYER_GROUP(2)
-#endif
-#if RRLW_LAYER_GROUPS > 3
-    LAYER_GROUP(3) LAYER_GROUP(4) LAYER_GROUP(5)
-#endif
-#if RRLW_LAYER_GROUPS > 6
-    LAYER_GROUP(6) LAYER_GROUP(7) LAYER_GROUP(8)
-#endif
 #undef LAYER_GROUP
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));

@@ -957,14 +957,26 @@ __device__ __forceinline__ void stamp(int seg)
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// Staging of a band's tables in LDS.  The table evaluation returns ~15 KB of table rows per (layer, column) to registers; through the
+// Staging of the bands' tables in LDS.  The table evaluation returns ~15 KB of table rows per (layer, column) to registers; through the
 // vector L1 that is bound by its 64 B/clk return path (measured: 90 % of it), LDS returns 256 B/clk.  All threads of a k_layer
-// workgroup work on the SAME layer, so they need the same few pressure planes of the key-species tables: the workgroup stages the
-// planes jp0 .. jp0+2 (jp0 = its smallest reference-pressure index; a cell uses planes jp and jp+1), the whole self / foreign /
-// minor-gas / halocarbon tables of the band, and evaluates from LDS.  A wave with a cell outside the window (other region of the
-// atmosphere, or jp > jp0 + 1) evaluates from global memory as before - same values either way.
+// workgroup work on the SAME layer, so they need the same few pressure planes of the key-species tables and the same few temperature
+// slices of the minor-gas tables: the workgroup stages, per band, the planes jp0 .. jp0+2 (jp0 = its smallest reference-pressure index;
+// a cell uses planes jp and jp+1), MINOR_WIN slices of each minor-gas table from im0 = its smallest minor-gas temperature index (a
+// cell uses slices indminor and indminor+1), the whole self / foreign / halocarbon tables, and evaluates from LDS.  A wave with a cell
+// outside the window (other region of the atmosphere, jp > jp0 + 1, indminor > im0 + MINOR_WIN - 2) evaluates from global memory -
+// same values either way.
+// Bands are staged in PASSES of several bands (LayerPasses, below): in-kernel stamps (tools/stamps_run.py) showed a wave spending 30 %
+// of its cycles between the barriers of the sixteen per-band staging rounds and 7 % at the barrier in front of each; a pass is ONE
+// round - the tables of up to eleven bands, as one flat list of 16-byte pieces - and the windowed minor-gas tables make four passes
+// of the sixteen bands.
 // ------------------------------------------------------------------------------------------------
 enum Role { RL_MAJOR, RL_SELF, RL_FOR, RL_MINOR0, RL_MINOR1, RL_MINOR2, RL_CFC0, RL_CFC1, NROLE };
+
+#ifndef RRLW_MINOR_WIN
+#define RRLW_MINOR_WIN 6          // temperature slices (7.2 K each) of a minor-gas table staged per workgroup; 19 = the whole table
+#endif
+constexpr int MINOR_WIN = RRLW_MINOR_WIN;
+static_assert(MINOR_WIN >= 2 && MINOR_WIN <= 19, "minor-gas tables have 19 temperature slices");
 
 template <int B, bool LOWER>
 struct Stage {
@@ -974,86 +986,122 @@ struct Stage {
     static constexpr int NPL = 3;                                                // pressure planes staged
     static constexpr bool has_major = R.key == K_SINGLE || R.key == K_BINARY;
     static constexpr int major_rows = has_major ? NPL * 5 * nsp + 3 : 0;         // + 3: zero-weight stencil rows may lie past the last plane
-    static constexpr int mrows(int k) { return k < R.nm ? 19 * (R.m[k].two_d ? (LOWER ? 9 : 5) : 1) : 0; }
-    static constexpr int l_major = 0;                                            // LDS start of each segment, in doubles
-    static constexpr int l_self = l_major + major_rows * ng;
-    static constexpr int l_for = l_self + (R.self_ ? 10 * ng : 0);
-    static constexpr int l_m0 = l_for + (R.for_ ? 4 * ng : 0);
-    static constexpr int l_m1 = l_m0 + mrows(0) * ng;
-    static constexpr int l_m2 = l_m1 + mrows(1) * ng;
-    static constexpr int l_c0 = l_m2 + mrows(2) * ng;
-    static constexpr int l_c1 = l_c0 + (R.ncfc > 0 ? ng : 0);
-    static constexpr int total = l_c1 + (R.ncfc > 1 ? ng : 0);
+    static constexpr int nj(int k) { return R.m[k].two_d ? (LOWER ? 9 : 5) : 1; }   // rows per temperature slice of minor gas k
+    static constexpr int mrows(int k) { return k < R.nm ? MINOR_WIN * nj(k) : 0; }
+    // doubles of the segment with role `r`, and its start within the band's part of the staging buffer (segments follow each other)
+    static constexpr int n(int r)
+    {
+        return r == RL_MAJOR ? major_rows * ng : r == RL_SELF ? (R.self_ ? 10 * ng : 0) : r == RL_FOR ? (R.for_ ? 4 * ng : 0) :
+               r == RL_MINOR0 ? mrows(0) * ng : r == RL_MINOR1 ? mrows(1) * ng : r == RL_MINOR2 ? mrows(2) * ng :
+               r == RL_CFC0 ? (R.ncfc > 0 ? ng : 0) : (R.ncfc > 1 ? ng : 0);
+    }
+    static constexpr int l(int r) { int s = 0; for (int q = 0; q < r; q++) s += n(q); return s; }
+    static constexpr int total = l(NROLE);
 };
-template <int B> constexpr int stage_max() { return std::max(std::max(Stage<B, true>::total, Stage<B, false>::total), stage_max<B - 1>()); }
-template <> constexpr int stage_max<0>() { return 0; }
-constexpr int STAGE_DOUBLES = stage_max<16>();       // 5166 doubles = 41.3 KB (bands 3 and 5, lower atmosphere)
 
 #ifndef RRLW_LAYER_BLOCK
 #define RRLW_LAYER_BLOCK 256      // (measured: 192 threads 29.9 ms, 256 25.5, 384 43.0, 512 35.5 per 1e6 cloudy columns)
 #endif
-constexpr int LAYER_BLOCK = RRLW_LAYER_BLOCK;   // threads of a k_layer workgroup: three workgroups per CU (a 41 KB staging buffer each), three waves per SIMD
+constexpr int LAYER_BLOCK = RRLW_LAYER_BLOCK;   // threads of a k_layer workgroup: three workgroups per CU (a 47 KB staging buffer each), three waves per SIMD
+#ifndef RRLW_STAGE_DOUBLES
+#define RRLW_STAGE_DOUBLES 5800   // capacity of the staging buffer: three workgroups per CU, each 46 400 B + 6 136 B of chi / ratio tables + flags = 52 552 B (the LDS is handed out in pieces of 2 KB: 53 248 x 3 of the 163 840 B)
+#endif
+constexpr int STAGE_DOUBLES = RRLW_STAGE_DOUBLES;
 
-// One segment of a band's staging list: [g0, g0 + N) doubles of the packed table buffer -> lds[l0 ..) (all even).  The copy of a band
-// is two-phase - every thread first issues ALL its 16-byte loads of ALL segments (at most 11, independent), then writes them to LDS -
-// so that a band's copy costs one memory round trip, not one per 4 KB (a load / wait / write loop: the first version).
-template <int N>
-struct SegRegs {
-    static constexpr int IT = (N / 2 + LAYER_BLOCK - 1) / LAYER_BLOCK;
-    double2 v[IT > 0 ? IT : 1];
-};
-template <int N>
-__device__ __forceinline__ void seg_load(__amdgpu_buffer_rsrc_t kt, unsigned g0, int tid, SegRegs<N> &r)
+// the bands of one staging pass, in evaluation order
+template <int... Bs> struct BandList { static constexpr int b[sizeof...(Bs)] = {Bs...}; static constexpr int n = sizeof...(Bs); };
+// start of band number I of the pass within the staging buffer, in doubles
+template <class PL, bool LOWER, int I> constexpr int pass_base()
 {
-#pragma unroll
-    for (int k = 0; k < SegRegs<N>::IT; k++) r.v[k] = ld2(kt, g0 + 2u * (unsigned)(tid + k * LAYER_BLOCK));     // (past the segment: following table data or, past the buffer, zeros; not stored)
+    if constexpr (I == 0) return 0;
+    else return pass_base<PL, LOWER, I - 1>() + Stage<PL::b[I - 1], LOWER>::total;
 }
-template <int N>
-__device__ __forceinline__ void seg_store(double2 *lds, int l0, int tid, const SegRegs<N> &r)
-{
-#pragma unroll
-    for (int k = 0; k < SegRegs<N>::IT; k++) {
-        const int i = tid + k * LAYER_BLOCK;
-        if (i < N / 2) lds[l0 / 2 + i] = r.v[k];
-    }
-}
+template <class PL, bool LOWER> constexpr int pass_total() { return pass_base<PL, LOWER, PL::n>(); }
 
+// where each segment of band B comes from: element offsets into the packed table buffer (wave-uniform: scalar registers)
 template <int B, bool LOWER>
-__device__ __forceinline__ void stage_band(const DevTables &T, __amdgpu_buffer_rsrc_t kt, double2 *lds, int jp0, int tid, int nth, unsigned (&delta)[NROLE])
+__device__ __forceinline__ void stage_sources(const DevTables &T, int jp0, int im0, unsigned (&g)[NROLE])
 {
     using S = Stage<B, LOWER>;
     constexpr Region R = S::R;
     constexpr int ng = S::ng;
-    (void)nth;                                       // == LAYER_BLOCK
     const BandLayout &L = T.band[B - 1];
-    unsigned g[NROLE];
 #pragma unroll
-    for (int r = 0; r < NROLE; r++) { delta[r] = 0u; g[r] = 0u; }
+    for (int r = 0; r < NROLE; r++) g[r] = 0u;
     if constexpr (S::has_major) {
         const int plane0 = LOWER ? jp0 - 1 : jp0 - 13;
         g[RL_MAJOR] = (unsigned)(LOWER ? L.absa : L.absb) + (unsigned)(plane0 * 5 * S::nsp * ng);
     }
     if constexpr (R.self_) g[RL_SELF] = (unsigned)L.selfref;
     if constexpr (R.for_) g[RL_FOR] = (unsigned)L.forref;
-    if constexpr (R.nm > 0) g[RL_MINOR0] = (unsigned)(LOWER ? L.minor_lo[0] : L.minor_up[0]);
-    if constexpr (R.nm > 1) g[RL_MINOR1] = (unsigned)(LOWER ? L.minor_lo[1] : L.minor_up[1]);
-    if constexpr (R.nm > 2) g[RL_MINOR2] = (unsigned)L.minor_lo[2];
+    if constexpr (R.nm > 0) g[RL_MINOR0] = (unsigned)(LOWER ? L.minor_lo[0] : L.minor_up[0]) + (unsigned)((im0 - 1) * S::nj(0) * ng);
+    if constexpr (R.nm > 1) g[RL_MINOR1] = (unsigned)(LOWER ? L.minor_lo[1] : L.minor_up[1]) + (unsigned)((im0 - 1) * S::nj(1) * ng);
+    if constexpr (R.nm > 2) g[RL_MINOR2] = (unsigned)L.minor_lo[2] + (unsigned)((im0 - 1) * S::nj(2) * ng);
     if constexpr (R.ncfc > 0) g[RL_CFC0] = (unsigned)L.vec[0];
     if constexpr (R.ncfc > 1) g[RL_CFC1] = (unsigned)L.vec[1];
-    constexpr int n_major = S::major_rows * ng, n_self = R.self_ ? 10 * ng : 0, n_for = R.for_ ? 4 * ng : 0;
-    constexpr int n_m0 = S::mrows(0) * ng, n_m1 = S::mrows(1) * ng, n_m2 = S::mrows(2) * ng;
-    constexpr int n_c0 = R.ncfc > 0 ? ng : 0, n_c1 = R.ncfc > 1 ? ng : 0;
-    SegRegs<n_major> r_major; SegRegs<n_self> r_self; SegRegs<n_for> r_for;
-    SegRegs<n_m0> r_m0; SegRegs<n_m1> r_m1; SegRegs<n_m2> r_m2; SegRegs<n_c0> r_c0; SegRegs<n_c1> r_c1;
-    seg_load(kt, g[RL_MAJOR], tid, r_major); seg_load(kt, g[RL_SELF], tid, r_self); seg_load(kt, g[RL_FOR], tid, r_for);
-    seg_load(kt, g[RL_MINOR0], tid, r_m0); seg_load(kt, g[RL_MINOR1], tid, r_m1); seg_load(kt, g[RL_MINOR2], tid, r_m2);
-    seg_load(kt, g[RL_CFC0], tid, r_c0); seg_load(kt, g[RL_CFC1], tid, r_c1);
-    seg_store(lds, S::l_major, tid, r_major); seg_store(lds, S::l_self, tid, r_self); seg_store(lds, S::l_for, tid, r_for);
-    seg_store(lds, S::l_m0, tid, r_m0); seg_store(lds, S::l_m1, tid, r_m1); seg_store(lds, S::l_m2, tid, r_m2);
-    seg_store(lds, S::l_c0, tid, r_c0); seg_store(lds, S::l_c1, tid, r_c1);
-    const int l[NROLE] = {S::l_major, S::l_self, S::l_for, S::l_m0, S::l_m1, S::l_m2, S::l_c0, S::l_c1};
+}
+
+// The staging buffer of a pass is the bands' segments one after the other; a thread copies the 16-byte pieces tid, tid + 256, ...
+// Per-lane source offsets of those pieces: of the segments, whose bounds are compile-time constants, only the few that meet the 256
+// pieces of round k contribute a compare and a select.
+template <class PL, bool LOWER, int I, int IT>
+__device__ __forceinline__ void pass_offsets(const DevTables &T, int jp0, int im0, int tid, unsigned (&off)[IT])
+{
+    if constexpr (I < PL::n) {
+        using S = Stage<PL::b[I], LOWER>;
+        constexpr int base = pass_base<PL, LOWER, I>();
+        unsigned g[NROLE];
+        stage_sources<PL::b[I], LOWER>(T, jp0, im0, g);
 #pragma unroll
-    for (int r = 0; r < NROLE; r++) delta[r] = (unsigned)l[r] - g[r];
+        for (int r = 0; r < NROLE; r++) {
+            const int n = S::n(r), lo = (base + S::l(r)) / 2, hi = lo + n / 2;         // constants once the loops are unrolled
+            if (n > 0) {
+#pragma unroll
+                for (int k = 0; k < IT; k++) {
+                    if (hi > LAYER_BLOCK * k && lo < LAYER_BLOCK * (k + 1)) {
+                        const int c = tid + LAYER_BLOCK * k;
+                        const unsigned src = g[r] + 2u * (unsigned)(c - lo);
+                        off[k] = (lo <= LAYER_BLOCK * k || c >= lo) ? src : off[k];
+                    }
+                }
+            }
+        }
+        pass_offsets<PL, LOWER, I + 1, IT>(T, jp0, im0, tid, off);
+    }
+}
+
+// two-phase copy: every thread first issues ALL its 16-byte loads (at most 12, independent), then writes them to LDS - a pass costs one
+// memory round trip
+template <class PL, bool LOWER>
+__device__ __forceinline__ void stage_pass(const DevTables &T, __amdgpu_buffer_rsrc_t kt, double2 *lds, int jp0, int im0, int tid)
+{
+    constexpr int NCH = pass_total<PL, LOWER>() / 2;
+    constexpr int IT = (NCH + LAYER_BLOCK - 1) / LAYER_BLOCK;
+    static_assert(pass_total<PL, LOWER>() <= STAGE_DOUBLES, "the pass does not fit the staging buffer");
+    if constexpr (IT > 0) {
+        unsigned off[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) off[k] = 0u;
+        pass_offsets<PL, LOWER, 0, IT>(T, jp0, im0, tid, off);
+        double2 v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) v[k] = ld2(kt, off[k]);          // (past the last piece: some table data or, past the buffer, zeros; not stored)
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int c = tid + LAYER_BLOCK * k;
+            if (c < NCH) lds[c] = v[k];
+        }
+    }
+}
+
+// packed-table offset -> staging-buffer offset, per role, for band B whose part of the buffer starts at BASE
+template <int B, bool LOWER, int BASE>
+__device__ __forceinline__ void band_delta(const DevTables &T, int jp0, int im0, unsigned (&delta)[NROLE])
+{
+    unsigned g[NROLE];
+    stage_sources<B, LOWER>(T, jp0, im0, g);
+#pragma unroll
+    for (int r = 0; r < NROLE; r++) delta[r] = (unsigned)(BASE + Stage<B, LOWER>::l(r)) - g[r];
 }
 
 // row offsets of the packed table buffer -> offsets into the staging buffer (rows_prep's row order: key species, self, foreign, minors, halocarbons)
@@ -1068,6 +1116,9 @@ __device__ __forceinline__ void rows_to_lds(Rows<N> &rw, const unsigned (&delta)
         const int role = i < IS ? RL_MAJOR : i < IF ? RL_SELF : i < IM0 ? RL_FOR :
                          (i < IC ? (R.nm > 1 && i >= IM1 ? (R.nm > 2 && i >= IM2 ? RL_MINOR2 : RL_MINOR1) : RL_MINOR0) : (i == IC ? RL_CFC0 : RL_CFC1));
         rw.off[i] = rw.off[i] + delta[role];
+#ifdef RRLW_KO_LDS_UNIFORM      // knock-out (timing only, wrong results): every lane reads the first lane's rows - pure broadcasts, no bank conflict
+        rw.off[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)rw.off[i]);
+#endif
     }
 }
 
@@ -1214,6 +1265,8 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     // below the next branch and keep every loaded row alive until then)
 #pragma unroll
     for (int j = 0; j < NP; j++) {        // optical depth along the diffusivity angle: rtrn :368-369
+        // (as a compare and a select: with fmax(o, 0) - one v_max_f64 - the scheduler overlaps more of the band and spills 29 registers:
+        // 24.3 -> 36.0 ms; this kernel sits at its 168-register budget)
         double o = secdiff * (od[j] + taua);
         if (!(o >= 0.0) || j >= ng) o = 0.0;
         od[j] = o;
@@ -1221,6 +1274,8 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 #pragma unroll
     for (int j = 0; j < NP; j++) asm volatile("" : "+v"(od[j]));   // pin: the values exist here (LLVM's Sink pass may not move their FMA chains past this point)
     STAMP(3);
+    // (the stores stay inside `if (incol)`: made unconditional - lanes past the last column write what the last column writes - the
+    // scheduler moves code across them and spills 26 registers: 24.4 -> 31.5 ms)
     if constexpr (R.key == K_BINARY) { if (incol) W.fw[((size_t)fw_slot(B) * nlay + (lay - 1)) * ncb + col] = rw.fw; }
     const size_t so0 = ((size_t)QS * nlay + (lay - 1)) * ncb + col;     // scratch cell of the band's first quad
     const size_t qstride = (size_t)nlay * ncb;
@@ -1300,44 +1355,25 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     }
 }
 
-#ifndef RRLW_NOSTAGE_MASK
-#define RRLW_NOSTAGE_MASK 0       // bit B-1: band B evaluates from global memory, without staging
-#endif
 #ifndef RRLW_LAYER_WAVES
-#define RRLW_LAYER_WAVES 3        // waves per SIMD k_layer is compiled for (168 VGPRs; three workgroups of 256 threads and 41 KB of LDS per CU)
+#define RRLW_LAYER_WAVES 3        // waves per SIMD k_layer is compiled for (168 VGPRs; three workgroups of 256 threads and 53 KB of LDS per CU)
 #endif
 
-// workgroup-level state of the LDS staging: the staged region (lower / upper atmosphere) and first pressure plane, this thread's
-// place in the copy loops, and whether this thread's cell lies inside the staged window
-struct LayerWg { double2 *lds; int jp0, tid, nth; bool lower, ok; };
+// workgroup-level state of the LDS staging: the staged region (lower / upper atmosphere), first pressure plane and first minor-gas
+// temperature slice, this thread's place in the copy loops, and whether this thread's cell lies inside the staged window
+struct LayerWg { double2 *lds; int jp0, im0, tid, nth; bool lower, ok; };
 
-// all cells of band B for one (layer, column)
-template <int B, int CLOUD>
+// all cells of band B for one (layer, column); BASE_LO / BASE_UP: where the band's tables start in the staging buffer of its pass
+template <int B, int CLOUD, int BASE_LO, int BASE_UP>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
                                            __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol, int cloudy,
                                            const unsigned (&mw)[5])
 {
-    // the band's tables -> LDS (see Stage); the barriers are reached by every thread of the workgroup (the band test is uniform)
+    STAMP(4);                                                                   // (cells of the previous band)
     unsigned delta[NROLE];
 #pragma unroll
     for (int r = 0; r < NROLE; r++) delta[r] = 0u;
-    STAMP(4);                                                                   // (cells of the previous band)
-    // bands with few g-points read little: they take their rows through the vector L1 and skip the staging round trip and its barriers
-    constexpr bool staged = ((RRLW_NOSTAGE_MASK >> (B - 1)) & 1) == 0;
-#ifdef RRLW_KO_STAGE_MASK       // knock-out (timing only, wrong results): these bands evaluate from whatever the staging buffer holds
-    constexpr bool ko = ((RRLW_KO_STAGE_MASK >> (B - 1)) & 1) != 0;
-#else
-    constexpr bool ko = false;
-#endif
-    if (!ko && staged && (wg.lower ? Stage<B, true>::total : Stage<B, false>::total) > 0) {      // uniform; regions without tables stage nothing
-        lds_barrier();                  // the previous band's readers are done with the staging buffer
-        STAMP(0);
-        if (wg.lower) stage_band<B, true>(T, kt, wg.lds, wg.jp0, wg.tid, wg.nth, delta);
-        else stage_band<B, false>(T, kt, wg.lds, wg.jp0, wg.tid, wg.nth, delta);
-        lds_barrier();
-        STAMP(1);
-    }
-    const bool use_lds = staged && __builtin_amdgcn_ballot_w64(!wg.ok) == 0ull;       // wave-uniform: every cell of the wave lies in the staged window
+    const bool use_lds = __builtin_amdgcn_ballot_w64(!wg.ok) == 0ull;       // wave-uniform: every cell of the wave lies in the staged window
     const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
     double odcld = 0.0;
     if constexpr (CLOUD == 1 || CLOUD == 3) { if (cloudy) odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col]; }   // (written for cloudy layers only)
@@ -1354,6 +1390,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         Rows<N> rw;
         rows_prep<B, true, N>(T, C, rw);
         if (use_lds) {
+            band_delta<B, true, BASE_LO>(T, wg.jp0, wg.im0, delta);
             rows_to_lds<B, true, N>(rw, delta);
             STAMP(2);
             band_cells<B, CLOUD, true, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
@@ -1365,6 +1402,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         Rows<N> rw;
         rows_prep<B, false, N>(T, C, rw);
         if (use_lds) {
+            band_delta<B, false, BASE_UP>(T, wg.jp0, wg.im0, delta);
             rows_to_lds<B, false, N>(rw, delta);
             STAMP(2);
             band_cells<B, CLOUD, false, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
@@ -1374,45 +1412,48 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
     }
 }
 
-
-// band groups: one k_layer launch covers the bands of one group; its threads do the inatm/setcoef prologue once.
-// Fewer groups = less repeated prologue work and fewer re-reads of the profile inputs, more groups = shorter kernels with
-// fewer live registers (RRLW_LAYER_GROUPS: 9, 6, 3, 2 or 1).  Default: one launch for all 16 bands.
-#ifndef RRLW_LAYER_GROUPS
-#define RRLW_LAYER_GROUPS 1
+// The staging passes: every band once, in evaluation order (bands that are the only users of some setcoef quantity - pavel, broadening
+// gases, O2, halocarbons, CO - first, the bands with the longest row lists last: their register peak then meets fewer live quantities).
+// A pass must fit the staging buffer in both regions of the atmosphere (static_assert in stage_pass).
+#ifdef RRLW_G256
+using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6>, BandList<8, 10, 14, 16>, BandList<12>, BandList<13>, BandList<4, 9>, BandList<7>, BandList<3>, BandList<5>>;
+#elif defined(RRLW_LAYER_PASS_PER_BAND)       // measurement: one staging round per band, as before round 3
+using LayerPasses = std::tuple<BandList<1>, BandList<2>, BandList<11>, BandList<15>, BandList<6>, BandList<8>, BandList<10>, BandList<14>, BandList<16>,
+                               BandList<12>, BandList<13>, BandList<4>, BandList<9>, BandList<7>, BandList<3>, BandList<5>>;
+#else
+using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13>, BandList<4, 9>, BandList<7, 3>, BandList<5>>;
 #endif
-constexpr int NLGROUP = RRLW_LAYER_GROUPS;
 
-template <int NG, int G> struct GroupBands;
-#define GROUP_BANDS(NG, G, ...)                                                \
-    template <> struct GroupBands<NG, G> {                                     \
-        static constexpr int b[] = {__VA_ARGS__};                              \
-        static constexpr int n = sizeof(b) / sizeof(int);                      \
-    };
-GROUP_BANDS(6, 0, 3, 14) GROUP_BANDS(6, 1, 5, 15) GROUP_BANDS(6, 2, 4, 10, 16) GROUP_BANDS(6, 3, 7, 8) GROUP_BANDS(6, 4, 9, 11, 13)
-GROUP_BANDS(6, 5, 1, 2, 6, 12)
-GROUP_BANDS(3, 0, 3, 14, 5, 15) GROUP_BANDS(3, 1, 4, 10, 16, 7, 8) GROUP_BANDS(3, 2, 9, 11, 13, 1, 2, 6, 12)
-GROUP_BANDS(2, 0, 3, 14, 5, 15, 4, 10, 16) GROUP_BANDS(2, 1, 7, 8, 9, 11, 13, 1, 2, 6, 12)
-// (order: bands that are the only users of some setcoef quantity - pavel, broadening gases, O2, halocarbons, CO - first, the bands with
-// the longest row lists last: their register peak then meets fewer live quantities)
-GROUP_BANDS(1, 0, 1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13, 4, 9, 7, 3, 5)
-GROUP_BANDS(9, 0, 3) GROUP_BANDS(9, 1, 5) GROUP_BANDS(9, 2, 4) GROUP_BANDS(9, 3, 7, 14) GROUP_BANDS(9, 4, 9, 15) GROUP_BANDS(9, 5, 8, 16, 13)
-GROUP_BANDS(9, 6, 1, 10) GROUP_BANDS(9, 7, 2, 11) GROUP_BANDS(9, 8, 6, 12)
-#undef GROUP_BANDS
-
-template <class GB, int CLOUD, int... K>
-__device__ __forceinline__ void group_run(std::integer_sequence<int, K...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
-                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
-                                          int cloudy, const unsigned (&mw)[5])
+template <class PL, int CLOUD, int... I>
+__device__ __forceinline__ void pass_run(std::integer_sequence<int, I...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
+                                         const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
+                                         int cloudy, const unsigned (&mw)[5])
 {
-    ((GB::b[K] >= a.istart && GB::b[K] <= a.iend ? layer_band<GB::b[K], CLOUD>(T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw) : (void)0), ...);
+    // the pass's tables -> LDS; the barriers are reached by every thread of the workgroup
+    STAMP(4);
+    lds_barrier();                      // the previous pass's readers are done with the staging buffer
+    STAMP(0);
+    if (wg.lower) stage_pass<PL, true>(T, kt, wg.lds, wg.jp0, wg.im0, wg.tid);
+    else stage_pass<PL, false>(T, kt, wg.lds, wg.jp0, wg.im0, wg.tid);
+    lds_barrier();
+    STAMP(1);
+    ((PL::b[I] >= a.istart && PL::b[I] <= a.iend
+          ? layer_band<PL::b[I], CLOUD, pass_base<PL, true, I>(), pass_base<PL, false, I>()>(T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw)
+          : (void)0), ...);
+}
+template <int CLOUD, class... PLs>
+__device__ __forceinline__ void passes_run(std::tuple<PLs...> *, const DevTables &T, const Workspace &W, const LayerArgs &a,
+                                           const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
+                                           int cloudy, const unsigned (&mw)[5])
+{
+    (pass_run<PLs, CLOUD>(std::make_integer_sequence<int, PLs::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw), ...);
 }
 
 template <bool GCM, int CLOUD, int GROUP>
 __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
 {
     __shared__ double2 s_tab[STAGE_DOUBLES / 2];
-    __shared__ int s_wg[2];
+    __shared__ int s_wg[3];
     const int colr = blockIdx.x * blockDim.x + threadIdx.x;
     const bool incol = colr < a.ncol;
     const int col = incol ? colr : a.ncol - 1;      // threads past the end shadow the last column (they take part in the staging and the barriers)
@@ -1529,24 +1570,24 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
             for (int w = 0; w < 5; w++) mw[w] = W.mask[((size_t)w * W.nlay + (lay - 1)) * W.mask_stride + W.mask_col0 + gc];
         }
     }
-    using GB = GroupBands<NLGROUP, GROUP>;
 #ifdef RRLW_LAYER_STAMPS
     if ((threadIdx.x & 63) == 0) { for (int i = 0; i < NSTAMP; i++) s_stamp[(threadIdx.x >> 6) * (NSTAMP + 1) + i] = 0ull; }
     STAMP(-1);
 #endif
-    // staging window of the workgroup: the region of its first thread, the smallest jp among the cells of that region
+    // staging window of the workgroup: the region of its first thread, the smallest jp and the smallest indminor among the cells of that region
     for (int i = threadIdx.x; i < NRATCHI; i += LAYER_BLOCK) s_ratchi[i] = S[T.sl.rat + i];
-    if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; }
+    if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; s_wg[2] = 99; }
     __syncthreads();
     LayerWg wg;
     wg.lds = s_tab; wg.tid = threadIdx.x; wg.nth = blockDim.x;
     wg.lower = s_wg[0] != 0;
-    if (lower == wg.lower) atomicMin(&s_wg[1], jp);
+    if (lower == wg.lower) { atomicMin(&s_wg[1], jp); atomicMin(&s_wg[2], indminor); }
     __syncthreads();
     wg.jp0 = s_wg[1];
-    wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= 1u;
+    wg.im0 = min(s_wg[2], 20 - MINOR_WIN);           // (the window ends with the table's last slice at the latest)
+    wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= 1u && (unsigned)(indminor - wg.im0) <= (unsigned)(MINOR_WIN - 2);
     STAMP(5);                       // set-up of the workgroup's staging window
-    group_run<GB, CLOUD>(std::make_integer_sequence<int, GB::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
+    passes_run<CLOUD>(static_cast<LayerPasses *>(nullptr), T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
 #ifdef RRLW_LAYER_STAMPS
     STAMP(4);
     if ((threadIdx.x & 63) == 0) {

@@ -1,2 +1,7 @@
 export RRTMG_LW_ALLOW_STANDIN=1
-STEPS=5 bash tools/run_variants.sh exp/lib_tune_ldsbar.so exp/lib_k6.so exp/lib_k16.so 2>&1 | grep -E "^==|ms/step|k_layer<"  | sed -e "s/'k_sweepz.*//"
+for l in pass4 ko_ldsu; do echo "== $l"; RRTMG_LW_HIP_LIB=$PWD/exp/lib_$l.so timeout -k 10 300 python bench.py --check --no-cpu-baseline --host-cols 0 --steps 5 --warmup 1 2> gpurun_out/_err.txt | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('ms/step',d['ms_per_step'], {k:v for k,v in d['path']['kernels'].items() if 'layer' in k})
+"; grep "check vs" gpurun_out/_err.txt; done
