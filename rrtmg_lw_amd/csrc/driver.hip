@@ -3,6 +3,7 @@
 // (src/rrtmg_lw_rad.nomcica.f90:472-586) with batched launches of the kernels in kernels.hip.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <sched.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -64,6 +65,9 @@ struct State {
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
     hipStream_t cp_in = nullptr, cp_out = nullptr;      // host-pointer entries: H2D and D2H copy streams
+    double *h_tot = nullptr;                            // pinned host scratch of the non-McICA host entry: tauctot of two column batches
+    size_t h_tot_doubles = 0;
+    std::vector<unsigned char> zrow[2];                 // ... and the zero-row flags of tauaer and taucld
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
     std::string err;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -690,7 +694,10 @@ int check_common(int ncol, int nlay)
 // ---- host-pointer staging ---------------------------------------------------------------------------
 // Every array of the interface is [rows][ncol][inner] with `inner` fastest (inner = 1 for (ncol,nlay) arrays,
 // 16 for taucld, 140 for the McICA sub-column arrays); a column block is therefore one 2-D copy.
-struct HostIn { const double *h; size_t inner, rows; double *d; };
+// prepared = the device copy is filled by the entry itself (host-side reduction of the array: tauctot), not copied from h;
+// rowzero = per-row flags of the CURRENT column batch: a row whose values are all +0.0 is not copied - the device copy is zeroed
+// with one memset and only the runs of other rows travel (aerosol / in-cloud optical depths are zero in most (layer, band) rows).
+struct HostIn { const double *h; size_t inner, rows; double *d; bool prepared = false; const unsigned char *rowzero = nullptr; };
 struct HostOut { double *h; size_t rows; double *d; bool active; };
 
 int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
@@ -708,11 +715,65 @@ int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
 int stage_in(std::vector<HostIn> &ins, size_t ncol, size_t col0, size_t nb, hipStream_t s)
 {
     for (auto &a : ins) {
-        if (!a.h) continue;
+        if (!a.h || a.prepared) continue;
         const size_t w = a.inner * nb * 8, sp = a.inner * ncol * 8;
-        HIP_TRY(hipMemcpy2DAsync(a.d, w, a.h + a.inner * col0, sp, w, a.rows, hipMemcpyHostToDevice, s));
+        if (!a.rowzero) {
+            HIP_TRY(hipMemcpy2DAsync(a.d, w, a.h + a.inner * col0, sp, w, a.rows, hipMemcpyHostToDevice, s));
+            continue;
+        }
+        HIP_TRY(hipMemsetAsync(a.d, 0, w * a.rows, s));
+        for (size_t r0 = 0; r0 < a.rows;) {
+            if (a.rowzero[r0]) { r0++; continue; }
+            size_t r1 = r0 + 1;
+            while (r1 < a.rows && !a.rowzero[r1]) r1++;
+            HIP_TRY(hipMemcpy2DAsync(a.d + a.inner * nb * r0, w, a.h + a.inner * (col0 + ncol * r0), sp, w, r1 - r0, hipMemcpyHostToDevice, s));
+            r0 = r1;
+        }
     }
     return 0;
+}
+
+// f(t, nt) on nt host threads (the host-pointer entries' own arithmetic on the caller's arrays: row scans, tauctot)
+int host_threads()
+{
+    static int nt = 0;
+    if (nt == 0) {
+        const char *e = getenv("RRTMG_LW_HOST_THREADS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+#ifdef __linux__
+        cpu_set_t set;
+        if (!e && sched_getaffinity(0, sizeof set, &set) == 0) v = std::min(v, CPU_COUNT(&set));
+#endif
+        nt = std::max(1, std::min(v, 16));
+    }
+    return nt;
+}
+template <class F>
+void host_parallel(F f)
+{
+    const int nt = host_threads();
+    if (nt == 1) { f(0, 1); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back([=, &f]() { f(t, nt); });
+    f(0, nt);
+    for (auto &x : th) x.join();
+}
+
+// flags[r] = 1 when row r of the column batch [col0, col0 + nb) of a (rows, ncol, inner) array holds nothing but +0.0
+void scan_zero_rows(const double *h, size_t inner, size_t rows, size_t ncol, size_t col0, size_t nb, unsigned char *flags)
+{
+    host_parallel([&](int t, int nt) {
+        for (size_t r = rows * t / nt; r < rows * (t + 1) / nt; r++) {
+            const uint64_t *p = reinterpret_cast<const uint64_t *>(h + inner * (col0 + ncol * r));
+            const size_t n = inner * nb;
+            uint64_t acc = 0;
+            size_t i = 0;
+            for (; i + 64 <= n && acc == 0; i += 64)
+                for (size_t k = 0; k < 64; k++) acc |= p[i + k];
+            for (; i < n; i++) acc |= p[i];
+            flags[r] = acc == 0;
+        }
+    });
 }
 
 int stage_out(std::vector<HostOut> &outs, size_t ncol, size_t col0, size_t nb, hipStream_t s)
@@ -744,8 +805,9 @@ int ensure_copy_streams()
 // block the calling thread, which still overlaps them with the kernels of the previous batch; with arrays pinned through
 // rrtmg_lw_hip_host_register they are asynchronous DMA at PCIe rate.  body(stream, nb, in_ptrs, out_ptrs) enqueues the
 // kernels of one batch whose staged arrays start at column 0.
-template <class Body>
-int host_pipeline(int ncol, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body)
+struct NoPrep { int operator()(int, int, int, hipStream_t) const { return 0; } };
+template <class Body, class Prep = NoPrep>
+int host_pipeline(int ncol, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body, Prep prep = Prep())
 {
     if (int rc = ensure_copy_streams()) return rc;
     size_t set = 0;
@@ -774,6 +836,9 @@ int host_pipeline(int ncol, int nbmax, std::vector<HostIn> &ins, std::vector<Hos
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
         bind(k);
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.cp_in, G.ev_cmp[k], 0));          // kernels of batch i-2 have read staging set k
+        // the entry's own host work for this batch (row scans, reductions; its results go to staging set k through G.cp_in): it runs on
+        // the calling thread while the copies and kernels of the batches before are in flight
+        if (int rc = prep(k, col0, nb, G.cp_in)) return rc;
         if (int rc = stage_in(ins, (size_t)ncol, (size_t)col0, (size_t)nb, G.cp_in)) return rc;
         HIP_TRY(hipEventRecord(G.ev_h2d[k], G.cp_in));
         HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_h2d[k], 0));
@@ -1119,6 +1184,7 @@ void rrtmg_lw_hip_finalize(void)
         for (int k = 0; k < 3; k++) { (void)hipStreamDestroy(G.swq[k]); (void)hipEventDestroy(G.ev_swq_done[k]); }
         (void)hipEventDestroy(G.ev_swq_go);
     }
+    if (G.h_tot) (void)hipHostFree(G.h_tot);
     G = State();
 }
 
@@ -1257,25 +1323,62 @@ int rrtmg_lw_hip_run_nomcica(
     const int nbmax = balanced_batch(ncol, std::min(G.batch, HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
     const size_t L = (size_t)nlay;
+    // What the copies need not carry (62 % of a column's bytes are taucld and tauaer, 2 x 16 nlay values):
+    //  * with inflglw >= 1 cldprop reads taucld only through the sum over the bands, tauctot (src/rrtmg_lw_cldprop.f90:173-186): the sum is
+    //    formed here, in the reference's order, on the host threads - one value per (column, layer) travels instead of sixteen;
+    //  * a (layer, band) row of tauaer - and with inflglw = 0 a layer of taucld - that is all zero for the batch's columns is not copied.
+    const bool use_tot = cloud && inflglw != 0;
     std::vector<HostIn> ins = {
         {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
         {h2ovmr, 1, L, 0}, {o3vmr, 1, L, 0}, {co2vmr, 1, L, 0}, {ch4vmr, 1, L, 0}, {n2ovmr, 1, L, 0}, {o2vmr, 1, L, 0},
         {cfc11vmr, 1, L, 0}, {cfc12vmr, 1, L, 0}, {cfc22vmr, 1, L, 0}, {ccl4vmr, 1, L, 0}, {emis, 1, 16, 0}, {tauaer, 1, 16 * L, 0},
-        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, NBND, L, 0}, {cloud ? cicewp : nullptr, 1, L, 0},
+        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, (size_t)(use_tot ? 1 : NBND), L, 0, use_tot}, {cloud ? cicewp : nullptr, 1, L, 0},
         {cloud ? cliqwp : nullptr, 1, L, 0}, {cloud ? reice : nullptr, 1, L, 0}, {cloud ? reliq : nullptr, 1, L, 0}};
     for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
+    if (use_tot && G.h_tot_doubles < 2 * L * (size_t)nbmax) {
+        if (G.h_tot) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipHostFree(G.h_tot)); G.h_tot = nullptr; G.h_tot_doubles = 0; }
+        HIP_TRY(hipHostMalloc((void **)&G.h_tot, 2 * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
+        G.h_tot_doubles = 2 * L * (size_t)nbmax;
+    }
+    for (auto &z : G.zrow) z.assign(17 * L, 0);
+    auto prep = [&](int k, int col0, int nb, hipStream_t cs) -> int {
+        unsigned char *zf = G.zrow[k].data();
+        scan_zero_rows(tauaer, 1, 16 * L, (size_t)ncol, (size_t)col0, (size_t)nb, zf);
+        ins[16].rowzero = zf;
+        if (cloud && !use_tot) {
+            scan_zero_rows(taucld, NBND, L, (size_t)ncol, (size_t)col0, (size_t)nb, zf + 16 * L);
+            ins[18].rowzero = zf + 16 * L;
+        }
+        if (use_tot) {
+            HIP_TRY(hipEventSynchronize(G.ev_h2d[k]));       // the copy of batch i - 2 has left the pinned scratch set k (this thread runs ahead of the device)
+            double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;
+            host_parallel([&](int t, int nt) {
+                const size_t n = L * (size_t)nb;
+                for (size_t e = n * t / nt; e < n * (t + 1) / nt; e++) {
+                    const size_t lay = e / (size_t)nb, c = e % (size_t)nb;
+                    const double *p = taucld + (size_t)NBND * ((size_t)col0 + c + (size_t)ncol * lay);
+                    double sum = 0.0;
+                    for (int ib = 0; ib < NBND; ib++) sum = sum + p[ib];
+                    tot[e] = sum;
+                }
+            });
+            HIP_TRY(hipMemcpyAsync(ins[18].d, tot, L * (size_t)nb * sizeof(double), hipMemcpyHostToDevice, cs));
+        }
+        return 0;
+    };
     std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
     for (size_t k = 0; k < 6; k++) if (!outs[k].h) return fail(RRTMG_LW_HIP_EARG, "null output array");
     auto body = [&](hipStream_t s, int nb, std::vector<HostIn> &in, std::vector<HostOut> &out_) -> int {
         GcmIn g{in[0].d, in[1].d, in[2].d, in[3].d, in[4].d, in[5].d, in[6].d, in[7].d, in[8].d, in[9].d, in[10].d,
-                in[11].d, in[12].d, in[13].d, in[14].d, in[15].d, in[17].d, in[18].d, in[19].d, in[20].d, in[21].d, in[22].d, in[16].d};
+                in[11].d, in[12].d, in[13].d, in[14].d, in[15].d, in[17].d, use_tot ? nullptr : in[18].d, in[19].d, in[20].d, in[21].d, in[22].d, in[16].d,
+                use_tot ? in[18].d : nullptr};
         ColIn c{};
         FluxOut out{out_[0].d, out_[1].d, out_[2].d, out_[3].d, out_[4].d, out_[5].d, out_[6].d, out_[7].d, nullptr, nullptr};
         return run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out);
     };
-    if (int rc = host_pipeline(ncol, nbmax, ins, outs, body)) return rc;
+    if (int rc = host_pipeline(ncol, nbmax, ins, outs, body, prep)) return rc;
     hipStream_t s = G.stream;
     return read_physics_error(s);
 }
@@ -1796,14 +1899,50 @@ int rrtmg_lw_hip_run_mcica_subcol(
         if (rc) return rc;
     }
     // 2. column batches
+    // What the copies need not carry (62 % of a column's bytes are taucld and tauaer, 2 x 16 nlay values):
+    //  * with inflglw >= 1 cldprop reads taucld only through the sum over the bands, tauctot (src/rrtmg_lw_cldprop.f90:173-186): the sum is
+    //    formed here, in the reference's order, on the host threads - one value per (column, layer) travels instead of sixteen;
+    //  * a (layer, band) row of tauaer - and with inflglw = 0 a layer of taucld - that is all zero for the batch's columns is not copied.
+    const bool use_tot = cloud && inflglw != 0;
     std::vector<HostIn> ins = {
         {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
         {h2ovmr, 1, L, 0}, {o3vmr, 1, L, 0}, {co2vmr, 1, L, 0}, {ch4vmr, 1, L, 0}, {n2ovmr, 1, L, 0}, {o2vmr, 1, L, 0},
         {cfc11vmr, 1, L, 0}, {cfc12vmr, 1, L, 0}, {cfc22vmr, 1, L, 0}, {ccl4vmr, 1, L, 0}, {emis, 1, 16, 0}, {tauaer, 1, 16 * L, 0},
-        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, NBND, L, 0}, {cloud ? cicewp : nullptr, 1, L, 0},
+        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, (size_t)(use_tot ? 1 : NBND), L, 0, use_tot}, {cloud ? cicewp : nullptr, 1, L, 0},
         {cloud ? cliqwp : nullptr, 1, L, 0}, {cloud ? reice : nullptr, 1, L, 0}, {cloud ? reliq : nullptr, 1, L, 0}};
     for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
+    if (use_tot && G.h_tot_doubles < 2 * L * (size_t)nbmax) {
+        if (G.h_tot) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipHostFree(G.h_tot)); G.h_tot = nullptr; G.h_tot_doubles = 0; }
+        HIP_TRY(hipHostMalloc((void **)&G.h_tot, 2 * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
+        G.h_tot_doubles = 2 * L * (size_t)nbmax;
+    }
+    for (auto &z : G.zrow) z.assign(17 * L, 0);
+    auto prep = [&](int k, int col0, int nb, hipStream_t cs) -> int {
+        unsigned char *zf = G.zrow[k].data();
+        scan_zero_rows(tauaer, 1, 16 * L, (size_t)ncol, (size_t)col0, (size_t)nb, zf);
+        ins[16].rowzero = zf;
+        if (cloud && !use_tot) {
+            scan_zero_rows(taucld, NBND, L, (size_t)ncol, (size_t)col0, (size_t)nb, zf + 16 * L);
+            ins[18].rowzero = zf + 16 * L;
+        }
+        if (use_tot) {
+            HIP_TRY(hipEventSynchronize(G.ev_h2d[k]));       // the copy of batch i - 2 has left the pinned scratch set k (this thread runs ahead of the device)
+            double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;
+            host_parallel([&](int t, int nt) {
+                const size_t n = L * (size_t)nb;
+                for (size_t e = n * t / nt; e < n * (t + 1) / nt; e++) {
+                    const size_t lay = e / (size_t)nb, c = e % (size_t)nb;
+                    const double *p = taucld + (size_t)NBND * ((size_t)col0 + c + (size_t)ncol * lay);
+                    double sum = 0.0;
+                    for (int ib = 0; ib < NBND; ib++) sum = sum + p[ib];
+                    tot[e] = sum;
+                }
+            });
+            HIP_TRY(hipMemcpyAsync(ins[18].d, tot, L * (size_t)nb * sizeof(double), hipMemcpyHostToDevice, cs));
+        }
+        return 0;
+    };
     std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
     if (int rc = stage_alloc(ins, outs, (size_t)nbmax)) return rc;

@@ -107,6 +107,7 @@ struct GcmIn {
     const double *play, *plev, *tlay, *tlev, *tsfc, *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;
     const double *cfc11vmr, *cfc12vmr, *cfc22vmr, *ccl4vmr, *emis;
     const double *cldfr, *taucld, *cicewp, *cliqwp, *reice, *reliq, *tauaer;
+    const double *tauctot = nullptr;    // (ncol,nlay), optional: the sum of taucld over the bands where the caller has formed it (host entry, inflglw >= 1); taucld is null then
 };
 // prepared-column inputs (device pointers, column stride = ncol_total), reference src/rrtmg_lw.1col.f90:497-580
 struct ColIn {
@@ -246,6 +247,7 @@ __device__ __forceinline__ bool cloud_layer_enters(double cf, double cwp, double
 template <bool GCM>
 __device__ __forceinline__ double cloud_tauctot(const GcmIn &g, const ColIn &c, size_t gc, size_t gi, int nct, int lay)
 {
+    if constexpr (GCM) { if (g.tauctot) return g.tauctot[gi]; }
     double tauctot = 0.0;                               // taucld (16,ncol,nlay) | tauc (ncol,16,nlayers)
     for (int ib = 0; ib < NBND; ib++)
         tauctot = tauctot + (GCM ? g.taucld[ib + (size_t)NBND * gi] : c.tauc[gc + (size_t)nct * (ib + (size_t)NBND * (lay - 1))]);
@@ -1305,7 +1307,10 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
         //   p1: odtot < 0.06              total from the series
         //   p2: else if odepth <= 0.06    total = odepth + odcld from the table
         //   p3: else                      odepth := tau_tbl(itgas), total from the table
-        constexpr int QC = RRLW_CLOUD_QUADS < NQ ? RRLW_CLOUD_QUADS : NQ;
+        // (McICA, CLOUD 2 / 3: every g-point has its own cloud optical depth - eight more live doubles per quad in flight; with two quads
+        // the kernel spilled 13-18 registers)
+        constexpr int QCW = CLOUD >= 2 ? 1 : RRLW_CLOUD_QUADS;
+        constexpr int QC = QCW < NQ ? QCW : NQ;
 #pragma unroll
         for (int q0 = 0; q0 < NQ; q0 += QC) {
             constexpr int GC = 4 * QC;
@@ -1381,9 +1386,16 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
     const double taua = a.tauaer[gcx + (size_t)a.nct * ((lay - 1) + (size_t)W.nlay * (B - 1))];
     unsigned gbits = 0u;
     if constexpr (CLOUD == 3) {
-        constexpr int g0 = band_g0(B), ng = BT<B>::ng, w0 = g0 >> 5;
-        const unsigned long long lo = mw[w0], hi = w0 < 4 ? mw[w0 + 1 < 5 ? w0 + 1 : 4] : 0u;
-        gbits = (unsigned)(((lo | (hi << 32)) >> (g0 & 31)) & ((1ull << ng) - 1ull));
+        // the band's bits of the sub-column mask: the one or two words that hold them, read here (all five held from the top of the kernel
+        // ended up in scratch memory)
+        (void)mw;
+        constexpr int g0 = band_g0(B), ng = BT<B>::ng, w0 = g0 >> 5, w1 = (g0 + ng - 1) >> 5;
+        if (cloudy) {
+            const unsigned *mrow = W.mask + (size_t)(lay - 1) * W.mask_stride + W.mask_col0 + gcx;
+            const unsigned long long lo = mrow[(size_t)w0 * W.nlay * W.mask_stride];
+            const unsigned long long hi = w1 != w0 ? mrow[(size_t)w1 * W.nlay * W.mask_stride] : 0u;
+            gbits = (unsigned)(((lo | (hi << 32)) >> (g0 & 31)) & ((1ull << ng) - 1ull));
+        }
     }
     if (lower) {
         constexpr int N = region_nrows(BT<B>::lo, true);
@@ -1563,13 +1575,7 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
     if (CLOUD) cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
     // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
     const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
-    unsigned mw[5] = {0u, 0u, 0u, 0u, 0u};
-    if constexpr (CLOUD == 3) {
-        if (cloudy) {
-#pragma unroll
-            for (int w = 0; w < 5; w++) mw[w] = W.mask[((size_t)w * W.nlay + (lay - 1)) * W.mask_stride + W.mask_col0 + gc];
-        }
-    }
+    const unsigned mw[5] = {0u, 0u, 0u, 0u, 0u};
 #ifdef RRLW_LAYER_STAMPS
     if ((threadIdx.x & 63) == 0) { for (int i = 0; i < NSTAMP; i++) s_stamp[(threadIdx.x >> 6) * (NSTAMP + 1) + i] = 0ull; }
     STAMP(-1);
@@ -2500,8 +2506,15 @@ __host__ __device__ constexpr int sweepc_lds_bytes(int PHASE, bool IDRV, int nb,
 #ifndef RRLW_SWEEPC_SPLIT
 #define RRLW_SWEEPC_SPLIT 1
 #endif
+#ifndef RRLW_SWEEPC_SPLIT3
+#define RRLW_SWEEPC_SPLIT3 0
+#endif
 __host__ __device__ constexpr int sweepc_nt(int NQ, int PHASE, bool IDRV)
 {
+    // 12 g-points x {total, clear} x {radiance, d/dT} in one thread need 256 registers + 70 accumulation registers as spill space: one wave
+    // per SIMD.  Three threads of one quad (RRLW_SWEEPC_SPLIT3 = 1: three waves per SIMD, nothing spilled) repeat the level's Planck terms,
+    // fraction rows and temperature loads three times: 8.26 ms against 5.59 per 5e5 137-layer columns - the one-wave form stays.
+    if (RRLW_SWEEPC_SPLIT3 && NQ == 3 && PHASE == 2 && IDRV) return 3;
     return (RRLW_SWEEPC_SPLIT && NQ == 4 && (PHASE == 2 || PHASE == 0)) ? 2 : 1;
 }
 // bands per group: what fits the wave slots of the most register-hungry instantiation (phase 2 with d/dT)
@@ -2538,7 +2551,7 @@ template <int G> struct SweepcLev { double tl, tz; unsigned w; };
 template <int NQ, int PHASE, bool IDRV, int NT = 1>
 __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_waves(NQ / NT, PHASE, IDRV)) void k_sweepc(DevTables T, Workspace W, SweepArgs a)
 {
-    static_assert(NQ % NT == 0 && (NT == 1 || NT == 2), "threads per band");
+    static_assert(NQ % NT == 0 && (NT == 1 || NT == 2 || NT == 3), "threads per band");
     constexpr int G = NQ / NT, NG = 4 * G, NC = RRLW_SWEEPC_CODES;
     constexpr bool DOWN = PHASE != 2, UP = PHASE != 1, TWO = PHASE == 2;       // TWO: total and clear-sky streams differ
     constexpr int NVAL = sweepc_nval(PHASE, IDRV);
@@ -2636,8 +2649,9 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
                 const bool deriv = IDRV && !DN && val >= (TWO ? 2 : 1);
                 double sum = 0.0;
                 for (int q = 0; q < nb; q++) {
-                    double pq = r[(unsigned)(q * NT * NC * ncw)];
-                    if constexpr (NT == 2) pq = pq + r[(unsigned)((q * NT + 1) * NC * ncw)];
+                    double pq = r[(unsigned)(q * NT * NC * ncw)];            // (the band's parts in the order one thread adds its quads: pairs first)
+                    if constexpr (NT >= 2) pq = pq + r[(unsigned)((q * NT + 1) * NC * ncw)];
+                    if constexpr (NT == 3) pq = pq + r[(unsigned)((q * NT + 2) * NC * ncw)];
                     double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
                     if (deriv) v = v * T.fluxfac;
                     sum = q == 0 ? v : sum + v;
@@ -2818,6 +2832,9 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
 //            1.9x the time per clear level (per-quad duplication of the level's Planck terms, conditional loads with full waits, two
 //            barriers per four levels).
 // ------------------------------------------------------------------------------------------------
+#ifndef RRLW_SWEEPZ_CT_SLOTS
+#define RRLW_SWEEPZ_CT_SLOTS 1
+#endif
 #ifndef RRLW_SWEEPZ_G2
 #define RRLW_SWEEPZ_G2 0          // 1: two quads per thread for bands of 4 and 2 quads (253 registers, two waves per SIMD: measured slower)
 #endif
@@ -2995,7 +3012,11 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
 
     SweepzLev cur;
     cur.w = 0u;
-    scr4 cc[G][NC], ct[G][NC];
+    // code slots: NC levels of the gas codes in flight, NCT of the total (gas + cloud) ones (a second slot of those put the rtrnmr
+    // instantiations 3-5 registers over their 168: scratch reloads count in vmcnt and drain the prefetches)
+    constexpr int NCT = RRLW_SWEEPZ_CT_SLOTS;
+    static_assert(NCT == 1 || NCT == NC, "slots of the total-optical-depth codes");
+    scr4 cc[G][NC], ct[G][NCT];
     // One level.  DN: downward (Planck difference towards the interface below, partial of level lev - 1, istcldd = flag bit 1), else
     // upward (istcld = bit 2).  The overlap factors of the level are requested first and used last.
     auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) __attribute__((always_inline)) {
@@ -3043,7 +3064,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         for (int k = 0; k < G; k++) {
             scr4 ck, ckt;
 #pragma unroll
-            for (int c = 0; c < NC; c++) if (c == slot) { ck = cc[k][c]; ckt = ct[k][c]; }
+            for (int c = 0; c < NC; c++) if (c == slot) { ck = cc[k][c]; ckt = ct[k][NCT == 1 ? 0 : c]; }
             float2 e[4], et[4];
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) e[jj] = RRLW_LUT_ENTRY(s_lut, code_index(ck.v[jj]));
@@ -3052,9 +3073,9 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                 for (int jj = 0; jj < 4; jj++) et[jj] = RRLW_LUT_ENTRY(s_lut, min(code_index(ckt.v[jj]), (unsigned)NTBL));
             }
             {
-                const scr4 nx = ld_c(sC, lev + NC * dir, k), nxt = ld_c(sCt, lev + NC * dir, k);
+                const scr4 nx = ld_c(sC, lev + NC * dir, k), nxt = ld_c(sCt, lev + NCT * dir, k);
 #pragma unroll
-                for (int c = 0; c < NC; c++) if (c == slot) { cc[k][c] = nx; ct[k][c] = nxt; }
+                for (int c = 0; c < NC; c++) if (c == slot) { cc[k][c] = nx; ct[k][NCT == 1 ? 0 : c] = nxt; }
             }
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
@@ -3146,7 +3167,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         for (int c = 0; c < NC; c++) {
             if (c == NC - 1) fill_t(bin_tag, first, DN ? 0 : 1, cur);
 #pragma unroll
-            for (int k = 0; k < G; k++) { cc[k][c] = ld_c(sC, first + c * dir, k); ct[k][c] = ld_c(sCt, first + c * dir, k); }
+            for (int k = 0; k < G; k++) { cc[k][c] = ld_c(sC, first + c * dir, k); if (c < NCT) ct[k][c] = ld_c(sCt, first + c * dir, k); }
         }
         int n = 0;
         for (; n + NC <= count; n += NC) {
@@ -3194,9 +3215,14 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     // ------------------------------------------------------------------ upward: layers 1 .. ltop
     if (any_bin) sweep(true_type{}, false_type{}); else sweep(false_type{}, false_type{});
     if (incol) {                    // upward radiances at level ltop for k_sweepc<., 2>
+        // (the hand-off address is formed again from the lane's column offset, hidden from common-subexpression elimination: held in
+        // registers from the first use at the top of the kernel it cost the rtrnmr instantiations the two registers they were over budget)
+        unsigned o4 = off4;
+        asm volatile("" : "+v"(o4));
+        double2 *hand_up = reinterpret_cast<double2 *>(W.hand) + ((size_t)quad * ncb + (o4 >> 2)) * 2;
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            double2 *h = hand + (size_t)k * ncb * 2;
+            double2 *h = hand_up + (size_t)k * ncb * 2;
             h[hstream] = make_double2(rad[4 * k], rad[4 * k + 1]);        h[hstream + 1] = make_double2(rad[4 * k + 2], rad[4 * k + 3]);
             h[2 * hstream] = make_double2(radc[4 * k], radc[4 * k + 1]);  h[2 * hstream + 1] = make_double2(radc[4 * k + 2], radc[4 * k + 3]);
             if constexpr (IDRV) {

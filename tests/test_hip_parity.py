@@ -323,6 +323,42 @@ def test_cloud_field_variants(hip, oracle, config):
     _compare_thin_layers(got, ref, d, d["idrv"], config)      # (the towers reach layer 45 of 72: 2.5 hPa, 0.35 hPa thick)
 
 
+def test_host_entry_skips_zero_rows_and_sums_taucld(hip, oracle):
+    """The host-pointer entry does not copy (layer, band) rows of tauaer that are all zero for a column batch and, with inflglw >= 1,
+    ships the band sum of taucld (cldprop's tauctot, src/rrtmg_lw_cldprop.f90:173-186) instead of taucld: isolated non-zero rows, a row
+    that is non-zero in one batch only, -0.0 entries (not +0.0: copied), and the corner where the layer enters cldprop through
+    tauctot alone (water path below cldmin = 1e-20, tauctot above / below it)."""
+    ncol, nlay = 700, 40
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=3)
+    rng = np.random.default_rng(8)
+    ta = np.zeros((ncol, nlay, 16))
+    ta[:, 3, 5] = 0.02 * rng.random(ncol)             # one isolated (layer, band) row
+    ta[:, 10:13, :] = 0.01 * rng.random((ncol, 3, 16))  # a run of rows
+    ta[300:, 20, 0] = 0.03                              # non-zero in the later batches only
+    ta[5, 30, 7] = -0.0                                 # a negative zero is data
+    ta[650, 39, 15] = 1e-300
+    d["tauaer"] = np.asfortranarray(ta)
+    # cloud layers that enter cldprop through tauctot only: tiny water paths, taucld summing to >= / < cldmin
+    cf, ci, cl = (np.array(d[k]) for k in ("cldfr", "cicewp", "cliqwp"))
+    tc = np.zeros((16, ncol, nlay))
+    cf[::7, 20] = 0.4; ci[::7, 20] = 1e-25; cl[::7, 20] = 0.0
+    tc[:, ::14, 20] = 1e-21                             # sum 1.6e-20 >= cldmin: enters (ncbands follows iceflag) ...
+    tc[:, 7::14, 20] = 1e-22                            # ... sum 1.6e-21 < cldmin: does not
+    d["cldfr"], d["cicewp"], d["cliqwp"], d["taucld"] = (np.asfortranarray(a) for a in (cf, ci, cl, tc))
+    d["iceflglw"] = 1                                   # five cloud bands unless another layer sets sixteen
+    hip.set_batch(256)
+    try:
+        for inflag in (2, 1, 0):
+            d["inflglw"] = inflag
+            if inflag == 0:
+                tc0 = np.array(d["taucld"]); tc0[:, :, 5:9] = 0.3 * rng.random((16, ncol, 4)) * (cf[None, :, 5:9] > 0); d["taucld"] = np.asfortranarray(tc0)
+            got = hip.rrtmg_lw_from_dict(d, icld=2)
+            ref = oracle.rrtmg_lw(ncol, nlay, 2, d["idrv"], d)
+            _compare(got, ref, d["idrv"], f"host entry, zero rows, inflag {inflag}")
+    finally:
+        hip.set_batch(262144)
+
+
 def test_device_entry_from_two_streams(hip, oracle):
     """Two callers enqueue device-resident work on different streams without synchronising in between: the driver orders the
     second call after the first (they share the workspace)."""

@@ -1,7 +1,7 @@
 export RRTMG_LW_ALLOW_STANDIN=1
-for l in pass4 ko_ldsu; do echo "== $l"; RRTMG_LW_HIP_LIB=$PWD/exp/lib_$l.so timeout -k 10 300 python bench.py --check --no-cpu-baseline --host-cols 0 --steps 5 --warmup 1 2> gpurun_out/_err.txt | python -c "
+for l in ct2 ct1 ct1b; do echo "== $l"; RRTMG_LW_HIP_LIB=$PWD/exp/lib_$l.so timeout -k 10 300 python bench.py --check --no-cpu-baseline --host-cols 0 --steps 5 --warmup 1 2> gpurun_out/_err.txt | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('ms/step',d['ms_per_step'], {k:v for k,v in d['path']['kernels'].items() if 'layer' in k})
+        d=json.loads(l); print('ms/step',d['ms_per_step'], d['path']['families'], {k:v for k,v in d['path']['kernels'].items() if 'sweepz' in k})
 "; grep "check vs" gpurun_out/_err.txt; done
