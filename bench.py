@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="initialise RCCL and run the all-gather even with one rank (plumbing check under torchrun with N = 1)")
     ap.add_argument("--check", action="store_true", help="compare 256 columns with the CPU oracle before timing")
+    ap.add_argument("--n1-prototype", action="store_true",
+                    help="measurement only: cloud-free calls through the one-column-per-wavefront prototype k_n1 (profiles/round2_n1_expf.md)")
     ap.add_argument("--host-cols", type=int, default=131072,
                     help="columns of the end-to-end (host-pointer, PCIe-inclusive) measurement after the timed region; 0 = skip")
     args = ap.parse_args()
@@ -99,6 +101,8 @@ def main():
 
     # (explicit choice of the coefficient file: the line's config.kdata says which one ran)
     api.rrtmg_lw_ini(1004.0, kdata=api.REAL_KDATA if os.path.exists(api.REAL_KDATA) else api.STANDIN_KDATA, device=local_rank)
+    if args.n1_prototype:
+        api.set_n1_prototype(True)
     if args.batch:
         api.set_batch(args.batch)
     if args.no_overlap:
@@ -341,7 +345,8 @@ def main():
                                         f"sharded {world}x{per}",
                                ncol_total=args.ncol, nlay=nlay, columns_per_gpu=per, parallelism=f"columns/{world}",
                                gather="rccl all_gather_into_tensor of the packed outputs, overlapped with the next step's kernels" if do_gather else "none",
-                               kdata="stand-in (real k-data absent from the reference mount)" if api.kdata_is_standin() else "real"),
+                               kdata="stand-in (real k-data absent from the reference mount)" if api.kdata_is_standin() else "real",
+                               sweeps="k_n1 prototype (measurement)" if args.n1_prototype else "production"),
                    roofline=roof, compute=compute, path=path, cpu_baseline=cpu, end_to_end=e2e)
         print(json.dumps(res))
     if use_dist:

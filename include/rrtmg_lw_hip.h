@@ -45,6 +45,16 @@ extern "C" {
  * cpdair in J kg-1 K-1 sets heatfac (src/rrtmg_lw_init.f90:298). */
 int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, double cpdair, int device);
 
+/* The same for SEVERAL GPUs driven by one process (SURVEY.md 8b `ndev`; the reference's calling model is one serial `do iplon` loop,
+ * src/rrtmg_lw_rad.nomcica.f90:472: a non-MPI host has one process).  devices[0 .. ndev-1] are HIP ordinals; the host-pointer entries
+ * rrtmg_lw_hip_run_nomcica and rrtmg_lw_hip_run_mcica then split their columns into ndev contiguous blocks and feed every device from
+ * its own host thread (its own PCIe link, copy streams and workspace); every other entry works on devices[0].  An ordinal may be
+ * listed more than once ("virtual devices": separate workspaces and streams on one GPU - how the fan-out is tested on a one-GPU box).
+ * The Fortran shim calls this from rrtmg_lw_ini when RRTMG_LW_NDEV is set (devices RRTMG_LW_DEVICE, +1, ...; RRTMG_LW_VIRTUAL_DEVICES=1
+ * keeps them all on RRTMG_LW_DEVICE). */
+int rrtmg_lw_hip_init_devices(const char *static_tables_path, const char *kdata_path, double cpdair, int ndev, const int *devices);
+int rrtmg_lw_hip_num_devices(void);     /* 0 before initialisation */
+
 /* 1 if the loaded k-data is the synthetic stand-in (fluxes not physical), 0 if real, -1 if not initialised */
 int rrtmg_lw_hip_kdata_is_standin(void);
 
@@ -157,7 +167,7 @@ int rrtmg_lw_hip_get_alpha(int ncol, int nlay, int icld, int idcor, double decor
  * exponential-random overlap (alpha may be NULL unless icld is 4 or 5); icld 0 returns without touching the
  * outputs.  irng is in/out (any non-zero value becomes 1): 0 = kissvec, one stream per column seeded from
  * its four lowest layer pressures; 1 = one Mersenne-Twister stream seeded with permuteseed, consumed in
- * (sub-column, column, layer) order.  kissvec: 4 <= nlay <= 639 (the reference's mxlay is 203); a permuteseed that differs
+ * (sub-column, column, layer) order.  kissvec: 4 <= nlay <= 603 (modules/parrrtm.f90:31; the column driver's mxlay is 203); a permuteseed that differs
  * from the previous call's rebuilds a small jump-ahead table on the host (one device synchronisation). */
 int rrtmg_lw_hip_mcica_subcol(
     int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
@@ -228,8 +238,14 @@ int rrtmg_lw_hip_set_batch(int ncol_batch);
  * LDS, all vector registers), so the two do not share one (measured: 1-2 % faster on 1e6 cloudy columns).  on = 0 frees the second set at the next workspace
  * allocation. */
 int rrtmg_lw_hip_set_overlap(int on);
-/* Bytes of device workspace currently allocated. */
+/* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (about 0.2 MB per column of the batch
+ * at 72 layers, 0.37 MB at 137: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer
+ * (<= 512 MB, or one slab) and the cached chunk states (<= 2 x 180 MB) of the Mersenne-Twister stream. */
 long long rrtmg_lw_hip_workspace_bytes(void);
+/* Measurement only: 1 = cloud-free GCM calls take the prototype of the "one column per wavefront" mapping (k_n1, profiles/round2_n1_expf.md)
+ * instead of the production sweeps.  Off after every rrtmg_lw_hip_init; rrtmg_lw_hip_n1_prototype() reports it. */
+int rrtmg_lw_hip_set_n1_prototype(int on);
+int rrtmg_lw_hip_n1_prototype(void);
 /* Number of g-point chunks the sweep kernel distributes over threads (one partial flux slab each). */
 int rrtmg_lw_hip_num_chunks(void);
 /* g-points of this build: 140 (librrtmg_lw_hip.so, the reference's shipped model) or 256 (librrtmg_lw_hip_g256.so: every band keeps its 16

@@ -114,6 +114,25 @@ def host_unregister(a):
     _check(lib().rrtmg_lw_hip_host_unregister(C.c_void_p(a.ctypes.data)))
 
 
+def set_n1_prototype(on):
+    """Measurement only: cloud-free calls through the prototype of the one-column-per-wavefront mapping (k_n1)."""
+    _check(lib().rrtmg_lw_hip_set_n1_prototype(C.c_int(1 if on else 0)))
+
+
+def init_devices(devices, cpdair=1004.0, kdata=None, static=STATIC_BLOB):
+    """rrtmg_lw_ini for several GPUs driven by this one process (rrtmg_lw_hip_init_devices): the host-pointer entries split their
+    columns over `devices` (HIP ordinals; an ordinal may repeat: virtual devices on one GPU)."""
+    global _initialised
+    kdata = kdata or default_kdata()
+    arr = (C.c_int * len(devices))(*[int(v) for v in devices])
+    _check(lib().rrtmg_lw_hip_init_devices(static.encode(), kdata.encode(), C.c_double(cpdair), C.c_int(len(devices)), arr))
+    _initialised = True
+
+
+def num_devices():
+    return int(lib().rrtmg_lw_hip_num_devices())
+
+
 def set_overlap(on):
     _check(lib().rrtmg_lw_hip_set_overlap(C.c_int(1 if on else 0)))
 
@@ -416,10 +435,16 @@ def column_mcica_samples(col, samples, irng=1, alpha=None):
     return run_columns_mcica([col] * len(subs), subs), subs
 
 
-def finalize():
+def finalize(selected_only=False):
+    """Release the device state of every library this process has loaded (the 140- and the 256-g-point build keep separate states:
+    workspace, pinned staging, generator caches, streams); selected_only = True: only that of the library select_gpoints chose."""
     global _initialised
-    if _lib is not None:
-        _lib.rrtmg_lw_hip_finalize()
+    if selected_only:
+        if _lib is not None:
+            _lib.rrtmg_lw_hip_finalize()
+        return
+    for h in _libs.values():
+        h.rrtmg_lw_hip_finalize()
     _initialised = False
 
 

@@ -58,7 +58,7 @@ struct State {
     bool split_sweep = false;    // run the sweeps / k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: a sweep
                                  // workgroup owns a CU (transmittance table in LDS), so the two do not share a CU (measured: 1-2 % gain for twice the code scratch)
     bool sweep_attrs = false;    // the sweeps' dynamic-LDS limit has been raised on this device
-    bool n1 = false;             // RRTMG_LW_N1=1: cloud-free calls take the north-star-mapping prototype k_n1 (measurement only)
+    bool n1 = false;             // rrtmg_lw_hip_set_n1_prototype(1): cloud-free calls take the north-star-mapping prototype k_n1 (measurement only)
     bool ws_two_scr = false;     // the workspace holds the second scratch set that split_sweep needs
     // host-entry staging
     void *stage_base = nullptr;
@@ -76,7 +76,15 @@ struct State {
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> evpool;
 };
-State G;
+// One State per device the library drives (rrtmg_lw_hip_init: one; rrtmg_lw_hip_init_devices: several GPUs from one process, SURVEY.md 8b
+// `ndev`).  Every function below works on the calling thread's CURRENT state `G`: state 0 for every entry, and inside the host-pointer
+// entries each worker thread of the fan-out (nomcica_host) takes the state of the device it feeds.  The same physical device may appear
+// in several states ("virtual devices": separate workspaces, streams and table copies - how the fan-out is tested on a one-GPU box).
+constexpr int MAXDEV = 16;
+State g_states[MAXDEV];
+int g_ndev = 1;
+thread_local State *g_cur = &g_states[0];
+#define G (*g_cur)
 std::mutex g_mu;
 
 // aggregation of small calls (rrtmg_lw_hip_queue_*): recorded chunks and the pinned staging set they are packed into
@@ -807,8 +815,8 @@ int ensure_copy_streams()
 // kernels of one batch whose staged arrays start at column 0.
 struct NoPrep { int operator()(int, int, int, hipStream_t) const { return 0; } };
 template <class Body, class Prep = NoPrep>
-int host_pipeline(int ncol, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body, Prep prep = Prep())
-{
+int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body, Prep prep = Prep())
+{   // columns [c0, c1) of arrays that are ncol columns wide
     if (int rc = ensure_copy_streams()) return rc;
     size_t set = 0;
     for (auto &a : ins) set += a.h ? a.inner * a.rows * (size_t)nbmax : 0;
@@ -832,8 +840,8 @@ int host_pipeline(int ncol, int nbmax, std::vector<HostIn> &ins, std::vector<Hos
         return 0;
     };
     int i = 0, prev_col0 = 0, prev_nb = 0;
-    for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
-        const int nb = std::min(nbmax, ncol - col0), k = i & 1;
+    for (int col0 = c0; col0 < c1; col0 += nbmax, i++) {
+        const int nb = std::min(nbmax, c1 - col0), k = i & 1;
         bind(k);
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.cp_in, G.ev_cmp[k], 0));          // kernels of batch i-2 have read staging set k
         // the entry's own host work for this batch (row scans, reductions; its results go to staging set k through G.cp_in): it runs on
@@ -899,6 +907,7 @@ struct MtStates {
     size_t cap = 0;                     // states allocated
     unsigned long long *polys = nullptr;   // [32][MT_PW]
     unsigned long long used = 0;        // last use (the older set makes room)
+    size_t bytes() const { return (dev ? cap * (size_t)MT_NW * sizeof(unsigned) : 0) + (polys ? (size_t)32 * MT_PW * sizeof(unsigned long long) : 0); }
 };
 MtStates g_mt[2];
 mtj::Poly g_mt_phi{};
@@ -1063,9 +1072,9 @@ int generate_mask(hipStream_t s, int ncol, int nlay, int icld, int permuteseed, 
         unsigned long long C = 0;
         unsigned *states = nullptr;
         if (int rc = mt_states(s, (uint32_t)permuteseed, per, &M, &C, &states)) return rc;
-        // as many slabs per launch as fit a 4 GiB buffer of deviates: a small call's 140 slabs are a few launches instead of 140, a large
+        // as many slabs per launch as fit a 512 MB buffer of deviates (a single slab if it is larger): a small call's 140 slabs are a few launches instead of 140, a large
         // one's launches hold enough chunks (one wavefront each) to fill the device
-        const int ns = (int)std::max<unsigned long long>(1ull, std::min<unsigned long long>((unsigned long long)NGPT, (4ull << 30) / (per * 8ull)));
+        const int ns = (int)std::max<unsigned long long>(1ull, std::min<unsigned long long>((unsigned long long)NGPT, (512ull << 20) / (per * 8ull)));     // slabs per pass: at most 512 MB of deviates
         const size_t need = (size_t)ns * per * 8;
         if (G.rnd_bytes < need) {
             if (G.d_rnd) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.d_rnd)); G.d_rnd = nullptr; G.rnd_bytes = 0; }
@@ -1099,9 +1108,8 @@ extern "C" {
 
 const char *rrtmg_lw_hip_last_error(void) { return G.err.c_str(); }
 
-int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, double cpdair, int device)
+static int init_state(const char *static_tables_path, const char *kdata_path, double cpdair, int device)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(RRTMG_LW_HIP_ENODEVICE, "no HIP device available (this library has no CPU path)");
@@ -1136,33 +1144,72 @@ int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, do
     D.heatfac = G.H.heatfac; D.fluxfac = G.H.fluxfac; D.oneminus = G.H.oneminus; D.bpade = G.H.bpade;
     if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; G.ws_mc = false; }
     G.device = device;
-    {
-        const char *e = std::getenv("RRTMG_LW_N1");
-        G.n1 = e && e[0] == '1';
-    }
+    G.n1 = false;
     G.init = true;
     G.err.clear();
     return 0;
 }
 
+static void finalize_state();
+
+int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, double cpdair, int device)
+{
+    return rrtmg_lw_hip_init_devices(static_tables_path, kdata_path, cpdair, 1, &device);
+}
+
+// Several GPUs from one process: state d drives devices[d].  The host-pointer entries rrtmg_lw_hip_run_nomcica / _run_mcica split
+// their columns into ndev contiguous blocks, one host thread and one device (its own PCIe link, copy streams, workspace) per block; the
+// device-pointer entries, the queue and the sub-column generator stay on devices[0].
+int rrtmg_lw_hip_init_devices(const char *static_tables_path, const char *kdata_path, double cpdair, int ndev, const int *devices)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cur = &g_states[0];
+    if (ndev < 1 || ndev > MAXDEV || !devices) return fail(RRTMG_LW_HIP_EARG, "ndev must be 1..%d", MAXDEV);
+    for (int d = ndev; d < g_ndev; d++) { g_cur = &g_states[d]; finalize_state(); }      // states of an earlier, larger set
+    g_cur = &g_states[0];
+    int rc = 0;
+    for (int d = 0; d < ndev && rc == 0; d++) {
+        g_cur = &g_states[d];
+        rc = init_state(static_tables_path, kdata_path, cpdair, devices[d]);
+        if (rc != 0 && d > 0) g_states[0].err = G.err;
+    }
+    g_cur = &g_states[0];
+    if (rc == 0) g_ndev = ndev;
+    (void)hipSetDevice(g_states[0].device >= 0 ? g_states[0].device : 0);
+    return rc;
+}
+
+int rrtmg_lw_hip_num_devices(void) { return g_states[0].init ? g_ndev : 0; }
+
 int rrtmg_lw_hip_kdata_is_standin(void) { return G.init ? (G.H.standin ? 1 : 0) : -1; }
 
 void rrtmg_lw_hip_finalize(void)
 {
-    ENTRY_LOCK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int d = g_ndev - 1; d >= 0; d--) { g_cur = &g_states[d]; finalize_state(); }
+    g_cur = &g_states[0];
+    g_ndev = 1;
+}
+
+static void finalize_state()
+{
     if (!G.init) return;
+    const bool first = g_cur == &g_states[0];
+    (void)hipSetDevice(G.device);
     (void)hipDeviceSynchronize();
     if (G.ws_base) (void)hipFree(G.ws_base);
     if (G.stage_base) (void)hipFree(G.stage_base);
-    if (Q.pinned) { (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
-    Q.chunks.clear(); Q.ncol = 0; Q.open = false;
-    if (G.mask) (void)hipFree(G.mask);
-    if (g_kiss_table.dev) { (void)hipFree(g_kiss_table.dev); g_kiss_table = KissTable{}; }
-    for (MtStates &S : g_mt) {
-        if (S.dev) (void)hipFree(S.dev);
-        if (S.polys) (void)hipFree(S.polys);
-        S = MtStates{};
+    if (first) {            // the queue and the generator's caches live on the first device
+        if (Q.pinned) { (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
+        Q.chunks.clear(); Q.ncol = 0; Q.open = false;
+        if (g_kiss_table.dev) { (void)hipFree(g_kiss_table.dev); g_kiss_table = KissTable{}; }
+        for (MtStates &S : g_mt) {
+            if (S.dev) (void)hipFree(S.dev);
+            if (S.polys) (void)hipFree(S.polys);
+            S = MtStates{};
+        }
     }
+    if (G.mask) (void)hipFree(G.mask);
     if (G.d_rnd) { (void)hipFree(G.d_rnd); G.d_rnd = nullptr; G.rnd_bytes = 0; }
     if (G.d_ktab) (void)hipFree(G.d_ktab);
     if (G.d_stat) (void)hipFree(G.d_stat);
@@ -1192,7 +1239,7 @@ int rrtmg_lw_hip_set_batch(int ncol_batch)
 {
     if (ncol_batch < 64) return fail(RRTMG_LW_HIP_EARG, "batch must be >= 64 columns");
     if (ncol_batch > 64 * SORT_MAXBLK) return fail(RRTMG_LW_HIP_EARG, "batch must be <= %d columns", 64 * SORT_MAXBLK);      // k_blocksort orders a batch's 64-column blocks in LDS
-    G.batch = ncol_batch;
+    for (int d = 0; d < MAXDEV; d++) g_states[d].batch = ncol_batch;
     return 0;
 }
 
@@ -1214,11 +1261,34 @@ int rrtmg_lw_hip_debug_stamps(unsigned long long *out, int n)
 int rrtmg_lw_hip_set_overlap(int on)
 {
     ENTRY_LOCK;
-    G.split_sweep = on != 0;       // the second scratch set is allocated by the next call that needs it
+    for (int d = 0; d < MAXDEV; d++) g_states[d].split_sweep = on != 0;       // the second scratch set is allocated by the next call that needs it
     return 0;
 }
 
-long long rrtmg_lw_hip_workspace_bytes(void) { return (long long)(G.ws_bytes + G.stage_bytes); }
+// measurement only (tools/n1_expf_measure.sh, the prototype's GPU test): cloud-free GCM calls take k_n1 instead of the production sweeps.
+// An explicit call, not an environment variable: a stray variable in a job's environment must not change the numerical path.
+int rrtmg_lw_hip_set_n1_prototype(int on)
+{
+    ENTRY_LOCK;
+    G.n1 = on != 0;
+    return 0;
+}
+int rrtmg_lw_hip_n1_prototype(void) { return g_states[0].n1 ? 1 : 0; }
+
+// device memory the library holds right now, over all its devices: workspaces, host-entry staging, sub-column masks, the slab buffer and
+// the cached chunk states of the Mersenne-Twister stream, the kissvec jump table
+long long rrtmg_lw_hip_workspace_bytes(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t tot = 0;
+    for (int d = 0; d < g_ndev; d++) {
+        const State &S = g_states[d];
+        tot += S.ws_bytes + S.stage_bytes + S.mask_bytes + S.rnd_bytes;
+    }
+    for (const MtStates &M : g_mt) tot += M.bytes();
+    tot += g_kiss_table.dev ? sizeof(KissJump) * (KJ_NGROUP + 1) : 0;
+    return (long long)tot;
+}
 int rrtmg_lw_hip_num_chunks(void) { return NQUAD; }
 int rrtmg_lw_hip_gpoints(void) { return NGPT; }
 
@@ -1299,8 +1369,11 @@ int rrtmg_lw_hip_run_nomcica_device(
     return run_pipelined((hipStream_t)stream, ncol, nlay, mode, idrv, g, inflglw, iceflglw, liqflglw, out, nullptr);
 }
 
-int rrtmg_lw_hip_run_nomcica(
-    int ncol, int nlay, int *icld, int idrv,
+}   // extern "C"
+
+namespace {
+// columns [c0, c1) of the caller's host arrays (ncol columns wide) on the calling thread's current device state; no lock taken
+int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
     const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
     const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
     const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
@@ -1310,17 +1383,13 @@ int rrtmg_lw_hip_run_nomcica(
     double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
     double *duflx_dt, double *duflxc_dt)
 {
-    ENTRY_LOCK;
     if (int rc = check_common(ncol, nlay)) return rc;
-    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
-    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
-    if (*icld < 0 || *icld > 3) *icld = 2;
-    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
-    const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);
-    const bool cloud = *icld >= 1;          // inatm copies the cloud arrays only when icld >= 1 (:893-910)
+    HIP_TRY(hipDeviceSynchronize());        // asynchronous device-entry work of earlier calls shares the workspace
+    const int mode = icld == 0 ? 0 : (icld == 1 ? 1 : 2);
+    const bool cloud = icld >= 1;           // inatm copies the cloud arrays only when icld >= 1 (:893-910)
     // host arrays: the copies bound the rate (PCIe), and they overlap with the kernels only across batches - smaller batches than
     // the device-resident default
-    const int nbmax = balanced_batch(ncol, std::min(G.batch, HOST_BATCH));
+    const int nbmax = balanced_batch(c1 - c0, std::min(G.batch, HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
     const size_t L = (size_t)nlay;
     // What the copies need not carry (62 % of a column's bytes are taucld and tauaer, 2 x 16 nlay values):
@@ -1378,9 +1447,75 @@ int rrtmg_lw_hip_run_nomcica(
         FluxOut out{out_[0].d, out_[1].d, out_[2].d, out_[3].d, out_[4].d, out_[5].d, out_[6].d, out_[7].d, nullptr, nullptr};
         return run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out);
     };
-    if (int rc = host_pipeline(ncol, nbmax, ins, outs, body, prep)) return rc;
+    if (int rc = host_pipeline(ncol, c0, c1, nbmax, ins, outs, body, prep)) return rc;
     hipStream_t s = G.stream;
     return read_physics_error(s);
+}
+
+// The columns of a host-pointer call over the devices of rrtmg_lw_hip_init_devices: contiguous blocks (multiples of 64 columns), one host
+// thread per device; every block runs the one-device pipeline on its own state (H2D | kernels | D2H on that device's streams).  Columns
+// are independent (src/rrtmg_lw_rad.nomcica.f90:472), so the results do not depend on the split.  Caller holds the entry lock.
+template <class RangeFn>
+int fan_out(int ncol, RangeFn range)
+{
+    State *const home = g_cur;
+    if (g_ndev <= 1 || ncol < 128) return range(0, ncol);
+    const int per = (int)align_up((size_t)(ncol + g_ndev - 1) / g_ndev, 64);
+    int rcs[MAXDEV] = {};
+    std::vector<std::thread> th;
+    for (int d = 0; d < g_ndev; d++) {
+        const int c0 = d * per, c1 = std::min(ncol, c0 + per);
+        if (c0 >= c1) break;
+        th.emplace_back([&rcs, &range, d, c0, c1]() {
+            g_cur = &g_states[d];
+            if (hipSetDevice(G.device) != hipSuccess) { rcs[d] = fail(RRTMG_LW_HIP_EHIP, "hipSetDevice(%d) failed", G.device); return; }
+            rcs[d] = range(c0, c1);
+        });
+    }
+    for (auto &x : th) x.join();
+    for (int d = 0; d < g_ndev; d++)
+        if (rcs[d] != 0) { if (&g_states[d] != home) home->err = g_states[d].err; return rcs[d]; }
+    return 0;
+}
+
+int nomcica_host(int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt)
+{
+    if (int rc = check_common(ncol, nlay)) return rc;
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (*icld < 0 || *icld > 3) *icld = 2;
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int ic = *icld;
+    return fan_out(ncol, [&](int c0, int c1) {
+        return nomcica_host_range(ncol, c0, c1, nlay, ic, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
+                              inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
+    });
+}
+}   // namespace
+
+extern "C" {
+
+int rrtmg_lw_hip_run_nomcica(
+    int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt)
+{
+    ENTRY_LOCK;
+    return nomcica_host(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
+                              inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
 }
 
 int rrtmg_lw_hip_run_columns(
@@ -1548,6 +1683,7 @@ int rrtmg_lw_hip_queue_begin(int nlay, int icld, int idrv, int inflglw, int icef
 {
     ENTRY_LOCK;
     if (int rc = check_common(1, nlay)) return rc;
+    if (Q.open && !Q.chunks.empty()) return fail(RRTMG_LW_HIP_EARG, "%lld queued columns have not been flushed", Q.ncol);
     Q.chunks.clear();
     Q.ncol = 0;
     Q.nlay = nlay; Q.icld = icld; Q.idrv = idrv; Q.inflg = inflglw; Q.iceflg = iceflglw; Q.liqflg = liqflglw;
@@ -1555,7 +1691,7 @@ int rrtmg_lw_hip_queue_begin(int nlay, int icld, int idrv, int inflglw, int icef
     return 0;
 }
 
-int rrtmg_lw_hip_queue_columns(void) { return (int)Q.ncol; }
+int rrtmg_lw_hip_queue_columns(void) { std::lock_guard<std::mutex> lk(g_mu); return (int)Q.ncol; }
 
 int rrtmg_lw_hip_queue_add(
     int ncol, int *icld,
@@ -1589,7 +1725,7 @@ int rrtmg_lw_hip_queue_add(
     return 0;
 }
 
-}   // extern "C" (the flush calls rrtmg_lw_hip_run_nomcica, which takes the entry lock itself)
+}   // extern "C"
 
 // f(i) for i in [0, n) on up to 8 host threads (contiguous index ranges)
 template <class F>
@@ -1609,8 +1745,8 @@ extern "C" int rrtmg_lw_hip_queue_flush(void)
     size_t in_inner[23], in_rows[23], out_rows[8];
     double *in_p[23], *out_p[8];
     long long N;
+    ENTRY_LOCK;             // held over pack, solve and scatter: another thread's queue_add / queue_begin / finalize must not touch the chunk list or the pinned set in between
     {
-        ENTRY_LOCK;
         if (!Q.open) return fail(RRTMG_LW_HIP_EARG, "rrtmg_lw_hip_queue_begin has not been called");
         N = Q.ncol;
         if (N == 0) return 0;
@@ -1643,13 +1779,12 @@ extern "C" int rrtmg_lw_hip_queue_flush(void)
     }
     int icld = Q.icld;
     const bool cloud = !(Q.icld == 0);
-    const int rc = rrtmg_lw_hip_run_nomcica((int)N, Q.nlay, &icld, Q.idrv, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
+    const int rc = nomcica_host((int)N, Q.nlay, &icld, Q.idrv, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
                                             in_p[8], in_p[9], in_p[10], in_p[11], in_p[12], in_p[13], in_p[14], in_p[15], Q.inflg, Q.iceflg, Q.liqflg,
                                             cloud ? in_p[16] : nullptr, cloud ? in_p[17] : nullptr, cloud ? in_p[18] : nullptr, cloud ? in_p[19] : nullptr,
                                             cloud ? in_p[20] : nullptr, cloud ? in_p[21] : nullptr, in_p[22],
                                             out_p[0], out_p[1], out_p[2], out_p[3], out_p[4], out_p[5],
                                             Q.idrv == 1 ? out_p[6] : nullptr, Q.idrv == 1 ? out_p[7] : nullptr);
-    ENTRY_LOCK;
     if (rc == 0) {
         std::vector<size_t> offs(Q.chunks.size());
         { size_t off = 0; for (size_t i = 0; i < Q.chunks.size(); i++) { offs[i] = off; off += (size_t)Q.chunks[i].ncol; } }
@@ -1710,15 +1845,17 @@ int rrtmg_lw_hip_run_mcica(
     ENTRY_LOCK;
     if (int rc = check_mcica_build()) return rc;
     if (int rc = check_common(ncol, nlay)) return rc;
-    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : 3;
     const bool cloud = mode == 3;
+    return fan_out(ncol, [&](int c0, int c1) -> int {     // (one block of columns per device of rrtmg_lw_hip_init_devices)
+    if (int rc = check_common(ncol, nlay)) return rc;
+    HIP_TRY(hipDeviceSynchronize());        // asynchronous device-entry work of earlier calls shares the workspace
     // the sub-column arrays are 4 x 140 x nlay doubles per column: bound the batch so that staging stays below ~4 GB
     const int mcmax = (int)std::max<size_t>(64, ((size_t)4 << 30) / ((size_t)4 * NGPT * nlay * 8));
-    const int nbmax = std::min(ncol, cloud ? std::min(G.batch, mcmax) : G.batch);
+    const int nbmax = std::min(c1 - c0, cloud ? std::min(G.batch, mcmax) : G.batch);
     if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud)) return rc;
     const size_t L = (size_t)nlay;
     std::vector<HostIn> ins = {
@@ -1733,8 +1870,8 @@ int rrtmg_lw_hip_run_mcica(
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
     if (int rc = stage_alloc(ins, outs, (size_t)nbmax)) return rc;
     hipStream_t s = G.stream;
-    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
-        const int nb = std::min(nbmax, ncol - col0);
+    for (int col0 = c0; col0 < c1; col0 += nbmax) {
+        const int nb = std::min(nbmax, c1 - col0);
         if (int rc = stage_in(ins, (size_t)ncol, (size_t)col0, (size_t)nb, s)) return rc;
         GcmIn g{ins[0].d, ins[1].d, ins[2].d, ins[3].d, ins[4].d, ins[5].d, ins[6].d, ins[7].d, ins[8].d, ins[9].d, ins[10].d,
                 ins[11].d, ins[12].d, ins[13].d, ins[14].d, ins[15].d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ins[16].d};
@@ -1745,6 +1882,7 @@ int rrtmg_lw_hip_run_mcica(
         if (int rc = stage_out(outs, (size_t)ncol, (size_t)col0, (size_t)nb, s)) return rc;
     }
     return read_physics_error(s);
+    });
 }
 
 int rrtmg_lw_hip_get_alpha(int ncol, int nlay, int icld, int idcor, double decorr_con, const double *dz, const double *lat,

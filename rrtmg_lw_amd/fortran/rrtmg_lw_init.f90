@@ -2,7 +2,7 @@
 !      use rrtmg_lw_init, only: rrtmg_lw_ini
 !      call rrtmg_lw_ini(cpdair)
 !  forwards to rrtmg_lw_hip_init of librrtmg_lw_hip.so (include/rrtmg_lw_hip.h).  The table files are
-!  looked up through the environment (RRTMG_LW_STATIC_TABLES, RRTMG_LW_KDATA, RRTMG_LW_DEVICE), falling
+!  looked up through the environment (RRTMG_LW_STATIC_TABLES, RRTMG_LW_KDATA, RRTMG_LW_DEVICE, RRTMG_LW_NDEV), falling
 !  back to ./lw_static.bin and ./rrtmg_lw.kdata.bin - the reference's netCDF reader likewise opens the
 !  literal 'rrtmg_lw.nc' in the working directory (src/rrtmg_lw_read_nc.f90:58).
       module rrtmg_lw_init
@@ -20,6 +20,14 @@
             integer(c_int), value :: device
             integer(c_int) :: rc
          end function rrtmg_lw_hip_init
+         function rrtmg_lw_hip_init_devices(static_path, kdata_path, cpdair, ndev, devices) bind(C, name='rrtmg_lw_hip_init_devices') result(rc)
+            import :: c_char, c_double, c_int
+            character(kind=c_char), intent(in) :: static_path(*), kdata_path(*)
+            real(c_double), value :: cpdair
+            integer(c_int), value :: ndev
+            integer(c_int), intent(in) :: devices(*)
+            integer(c_int) :: rc
+         end function rrtmg_lw_hip_init_devices
          function rrtmg_lw_hip_last_error() bind(C, name='rrtmg_lw_hip_last_error') result(p)
             import :: c_ptr
             type(c_ptr) :: p
@@ -31,8 +39,10 @@
       subroutine rrtmg_lw_ini(cpdair)
       real(kind=rb), intent(in) :: cpdair     ! Specific heat capacity of dry air at constant pressure at 273 K (J kg-1 K-1)
       character(len=1024) :: spath, kpath, dev
-      integer :: ls, lk, ld, idev, ios
+      integer :: ls, lk, ld, idev, ios, ndev, i
+      logical :: virtual
       integer(c_int) :: rc
+      integer(c_int) :: devices(16)
 
       call get_environment_variable('RRTMG_LW_STATIC_TABLES', spath, ls)
       if (ls == 0) then
@@ -48,7 +58,27 @@
          read(dev(1:ld), *, iostat=ios) idev
          if (ios /= 0) idev = 0
       endif
-      rc = rrtmg_lw_hip_init(spath(1:ls)//c_null_char, kpath(1:lk)//c_null_char, real(cpdair, c_double), int(idev, c_int))
+!  RRTMG_LW_NDEV = n > 1: this process drives n GPUs (ordinals RRTMG_LW_DEVICE, +1, ...); rrtmg_lw then splits its columns over
+!  them, one host thread per device.  RRTMG_LW_VIRTUAL_DEVICES = 1 keeps all n on RRTMG_LW_DEVICE (separate workspaces / streams).
+      ndev = 1
+      call get_environment_variable('RRTMG_LW_NDEV', dev, ld)
+      if (ld > 0) then
+         read(dev(1:ld), *, iostat=ios) ndev
+         if (ios /= 0) ndev = 1
+      endif
+      ndev = max(1, min(ndev, 16))
+      virtual = .false.
+      call get_environment_variable('RRTMG_LW_VIRTUAL_DEVICES', dev, ld)
+      if (ld > 0) virtual = dev(1:1) == '1'
+      if (ndev > 1) then
+         do i = 1, ndev
+            devices(i) = int(idev, c_int)
+            if (.not. virtual) devices(i) = int(idev + i - 1, c_int)
+         enddo
+         rc = rrtmg_lw_hip_init_devices(spath(1:ls)//c_null_char, kpath(1:lk)//c_null_char, real(cpdair, c_double), int(ndev, c_int), devices)
+      else
+         rc = rrtmg_lw_hip_init(spath(1:ls)//c_null_char, kpath(1:lk)//c_null_char, real(cpdair, c_double), int(idev, c_int))
+      endif
       if (rc /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_ini')
       end subroutine rrtmg_lw_ini
 

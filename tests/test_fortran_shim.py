@@ -51,11 +51,13 @@ def test_mcica_shim_modules_compile(tmp_path):
 
 @needs_flang
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,icld", [("cloudy", 2), ("aer_idrv", 1)])
-def test_fortran_host_model_matches_oracle(tmp_path, oracle, config, icld):
+@pytest.mark.parametrize("config,icld,ndev", [("cloudy", 2, 1), ("aer_idrv", 1, 1), ("cloudy", 2, 3)])
+def test_fortran_host_model_matches_oracle(tmp_path, oracle, config, icld, ndev):
+    """ndev = 3: RRTMG_LW_NDEV makes rrtmg_lw_ini set up three devices (virtual ones: all on GPU 0) and rrtmg_lw split its columns
+    over them - blocks of 128, 128 and 44 columns."""
     tmp = str(tmp_path)
     exe = _compile(tmp, link=True)
-    ncol, nlay = 96, 60
+    ncol, nlay = (96, 60) if ndev == 1 else (300, 60)
     d = make_gcm_inputs(ncol, nlay, config, col0=31)
     with open(os.path.join(tmp, "in.bin"), "wb") as f:
         np.array([ncol, nlay, icld, d["idrv"], d["inflglw"], d["iceflglw"], d["liqflglw"]], dtype=np.int32).tofile(f)
@@ -70,6 +72,8 @@ def test_fortran_host_model_matches_oracle(tmp_path, oracle, config, icld):
         f.write(np.asfortranarray(d["tauaer"]).tobytes(order="F"))
     env = dict(os.environ, RRTMG_LW_STATIC_TABLES=os.path.join(ROOT, "rrtmg_lw_amd", "data", "lw_static.bin"),
                RRTMG_LW_KDATA=os.path.join(ROOT, "rrtmg_lw_amd", "data", "standin.kdata.bin"))
+    if ndev > 1:
+        env.update(RRTMG_LW_NDEV=str(ndev), RRTMG_LW_VIRTUAL_DEVICES="1")
     subprocess.run([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")], check=True, env=env, cwd=tmp, timeout=300)
     raw = open(os.path.join(tmp, "out.bin"), "rb").read()
     icld_out = int(np.frombuffer(raw, dtype=np.int32, count=1)[0])

@@ -102,7 +102,7 @@ def hip256(hip):
     try:
         hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
         yield hip
-        hip.finalize()
+        hip.finalize(selected_only=True)      # (the 140-g-point library of the session fixture stays initialised)
     finally:
         hip.select_gpoints(140)
 

@@ -359,6 +359,45 @@ def test_host_entry_skips_zero_rows_and_sums_taucld(hip, oracle):
         hip.set_batch(262144)
 
 
+def test_several_devices_from_one_process(hip, oracle):
+    """rrtmg_lw_hip_init_devices: the host-pointer entries split their columns over the devices, one host thread each.  One GPU is
+    reachable here, so the three devices are virtual ones on GPU 0 (separate workspaces, streams, table copies): results must equal
+    the one-device call bit for bit (columns are independent), for a column count that is no multiple of 64, for one too small to
+    split, with a physics error raised on a device other than the first, and for the McICA array entry."""
+    from test_hip_mcica import _with_subcolumns
+    ncol, nlay = 1000, 45
+    d = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=9)
+    small = make_gcm_inputs(100, nlay, "cloudy", col0=2)
+    dm = _with_subcolumns(oracle, make_gcm_inputs(400, nlay, "cloudy", col0=4), 2)
+    one = hip.rrtmg_lw_from_dict(d, icld=2)
+    one_small = hip.rrtmg_lw_from_dict(small)
+    one_mc = hip.rrtmg_lw_mcica_from_dict(dm)
+    try:
+        hip.init_devices([0, 0, 0], kdata=hip.STANDIN_KDATA)
+        assert hip.num_devices() == 3
+        three = hip.rrtmg_lw_from_dict(d, icld=2)
+        three_small = hip.rrtmg_lw_from_dict(small)
+        three_mc = hip.rrtmg_lw_mcica_from_dict(dm)
+        bad = dict(d)
+        r = np.array(d["reice"]); r[900, 8] = 500.0          # a column of the third block
+        bad["reice"] = np.asfortranarray(r)
+        for k, v in (("cldfr", 0.5), ("cicewp", 10.0)):
+            a = np.array(d[k]); a[900, 8] = v; bad[k] = np.asfortranarray(a)
+        with pytest.raises(hip.RrtmgLwError, match="ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS"):
+            hip.rrtmg_lw_from_dict(bad, icld=2)
+        again = hip.rrtmg_lw_from_dict(d, icld=2)
+    finally:
+        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+    assert hip.num_devices() == 1
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt"):
+        assert np.array_equal(one[k], three[k]), k
+        assert np.array_equal(one[k], again[k]), k
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(one_small[k], three_small[k]), k
+        assert np.array_equal(one_mc[k], three_mc[k]), k
+    _compare(three, oracle.rrtmg_lw(ncol, nlay, 2, 1, d), 1, "three virtual devices")
+
+
 def test_device_entry_from_two_streams(hip, oracle):
     """Two callers enqueue device-resident work on different streams without synchronising in between: the driver orders the
     second call after the first (they share the workspace)."""
@@ -436,20 +475,19 @@ def test_chunk_queue_equals_one_call(hip, oracle):
 
 
 def test_north_star_mapping_prototype(hip, oracle):
-    """k_n1 (RRTMG_LW_N1=1 at init): one column per wavefront, g-points across lanes, wave-reduce over all bands, final fluxes and
-    heating rates written by the sweep itself (DESIGN.md, "north-star mapping").  Kept as a measured prototype for cloud-free calls;
-    it must give the oracle's numbers."""
-    import os
+    """k_n1 (rrtmg_lw_hip_set_n1_prototype): one column per wavefront, g-points across lanes, wave-reduce over all bands, final fluxes
+    and heating rates written by the sweep itself (DESIGN.md, "north-star mapping").  Kept as a measured prototype for cloud-free calls;
+    it must give the oracle's numbers.  The switch is an explicit call (an environment variable must not pick the numerical path)."""
     d = make_gcm_inputs(130, 72, "clear", col0=7)
     da = make_gcm_inputs(70, 51, "aer_idrv", col0=3)
-    os.environ["RRTMG_LW_N1"] = "1"
+    assert hip.lib().rrtmg_lw_hip_n1_prototype() == 0
+    hip.set_n1_prototype(True)
     try:
-        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+        assert hip.lib().rrtmg_lw_hip_n1_prototype() == 1
         got = hip.rrtmg_lw_from_dict(d, icld=0)
         gota = hip.rrtmg_lw_from_dict(da, icld=0, idrv=0)           # aerosol, perturbed columns
     finally:
-        del os.environ["RRTMG_LW_N1"]
-        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+        hip.set_n1_prototype(False)
     _compare(got, oracle.rrtmg_lw(130, 72, 0, 0, d), 0, "k_n1 clear 72")
     _compare(gota, oracle.rrtmg_lw(70, 51, 0, 0, da), 0, "k_n1 aerosol 51")
     again = hip.rrtmg_lw_from_dict(d, icld=0)                        # the production path, after the switch is off again
