@@ -134,17 +134,13 @@ def main():
     del parts
     idrv = d["idrv"]
 
-    # packed output block: rows = uflx, dflx, uflxc, dflxc [, duflx_dt, duflxc_dt with idrv = 1] (nlay+1 each), hr, hrc (nlay each)
-    rows = output_rows(nlay, idrv)
-    # two output blocks: the all-gather of step k (RCCL's own stream) overlaps the kernels of step k+1
-    outbufs = [torch.zeros((rows, ncol), dtype=torch.float64, device=dev) for _ in range(2)]
-    outs = [output_views(b, nlay, idrv) for b in outbufs]
-    outbuf, out = outbufs[0], outs[0]
-    gathered = [None, None]
-    pending = [None, None]
+    # packed output block (rows = uflx, dflx, uflxc, dflxc [, duflx_dt, duflxc_dt with idrv = 1] of nlay+1 levels, hr, hrc of nlay layers) and
+    # the single all-gather that reassembles it over the ranks: rrtmg_lw_amd/shard.py, ShardedStep (the two-rank gloo test runs the same class)
+    from rrtmg_lw_amd.shard import ShardedStep
     do_gather = use_dist and not args.no_gather
-    if do_gather:
-        gathered = [torch.empty((world * rows, per), dtype=torch.float64, device=dev) for _ in range(2)]   # rank-major concatenation
+    sharded = ShardedStep(nlay, idrv, per, world, device=dev, gather=do_gather)
+    outs = sharded.outs
+    out = outs[0]
 
     stream = torch.cuda.current_stream().cuda_stream
     alpha = None
@@ -156,31 +152,21 @@ def main():
         alpha = torch.cat([torch.zeros_like(a[:, :1]), a], dim=1).t().contiguous().t()
         del dz, a
 
-    step_no = [0]
+    def solve(o):
+        if args.mcica:
+            api.rrtmg_lw_mcica_subcol_device(d, o, 1, 0, alpha=alpha, icld=args.mcica, stream=stream)
+        else:
+            api.rrtmg_lw_device(d, o, stream=stream)
 
     def step():
-        k = step_no[0] & 1
-        step_no[0] += 1
-        if pending[k] is not None:          # the gather that last read this output block must be done before it is overwritten
-            pending[k].wait()
-            pending[k] = None
-        if args.mcica:
-            api.rrtmg_lw_mcica_subcol_device(d, outs[k], 1, 0, alpha=alpha, icld=args.mcica, stream=stream)
-        else:
-            api.rrtmg_lw_device(d, outs[k], stream=stream)
-        if do_gather:
-            pending[k] = dist.all_gather_into_tensor(gathered[k], outbufs[k], async_op=True)
+        sharded.step(solve)
 
-    def drain():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+    drain = sharded.drain
 
     if args.check and rank == 0:
         import numpy as np
         from oracle.bindings import Oracle
-        step_no[0] = 0
+        sharded.count = 0
         step()
         drain()
         api.check(stream)
@@ -271,7 +257,7 @@ def main():
         # parity of the timed GPU outputs with the CPU baseline's own results on the first 256 columns of the workload
         import numpy as np
         n = cpu_sample["uflx"].shape[0]
-        o = outs[(step_no[0] - 1) & 1]
+        o = outs[(sharded.count - 1) & 1]
         g = {k: o[k][:, :n].T.cpu().numpy() for k in cpu_sample}
         cpu["gpu_vs_this_baseline"] = dict(
             columns=n, max_abs_dflux_W_m2=float(max(np.abs(g[k] - cpu_sample[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))),

@@ -56,3 +56,48 @@ def unpack_gathered(gathered, nlay, ncol, idrv=1):
             import numpy as np
             out[nm] = np.concatenate(parts, axis=0)[:ncol]
     return out
+
+
+class ShardedStep:
+    """One rank's side of the sharded step (bench.py, and the two-rank gloo test runs the same code): the rank's packed output block,
+    filled by `solve`, and the single all-gather that reassembles the outputs of all ranks (north star).  Two blocks alternate: the
+    gather of step k - asynchronous, on the collective's own stream - overlaps the kernels of step k + 1, and a block is handed to
+    `solve` again only after the gather that last read it has completed.
+
+        st = ShardedStep(nlay, idrv, per, world, device)          # per = ceil(ncol / world) columns on EVERY rank
+        k = st.step(lambda out: rrtmg_lw_device(d, out, ...))     # out: dict of views into block k (output_views)
+        st.drain(); res = st.result(k, ncol)                      # dict of (ncol, nlay[+1]) tensors in global column order
+    """
+
+    def __init__(self, nlay, idrv, per, world, device=None, gather=True):
+        import torch
+        self.nlay, self.idrv, self.per, self.world = nlay, idrv, per, world
+        self.rows = output_rows(nlay, idrv)
+        self.outbufs = [torch.zeros((self.rows, per), dtype=torch.float64, device=device) for _ in range(2)]
+        self.outs = [output_views(b, nlay, idrv) for b in self.outbufs]
+        self.do_gather = bool(gather) and world >= 1
+        self.gathered = [torch.empty((world * self.rows, per), dtype=torch.float64, device=device) if self.do_gather else None for _ in range(2)]
+        self.pending = [None, None]
+        self.count = 0
+
+    def step(self, solve):
+        import torch.distributed as dist
+        k = self.count & 1
+        self.count += 1
+        if self.pending[k] is not None:          # the gather that last read this block must be done before it is overwritten
+            self.pending[k].wait()
+            self.pending[k] = None
+        solve(self.outs[k])
+        if self.do_gather:
+            self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.outbufs[k], async_op=True)
+        return k
+
+    def drain(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def result(self, k, ncol):
+        """outputs of all ranks after the gather of block k (drain first): global column order, padding columns dropped"""
+        return unpack_gathered(self.gathered[k].view(self.world, self.rows, self.per), self.nlay, ncol, self.idrv)

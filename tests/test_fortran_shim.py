@@ -19,7 +19,7 @@ needs_flang = pytest.mark.skipif(not os.path.exists(FLANG), reason="flang not in
 def _compile(tmp, link, mcica=False, prog=None):
     objs = []
     shim = ("parkind.f90", "rrtmg_lw_init.f90", "mcica_subcol_gen_lw.f90", "rrtmg_lw_rad.f90") if mcica else \
-           ("parkind.f90", "rrtmg_lw_init.f90", "rrtmg_lw_rad.nomcica.f90")
+           ("parkind.f90", "rrtmg_lw_init.f90", "rrtmg_lw_rad.nomcica.f90", "rrtmg_lw_queue.f90")
     prog = prog or ("drive_shim_mcica" if mcica else "drive_shim")
     for f in shim:
         o = os.path.join(tmp, f + ".o")
@@ -101,6 +101,44 @@ def _write_nomcica_inputs(path, d, ncol, nlay, icld):
         f.write(np.stack([d[k] for k in ("cldfr", "cicewp", "cliqwp", "reice", "reliq")], axis=2).tobytes(order="F"))
         f.write(np.asfortranarray(d["taucld"]).tobytes(order="F"))
         f.write(np.asfortranarray(d["tauaer"]).tobytes(order="F"))
+
+
+@needs_flang
+def test_queue_host_model_compiles(tmp_path):
+    _compile(str(tmp_path), link=False, prog="drive_queue")
+    assert os.path.exists(tmp_path / "rrtmg_lw_queue.mod")
+
+
+@needs_flang
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,icld,chunk", [("cloudy", 2, 16), ("aer_idrv", 1, 7)])
+def test_fortran_host_model_with_chunk_queue(tmp_path, oracle, config, icld, chunk):
+    """A Fortran host that calls per chunk of a few columns: chunk after chunk through rrtmg_lw, then the same chunks through module
+    rrtmg_lw_queue (recorded, ONE device pass).  Both must give the oracle's numbers and each other's bit for bit; the driver prints
+    the two wall times (no Python between the host model and the library)."""
+    tmp = str(tmp_path)
+    exe = _compile(tmp, link=True, prog="drive_queue")
+    ncol, nlay = 1000, 40            # the last chunk is short
+    d = make_gcm_inputs(ncol, nlay, config, col0=5)
+    _write_nomcica_inputs(os.path.join(tmp, "in.bin"), d, ncol, nlay, icld)
+    env = dict(os.environ, RRTMG_LW_STATIC_TABLES=os.path.join(ROOT, "rrtmg_lw_amd", "data", "lw_static.bin"),
+               RRTMG_LW_KDATA=os.path.join(ROOT, "rrtmg_lw_amd", "data", "standin.kdata.bin"))
+    r = subprocess.run([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin"), str(chunk)], check=True, env=env, cwd=tmp, timeout=600,
+                       capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert "max_abs_diff_queue_vs_direct= 0.000E+00" in r.stdout
+    raw = open(os.path.join(tmp, "out.bin"), "rb").read()
+    a = np.frombuffer(raw, dtype=np.float64, offset=4)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+    assert int(np.frombuffer(raw, dtype=np.int32, count=1)[0]) == ref["icld"]
+    pos = 0
+    for k, nl in (("uflx", nlay + 1), ("dflx", nlay + 1), ("hr", nlay), ("uflxc", nlay + 1), ("dflxc", nlay + 1), ("hrc", nlay),
+                  ("duflx_dt", nlay + 1), ("duflxc_dt", nlay + 1)):
+        got = a[pos:pos + ncol * nl].reshape((ncol, nl), order="F")
+        pos += ncol * nl
+        if k.startswith("du") and d["idrv"] != 1:
+            continue
+        assert np.abs(got - ref[k]).max() <= 5e-5, k
 
 
 @needs_flang

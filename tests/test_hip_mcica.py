@@ -190,6 +190,20 @@ def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld):
     assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
 
 
+def test_mcica_tallest_column(hip, oracle):
+    """nlay = 603 through the McICA array entry and the fused kissvec entry (the generator's thresholds: 603 x 16 x 16 B = 154 KB of LDS)."""
+    from test_hip_parity import _compare_thin_layers
+    ncol, nlay, icld = 20, 603, 2
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=40)
+    dd = _with_subcolumns(oracle, d, icld)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    got = hip.rrtmg_lw_mcica_from_dict(dd, icld=icld)
+    _compare_thin_layers(got, ref, d, d["idrv"], "mcica 603 layers")
+    fused = hip.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0, icld=icld)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(got[k], fused[k]), k
+
+
 def test_mcica_icld0_ignores_cloud_arrays(hip, oracle):
     d = make_gcm_inputs(100, 72, "cloudy")
     dd = _with_subcolumns(oracle, d, 2)

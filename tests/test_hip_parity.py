@@ -398,6 +398,20 @@ def test_several_devices_from_one_process(hip, oracle):
     _compare(three, oracle.rrtmg_lw(ncol, nlay, 2, 1, d), 1, "three virtual devices")
 
 
+@pytest.mark.parametrize("icld,idrv,ncol", [(2, 1, 70), (0, 0, 65), (1, 0, 64)])
+def test_tallest_column_the_interface_accepts(hip, oracle, icld, idrv, ncol):
+    """nlay = 603 = mxlay of modules/parrrtm.f90:31, the largest value the entries accept: level tiles of k_flux, the sweeps' level loops,
+    k_blocksort's histogram, 603 k_layer rows.  (Layers 0.002 hPa thick: heating rates relative, see _compare_thin_layers.)"""
+    nlay = 603
+    d = make_gcm_inputs(ncol, nlay, "aer_idrv" if idrv else "cloudy", col0=12)
+    got = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, idrv, d)
+    _compare_thin_layers(got, ref, d, idrv, f"603 layers icld={icld} idrv={idrv}")
+    with pytest.raises(hip.RrtmgLwError, match="bad dimensions"):
+        d604 = make_gcm_inputs(8, 604, "clear")
+        hip.rrtmg_lw_from_dict(d604)
+
+
 def test_device_entry_from_two_streams(hip, oracle):
     """Two callers enqueue device-resident work on different streams without synchronising in between: the driver orders the
     second call after the first (they share the workspace)."""

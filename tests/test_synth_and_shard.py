@@ -60,11 +60,13 @@ def _free_port():
 
 
 def _rank_main(rank, world, port, ncol, nlay, config, q):
-    """One rank of the sharded step as bench.py runs it: `per` = ceil(ncol / world) columns on every rank (the last rank continues
-    past ncol), the packed block sized by idrv, one all_gather_into_tensor."""
+    """One rank of the sharded step, through the class bench.py uses (shard.ShardedStep): `per` = ceil(ncol / world) columns on every
+    rank (the last rank continues past ncol), the packed block sized by idrv, one asynchronous all_gather_into_tensor per step.  Three
+    steps, so that both blocks are reused and a gather is waited for before its block is refilled; the oracle stands in for the device entry."""
     import torch
     import torch.distributed as dist
     from oracle.bindings import Oracle
+    from rrtmg_lw_amd.shard import ShardedStep
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,16 +74,21 @@ def _rank_main(rank, world, port, ncol, nlay, config, q):
     d = make_gcm_inputs(per, nlay, config, col0=rank * per)
     idrv = d["idrv"]
     o = Oracle().rrtmg_lw(per, nlay, d["icld"], idrv, d)
-    rows = output_rows(nlay, idrv)
-    buf = torch.zeros((rows, per), dtype=torch.float64)
-    views = output_views(buf, nlay, idrv)
-    assert set(views) == set(flux_names(idrv)) | {"hr", "hrc"}
-    for k in views:
-        views[k][:, :] = torch.from_numpy(np.ascontiguousarray(o[k].T))
-    gathered = torch.empty((world * rows, per), dtype=torch.float64)
-    dist.all_gather_into_tensor(gathered, buf)
+    st = ShardedStep(nlay, idrv, per, world, device=None, gather=True)
+    assert st.rows == output_rows(nlay, idrv) and set(st.outs[0]) == set(flux_names(idrv)) | {"hr", "hrc"}
+    calls = []
+
+    def solve(out):
+        calls.append(1)
+        scale = 1.0 if len(calls) == 3 else 0.5                # only the last step carries the true values
+        for k in out:
+            out[k][:, :] = torch.from_numpy(np.ascontiguousarray(o[k].T)) * scale
+
+    for _ in range(3):
+        last = st.step(solve)
+    st.drain()
     if rank == 0:
-        res = unpack_gathered(gathered.view(world, rows, per), nlay, ncol, idrv)
+        res = st.result(last, ncol)
         q.put({k: v.numpy() for k, v in res.items()})
     dist.destroy_process_group()
 
