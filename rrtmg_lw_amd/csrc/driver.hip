@@ -757,9 +757,10 @@ int host_threads()
     return nt;
 }
 template <class F>
-void host_parallel(F f)
+void host_parallel(size_t work_bytes, F f)
 {
-    const int nt = host_threads();
+    // (a thread per MB of host data at least: a call of a few columns must not pay for sixteen thread starts)
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), work_bytes >> 20));
     if (nt == 1) { f(0, 1); return; }
     std::vector<std::thread> th;
     for (int t = 1; t < nt; t++) th.emplace_back([=, &f]() { f(t, nt); });
@@ -770,7 +771,7 @@ void host_parallel(F f)
 // flags[r] = 1 when row r of the column batch [col0, col0 + nb) of a (rows, ncol, inner) array holds nothing but +0.0
 void scan_zero_rows(const double *h, size_t inner, size_t rows, size_t ncol, size_t col0, size_t nb, unsigned char *flags)
 {
-    host_parallel([&](int t, int nt) {
+    host_parallel(inner * rows * nb * 8, [&](int t, int nt) {
         for (size_t r = rows * t / nt; r < rows * (t + 1) / nt; r++) {
             const uint64_t *p = reinterpret_cast<const uint64_t *>(h + inner * (col0 + ncol * r));
             const size_t n = inner * nb;
@@ -1422,7 +1423,7 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
         if (use_tot) {
             HIP_TRY(hipEventSynchronize(G.ev_h2d[k]));       // the copy of batch i - 2 has left the pinned scratch set k (this thread runs ahead of the device)
             double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;
-            host_parallel([&](int t, int nt) {
+            host_parallel((size_t)NBND * L * (size_t)nb * 8, [&](int t, int nt) {
                 const size_t n = L * (size_t)nb;
                 for (size_t e = n * t / nt; e < n * (t + 1) / nt; e++) {
                     const size_t lay = e / (size_t)nb, c = e % (size_t)nb;
@@ -2037,50 +2038,14 @@ int rrtmg_lw_hip_run_mcica_subcol(
         if (rc) return rc;
     }
     // 2. column batches
-    // What the copies need not carry (62 % of a column's bytes are taucld and tauaer, 2 x 16 nlay values):
-    //  * with inflglw >= 1 cldprop reads taucld only through the sum over the bands, tauctot (src/rrtmg_lw_cldprop.f90:173-186): the sum is
-    //    formed here, in the reference's order, on the host threads - one value per (column, layer) travels instead of sixteen;
-    //  * a (layer, band) row of tauaer - and with inflglw = 0 a layer of taucld - that is all zero for the batch's columns is not copied.
-    const bool use_tot = cloud && inflglw != 0;
     std::vector<HostIn> ins = {
         {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
         {h2ovmr, 1, L, 0}, {o3vmr, 1, L, 0}, {co2vmr, 1, L, 0}, {ch4vmr, 1, L, 0}, {n2ovmr, 1, L, 0}, {o2vmr, 1, L, 0},
         {cfc11vmr, 1, L, 0}, {cfc12vmr, 1, L, 0}, {cfc22vmr, 1, L, 0}, {ccl4vmr, 1, L, 0}, {emis, 1, 16, 0}, {tauaer, 1, 16 * L, 0},
-        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, (size_t)(use_tot ? 1 : NBND), L, 0, use_tot}, {cloud ? cicewp : nullptr, 1, L, 0},
+        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, NBND, L, 0}, {cloud ? cicewp : nullptr, 1, L, 0},
         {cloud ? cliqwp : nullptr, 1, L, 0}, {cloud ? reice : nullptr, 1, L, 0}, {cloud ? reliq : nullptr, 1, L, 0}};
     for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
-    if (use_tot && G.h_tot_doubles < 2 * L * (size_t)nbmax) {
-        if (G.h_tot) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipHostFree(G.h_tot)); G.h_tot = nullptr; G.h_tot_doubles = 0; }
-        HIP_TRY(hipHostMalloc((void **)&G.h_tot, 2 * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
-        G.h_tot_doubles = 2 * L * (size_t)nbmax;
-    }
-    for (auto &z : G.zrow) z.assign(17 * L, 0);
-    auto prep = [&](int k, int col0, int nb, hipStream_t cs) -> int {
-        unsigned char *zf = G.zrow[k].data();
-        scan_zero_rows(tauaer, 1, 16 * L, (size_t)ncol, (size_t)col0, (size_t)nb, zf);
-        ins[16].rowzero = zf;
-        if (cloud && !use_tot) {
-            scan_zero_rows(taucld, NBND, L, (size_t)ncol, (size_t)col0, (size_t)nb, zf + 16 * L);
-            ins[18].rowzero = zf + 16 * L;
-        }
-        if (use_tot) {
-            HIP_TRY(hipEventSynchronize(G.ev_h2d[k]));       // the copy of batch i - 2 has left the pinned scratch set k (this thread runs ahead of the device)
-            double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;
-            host_parallel([&](int t, int nt) {
-                const size_t n = L * (size_t)nb;
-                for (size_t e = n * t / nt; e < n * (t + 1) / nt; e++) {
-                    const size_t lay = e / (size_t)nb, c = e % (size_t)nb;
-                    const double *p = taucld + (size_t)NBND * ((size_t)col0 + c + (size_t)ncol * lay);
-                    double sum = 0.0;
-                    for (int ib = 0; ib < NBND; ib++) sum = sum + p[ib];
-                    tot[e] = sum;
-                }
-            });
-            HIP_TRY(hipMemcpyAsync(ins[18].d, tot, L * (size_t)nb * sizeof(double), hipMemcpyHostToDevice, cs));
-        }
-        return 0;
-    };
     std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
     if (int rc = stage_alloc(ins, outs, (size_t)nbmax)) return rc;

@@ -204,6 +204,25 @@ def test_mcica_tallest_column(hip, oracle):
         assert np.array_equal(got[k], fused[k]), k
 
 
+def test_fused_entry_takes_optical_depths_from_taucld(hip, oracle):
+    """inflglw = 0: the fused generator + solver entry must expand the grid-mean taucld exactly as the generator's taucmcl does
+    (src/mcica_subcol_gen_lw.f90:664-680) - the host entry has to ship taucld whole."""
+    ncol, nlay, icld = 200, 40, 2
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=21)
+    rng = np.random.default_rng(2)
+    cf = np.array(d["cldfr"])
+    d["taucld"] = np.asfortranarray(3.0 * rng.random((16, ncol, nlay)) * (cf[None, :, :] > 0))
+    d["inflglw"], d["iceflglw"], d["liqflglw"] = 0, 0, 0
+    dd = _with_subcolumns(oracle, d, icld)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    arrays = hip.rrtmg_lw_mcica_from_dict(dd, icld=icld)
+    fused = hip.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0, icld=icld)
+    _compare(arrays, ref, d["idrv"], "mcica inflag 0, arrays")
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(arrays[k], fused[k]), k
+    assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
+
+
 def test_mcica_icld0_ignores_cloud_arrays(hip, oracle):
     d = make_gcm_inputs(100, 72, "cloudy")
     dd = _with_subcolumns(oracle, d, 2)
