@@ -290,24 +290,34 @@ def main():
                          # a fraction of the path; kept for continuity with round 1, next to the share-weighted one
                          whole_column_bytes_over_kernel_time_GBps=round(bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9, 3),
                          traffic=None)
+            # PMC-measured HBM bytes (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 passes, one entry per
+            # configuration): the PATH's bytes per column x this rank's columns per step, and the dominant kernel's per launch
+            key = f"{args.config}_L{nlay}" + (f"_mcica{args.mcica}" if args.mcica else "")
+            path_traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    dom_d["traffic"] = json.load(open(pmc)).get(dom)
+                    ent = json.load(open(pmc)).get(key)
+                    if ent:
+                        path_traffic = ent["bytes_per_column"] * ncol
+                        kb = ent["kernels"].get(dom) or ent["kernels"].get(dom.replace(">", ",false>"))
+                        if kb:
+                            dom_d["traffic"] = round(kb / ent["columns"] * cols_per_launch, 1)
+                            dom_d["traffic_source"] = f"profiles/pmc_traffic.json[{key}]"
                 except Exception:
                     pass
             roof = dict(bound="hbm", scope="path: all kernels of a step (sweep family = %.0f %% of it)" %
                         (100.0 * sum(v[1] for k, v in kern.items() if k.startswith("k_sweep")) / ktot),
                         achieved=round(pach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pach / HBM_PEAK_GBS, 5),
                         algorithmic_bytes_per_column=bpc, kernels_ms_per_step=round(ktot / args.steps, 3),
-                        traffic=dom_d["traffic"], dominant=dom_d)
+                        traffic=path_traffic, traffic_scope="HBM bytes of ALL kernels of one step on this rank (PMC, per-column figure of the same configuration x columns)" if path_traffic else None,
+                        traffic_over_algorithmic=round(path_traffic / (bpc * ncol), 3) if path_traffic else None, dominant=dom_d)
             path = dict(kernels_ms_per_step=round(ktot / args.steps, 3),
                         kernels={k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                         families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
                                   for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweepc", "k_sweepz", "k_flux")})
             # instruction side: counts per column from the committed PMC pass of the same configuration, times from this run
             pc = os.path.join(ROOT, "profiles", "pmc_compute.json")
-            key = f"{args.config}_L{nlay}" + (f"_mcica{args.mcica}" if args.mcica else "")
             if os.path.exists(pc):
                 try:
                     ent = json.load(open(pc)).get(key)

@@ -67,6 +67,8 @@ def main():
     ap.add_argument("dir")
     ap.add_argument("--json")
     ap.add_argument("--md")
+    ap.add_argument("--key", default="cloudy_L72", help="configuration key of the entry written to --json (bench.py: <config>_L<nlay>[_mcica<icld>])")
+    ap.add_argument("--columns", type=int, default=250000, help="columns of the profiled call (tools/pmc_run.py --ncol)")
     ap.add_argument("--calib-bytes", type=float, default=float(1 << 30))
     ap.add_argument("--skip-first", action="store_true", default=True,
                     help="drop the first half of each kernel's dispatches (the warm-up call)")
@@ -137,7 +139,21 @@ def main():
     if args.md:
         open(args.md, "w").write(text + "\n")
     if args.json:
-        json.dump({k: round(v, 1) for k, v in traffic.items()}, open(args.json, "w"), indent=1, sort_keys=True)
+        # profiles/pmc_traffic.json: one entry per configuration key (cloudy_L72, clear_L72, cloudy_L72_mcica5, aer_idrv_L137 ...): HBM bytes
+        # per launch of every kernel (FETCH_SIZE x 2 + WRITE_SIZE, calibrated above) for the profiled call and their sum per column
+        data = {}
+        if os.path.exists(args.json):
+            try:
+                data = json.load(open(args.json))
+            except Exception:
+                data = {}
+        if not all(isinstance(v, dict) for v in data.values()):
+            data = {}                         # (the round-2 layout: one flat dictionary of the cloudy configuration)
+        per_call = {k: launches.get(k, 1) for k in traffic}
+        path = sum(traffic[k] * max(per_call[k], 1) for k in traffic)
+        data[args.key] = dict(columns=args.columns, kernels={k: round(v, 1) for k, v in traffic.items()}, launches_per_call=per_call,
+                              path_bytes_per_call=round(path, 1), bytes_per_column=round(path / args.columns, 1))
+        json.dump(data, open(args.json, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
