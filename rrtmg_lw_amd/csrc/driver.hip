@@ -41,7 +41,7 @@ struct State {
     struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk; double2 *ovl; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
-    struct ScrSet { scr_t *scr[NSCR]; unsigned *fw; } scrset[2] = {};
+    struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
     hipStream_t aux = nullptr, sw = nullptr;
     hipStream_t swq[3] = {nullptr, nullptr, nullptr};     // the sweep launches of the 3-, 2- and 1-quad bands run beside the 4-quad launch
     hipEvent_t ev_swq_go = nullptr, ev_swq_done[3] = {nullptr, nullptr, nullptr};
@@ -277,9 +277,9 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     for (int k = 0; k < (two_scr ? 2 : 1); k++) {
         State::ScrSet &ss = G.scrset[k];
         ss = State::ScrSet{};
-        items.push_back({(void **)&ss.scr[S_CODE], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        items.push_back({(void **)&ss.scr[S_CODE], (size_t)NQUAD * L * n * CODE_BYTES});
         items.push_back({(void **)&ss.fw, (size_t)NFW * L * n * sizeof(unsigned)});
-        if (cloud) items.push_back({(void **)&ss.scr[S_CODET], (size_t)NQUAD * 4 * L * n * sizeof(scr_t)});
+        if (cloud) items.push_back({(void **)&ss.scr[S_CODET], (size_t)NQUAD * L * n * CODE_BYTES});
     }
     for (auto &ps : G.prep) {
         ps = State::PrepSet{};
@@ -1271,6 +1271,7 @@ int rrtmg_lw_hip_set_overlap(int on)
 int rrtmg_lw_hip_set_n1_prototype(int on)
 {
     ENTRY_LOCK;
+    if (on && CODE_BITS != 32) return fail(RRTMG_LW_HIP_EARG, "the k_n1 prototype reads 32-bit cell codes");
     G.n1 = on != 0;
     return 0;
 }

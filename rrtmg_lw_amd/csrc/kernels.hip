@@ -63,8 +63,17 @@ enum Scr { S_CODE, S_CODET, NSCR };
 // per-band partial fluxes, each [band][level][column] of {total-sky, clear-sky}: downward, upward, d(upward)/dT
 struct alignas(16) Part2 { double a, b; };
 
-// storage type of the per-cell codes handed from k_layer to the sweeps (all arithmetic stays float64)
+// the per-cell codes handed from k_layer to the sweeps (all arithmetic stays float64): in registers a float (scr_t, cell_code), in
+// memory RRLW_CODE_BITS bits per cell, four cells (a quad) per record.  32 = the float itself; 24 and 16 are measurement variants that
+// keep the table index whole and round the series-branch optical depth to 18 / 11 mantissa bits (pack4 / unpack4).
 typedef float scr_t;
+#ifndef RRLW_CODE_BITS
+#define RRLW_CODE_BITS 32
+#endif
+constexpr int CODE_BITS = RRLW_CODE_BITS;
+static_assert(CODE_BITS == 32 || CODE_BITS == 24 || CODE_BITS == 16, "bits per cell code");
+constexpr int CODE_WORDS = CODE_BITS / 8;        // 32-bit words per quad record
+constexpr int CODE_BYTES = 4 * CODE_WORDS;
 
 struct Workspace {
     int ncolb;          // column stride (batch capacity)
@@ -86,7 +95,7 @@ struct Workspace {
     int *hblk;          // [nblk]  hand-off level of the block's group (k_flux)
     double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at the block's hand-off level: 0 downward (k_sweepc<.,1> -> k_sweepz), 1 / 2 upward
                         // total / clear (k_sweepz -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
-    scr_t *scr[NSCR];   // [NQUAD][nlay][ncolb][4]
+    unsigned *scr[NSCR];   // [NQUAD][nlay][ncolb] quad records of CODE_WORDS words
     unsigned *fw;       // [NFW][nlay][ncolb]   binary-key bands: Planck-fraction interpolation (js << 28 | 28-bit fs)
     // k_sweepc's partials, summed over the bands of a GROUP (bands with the same number of quads, swept by one workgroup and added in
     // LDS): [NGROUP_MAX][nlay+1][ncolb].  gdn1 / gup1: 8 bytes where the clear-sky stream equals the total one (downward at and above the
@@ -1224,13 +1233,78 @@ struct alignas(16) scr4 { scr_t v[4]; };
 // The per-cell codes are written once by k_layer and read twice (down and up sweep) by k_sweepc / k_sweepz, gigabytes later: streaming
 // (non-temporal) stores here and loads there (bload_scr4_nt) keep them from evicting the absorption tables from L2.
 typedef float scr_vec __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void scr_store(scr_t *base, size_t cell, const scr4 &v)
+// a quad's four codes as they lie in memory
+struct pk4 { unsigned w[CODE_WORDS]; };
+// Reduced code widths (measurement variants): bit (CODE_BITS - 1) = table cell, then the table index (<= 10000); otherwise the series-branch
+// optical depth (0 <= od <= 0.06) as a small float - its float32 pattern scaled so that the exponent field fits E bits, cut to M mantissa
+// bits with rounding; tiny values go through the scaled float's denormals, i.e. they keep an ABSOLUTE resolution.
+//   24 bits: E = 5, M = 18 (relative 1.9e-6), scale 2^-91;   16 bits: E = 4, M = 11 (relative 2.4e-4), scale 2^-107
+template <int BITS> struct CodeFmt;
+template <> struct CodeFmt<24> { static constexpr int SH = 5;  static constexpr unsigned FLAG = 0x800000u, MASK = 0x7fffffu; static constexpr float DN = 0x1p-91f,  UP = 0x1p+91f; };
+template <> struct CodeFmt<16> { static constexpr int SH = 12; static constexpr unsigned FLAG = 0x8000u,   MASK = 0x7fffu;   static constexpr float DN = 0x1p-107f, UP = 0x1p+107f; };
+template <int BITS> __device__ __forceinline__ unsigned code_narrow(scr_t c)
 {
+    using F = CodeFmt<BITS>;
+    if (c < 0.f) return F::FLAG | (unsigned)(int)(-c);
+    const unsigned u = __float_as_uint(c * F::DN) & 0x7fffffffu;
+    return min((u + (1u << (F::SH - 1))) >> F::SH, F::MASK);
+}
+template <int BITS> __device__ __forceinline__ scr_t code_widen(unsigned h)
+{
+    using F = CodeFmt<BITS>;
+    const float tbl = -(float)(h & 0x3fffu), ser = __uint_as_float((h & F::MASK) << F::SH) * F::UP;
+    return (h & F::FLAG) ? tbl : ser;
+}
+__device__ __forceinline__ pk4 pack4(const scr4 &v)
+{
+    pk4 p;
+    if constexpr (CODE_BITS == 32) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) p.w[k] = __float_as_uint(v.v[k]);
+    } else if constexpr (CODE_BITS == 16) {
+        p.w[0] = code_narrow<16>(v.v[0]) | (code_narrow<16>(v.v[1]) << 16);
+        p.w[1] = code_narrow<16>(v.v[2]) | (code_narrow<16>(v.v[3]) << 16);
+    } else {
+        const unsigned a = code_narrow<24>(v.v[0]), b = code_narrow<24>(v.v[1]), c = code_narrow<24>(v.v[2]), d = code_narrow<24>(v.v[3]);
+        p.w[0] = a | (b << 24); p.w[1] = (b >> 8) | (c << 16); p.w[2] = (c >> 16) | (d << 8);
+    }
+    return p;
+}
+__device__ __forceinline__ scr4 unpack4(const pk4 &p)
+{
+    scr4 v;
+    if constexpr (CODE_BITS == 32) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v.v[k] = __uint_as_float(p.w[k]);
+    } else if constexpr (CODE_BITS == 16) {
+        v.v[0] = code_widen<16>(p.w[0] & 0xffffu); v.v[1] = code_widen<16>(p.w[0] >> 16);
+        v.v[2] = code_widen<16>(p.w[1] & 0xffffu); v.v[3] = code_widen<16>(p.w[1] >> 16);
+    } else {
+        v.v[0] = code_widen<24>(p.w[0] & 0xffffffu);
+        v.v[1] = code_widen<24>(__builtin_amdgcn_alignbit(p.w[1], p.w[0], 24) & 0xffffffu);
+        v.v[2] = code_widen<24>(__builtin_amdgcn_alignbit(p.w[2], p.w[1], 16) & 0xffffffu);
+        v.v[3] = code_widen<24>(p.w[2] >> 8);
+    }
+    return v;
+}
+typedef unsigned pk_vec __attribute__((ext_vector_type(CODE_WORDS)));
+__device__ __forceinline__ void scr_store(unsigned *base, size_t cell, const scr4 &v)
+{
+    const pk4 p = pack4(v);
+    pk_vec x;
+#pragma unroll
+    for (int k = 0; k < CODE_WORDS; k++) x[k] = p.w[k];
 #ifdef RRLW_NO_NT
-    reinterpret_cast<scr4 *>(base)[cell] = v;
+    __builtin_memcpy(base + cell * CODE_WORDS, &x, CODE_BYTES);
 #else
-    scr_vec x = {v.v[0], v.v[1], v.v[2], v.v[3]};
-    __builtin_nontemporal_store(x, reinterpret_cast<scr_vec *>(base) + cell);
+    if constexpr (CODE_WORDS == 3) {        // (no 12-byte vector store through a pointer: 8 + 4)
+        typedef unsigned v2 __attribute__((ext_vector_type(2)));
+        v2 lo = {p.w[0], p.w[1]};
+        __builtin_nontemporal_store(lo, reinterpret_cast<v2 *>(base + cell * 3));
+        __builtin_nontemporal_store(p.w[2], base + cell * 3 + 2);
+    } else {
+        __builtin_nontemporal_store(x, reinterpret_cast<pk_vec *>(base + cell * CODE_WORDS));
+    }
 #endif
 }
 // transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
@@ -2322,11 +2396,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_rsrc(const void *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
 }
-__device__ __forceinline__ scr4 bload_scr4_nt(const void *base, unsigned voff)
+// a quad record of cell codes (voff = the lane's column x CODE_BYTES), streaming
+__device__ __forceinline__ pk4 bload_pk4_nt(const void *base, unsigned voff)
 {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, 0, 2);
-    scr4 r;
-    __builtin_memcpy(&r, &v, 16);
+    pk4 r;
+    if constexpr (CODE_WORDS == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, 0, 2);
+        __builtin_memcpy(&r, &v, 16);
+    } else if constexpr (CODE_WORDS == 3) {
+        typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(sweep_rsrc(base), (int)voff, 0, 2);
+        r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2];
+    } else {
+        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(sweep_rsrc(base), (int)voff, 0, 2);
+        r.w[0] = v[0]; r.w[1] = v[1];
+    }
     return r;
 }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -2587,11 +2672,11 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     __syncthreads();
     const int lo = PHASE == 0 ? 1 : __builtin_amdgcn_readfirstlane(W.hgrp[(blockIdx.x * nsb) / SORT_GROUP]) + 1;       // layers lo .. nlay (uniform over the workgroup)
     const size_t qstride = (size_t)nlay * ncb;
-    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)quad * qstride;
+    const unsigned *__restrict__ sC = W.scr[S_CODE] + (size_t)quad * qstride * CODE_WORDS;
     const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
     const double *__restrict__ tlay = a.tlay + a.col0;
     const double *__restrict__ tlev = a.tlev + a.col0;
-    const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
+    const unsigned offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
     const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;        // (uniform: the group's slabs; a lane's column is the 32-bit offset of a buffer store)
     double *__restrict__ gdn1 = W.gdn1 + gslab;
     double *__restrict__ gup1 = W.gup1 + gslab;
@@ -2611,9 +2696,9 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
         q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8);
         if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
     };
-    auto ld_c = [&](int lev, int k) -> scr4 {
+    auto ld_c = [&](int lev, int k) -> pk4 {
         const int l = min(max(lev, 1), nlay);
-        return bload_scr4_nt(sC + k * qstride + (size_t)(l - 1) * ncb, off16);
+        return bload_pk4_nt(sC + ((size_t)k * qstride + (size_t)(l - 1) * ncb) * CODE_WORDS, offc);
     };
     // fraction rows of layer `lev`: first row and interpolation weight (taumol :556-561, :692-693)
     auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
@@ -2679,7 +2764,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     // The slot pieces are re-issued for level lev + NC * dir (codes) / lev + dir (temperatures) as soon as they have been consumed.
     SweepcLev<G> cur;
     cur.w = 0u;
-    scr4 cc[G][NC];
+    pk4 cc[G][NC];
     auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) {
         constexpr bool BIN = decltype(bin_tag)::value, DN = decltype(dn_tag)::value;
         constexpr int dir = DN ? -1 : 1;
@@ -2694,13 +2779,14 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
 #pragma unroll
         for (int k = 0; k < G; k++) {
             float2 e[4];
-            scr4 ck;
+            pk4 pk;
 #pragma unroll
-            for (int c = 0; c < NC; c++) if (c == slot) ck = cc[k][c];
+            for (int c = 0; c < NC; c++) if (c == slot) pk = cc[k][c];
+            const scr4 ck = unpack4(pk);
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) e[jj] = RRLW_LUT_ENTRY(s_lut, code_index(ck.v[jj]));
             {
-                const scr4 nx = ld_c(lev + NC * dir, k);
+                const pk4 nx = ld_c(lev + NC * dir, k);
 #pragma unroll
                 for (int c = 0; c < NC; c++) if (c == slot) cc[k][c] = nx;
             }
@@ -2913,14 +2999,14 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     __syncthreads();
     const int ltop = __builtin_amdgcn_readfirstlane(W.hgrp[(blockIdx.x * nsb) / SORT_GROUP]);       // layers 1 .. ltop (uniform over the workgroup)
     const size_t qstride = (size_t)nlay * ncb;
-    const scr4 *__restrict__ sC = reinterpret_cast<const scr4 *>(W.scr[S_CODE]) + (size_t)quad * qstride;
-    const scr4 *__restrict__ sCt = reinterpret_cast<const scr4 *>(W.scr[S_CODET]) + (size_t)quad * qstride;
+    const unsigned *__restrict__ sC = W.scr[S_CODE] + (size_t)quad * qstride * CODE_WORDS;
+    const unsigned *__restrict__ sCt = W.scr[S_CODET] + (size_t)quad * qstride * CODE_WORDS;
     const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
     const int *__restrict__ sFlag = W.cflag;
     const double *__restrict__ tlay = a.tlay + a.col0;
     const double *__restrict__ tlev = a.tlev + a.col0;
     const double *__restrict__ cldf = a.cldfrac + a.col0;
-    const unsigned off16 = (unsigned)colc * 16u, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
+    const unsigned off16 = (unsigned)colc * 16u, offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
     const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;
     Part2 *__restrict__ gdn = W.gdn + gslab;
     Part2 *__restrict__ gup = W.gup + gslab;
@@ -2945,7 +3031,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         q.flag = bload_u32(sFlag + (size_t)l * ncb, off4);
         if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
     };
-    auto ld_c = [&](const scr4 *base, int lev, int k) -> scr4 { return bload_scr4_nt(base + k * qstride + (size_t)(clampl(lev) - 1) * ncb, off16); };
+    auto ld_c = [&](const unsigned *base, int lev, int k) -> pk4 { return bload_pk4_nt(base + ((size_t)k * qstride + (size_t)(clampl(lev) - 1) * ncb) * CODE_WORDS, offc); };
     auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
         const bool lower = lev <= laytrop;
         if (any_bin) {          // uniform
@@ -3016,7 +3102,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     // instantiations 3-5 registers over their 168: scratch reloads count in vmcnt and drain the prefetches)
     constexpr int NCT = RRLW_SWEEPZ_CT_SLOTS;
     static_assert(NCT == 1 || NCT == NC, "slots of the total-optical-depth codes");
-    scr4 cc[G][NC], ct[G][NCT];
+    pk4 cc[G][NC], ct[G][NCT];
     // One level.  DN: downward (Planck difference towards the interface below, partial of level lev - 1, istcldd = flag bit 1), else
     // upward (istcld = bit 2).  The overlap factors of the level are requested first and used last.
     auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) __attribute__((always_inline)) {
@@ -3062,9 +3148,10 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         double qs[G], qsc[G];
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            scr4 ck, ckt;
+            pk4 pk, pkt;
 #pragma unroll
-            for (int c = 0; c < NC; c++) if (c == slot) { ck = cc[k][c]; ckt = ct[k][NCT == 1 ? 0 : c]; }
+            for (int c = 0; c < NC; c++) if (c == slot) { pk = cc[k][c]; pkt = ct[k][NCT == 1 ? 0 : c]; }
+            const scr4 ck = unpack4(pk), ckt = unpack4(pkt);
             float2 e[4], et[4];
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) e[jj] = RRLW_LUT_ENTRY(s_lut, code_index(ck.v[jj]));
@@ -3073,7 +3160,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                 for (int jj = 0; jj < 4; jj++) et[jj] = RRLW_LUT_ENTRY(s_lut, min(code_index(ckt.v[jj]), (unsigned)NTBL));
             }
             {
-                const scr4 nx = ld_c(sC, lev + NC * dir, k), nxt = ld_c(sCt, lev + NCT * dir, k);
+                const pk4 nx = ld_c(sC, lev + NC * dir, k), nxt = ld_c(sCt, lev + NCT * dir, k);
 #pragma unroll
                 for (int c = 0; c < NC; c++) if (c == slot) { cc[k][c] = nx; ct[k][NCT == 1 ? 0 : c] = nxt; }
             }
@@ -3305,7 +3392,7 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
         wt[p] = ok[p] ? 0.5 * T.delwave[b] : 0.0;
         coff[p] = ((size_t)min(q, NQUAD - 1) * nlay * ncb + col) * 4 + (slot & 3);        // + (lev - 1) * ncb * 4
     }
-    const scr_t *codes = W.scr[S_CODE];
+    const scr_t *codes = reinterpret_cast<const scr_t *>(W.scr[S_CODE]);      // (the prototype reads 32-bit codes: rrtmg_lw_hip_set_n1_prototype refuses other builds)
     // per level: lanes 0..15 (band = lane & 15) publish the band's Planck terms and fraction row
     const int mb = lane & 15;
     const bool m_lo_bin = (LO_BINARY >> mb) & 1u, m_up_bin = (UP_BINARY >> mb) & 1u;
