@@ -138,11 +138,13 @@ enum ErrCode { E_NONE = 0, E_ICE_SMALL = 1, E_ICE_BOUNDS = 2, E_ICE_GEN_BOUNDS =
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// a / b for normal, finite operands in k_layer: hardware reciprocal seed, two Newton steps, one residual correction (8 VALU
-// operations in one dependency chain instead of the ~13 of the IEEE sequence with its scale / fix-up steps; a third of
-// k_layer's VALU instructions were divisions).  The quotient is within an ulp of the correctly rounded one; where it feeds
-// an index (`int(...)`, the 1e-4-quantised transmittance table) a different index needs the exact quotient to sit within
-// ~1e-16 of a boundary.  -DRRLW_EXACT_DIV restores the IEEE division.
+// a / b for normal, finite operands in k_layer: hardware reciprocal seed (2^-24), ONE Newton step (2^-48), one residual correction
+// q + (a - b q) r, whose error is the product of the two (6 VALU operations in one dependency chain instead of the ~13 of the IEEE
+// sequence with its scale / fix-up steps; a third of k_layer's VALU instructions were divisions).  The quotient is within an ulp of
+// the correctly rounded one; where it feeds an index (`int(...)`, the 1e-4-quantised transmittance table) a different index needs the
+// exact quotient to sit within ~1e-16 of a boundary: tools/divtest.hip finds 0 quotients and 0 table indices different from the IEEE
+// division in 2.1e9 operands, with one Newton step as with two (profiles/round2_divtest.txt; round 3 made one the default: -0.3 ms).
+// -DRRLW_EXACT_DIV restores the IEEE division, -DRRLW_FDIV_TWO_NEWTON the second step.
 __device__ __forceinline__ double fdiv(double a, double b)
 {
 #ifdef RRLW_EXACT_DIV
@@ -150,7 +152,7 @@ __device__ __forceinline__ double fdiv(double a, double b)
 #else
     double r = __builtin_amdgcn_rcp(b);
     r = fma(fma(-b, r, 1.0), r, r);
-#ifndef RRLW_FDIV_ONE_NEWTON
+#ifdef RRLW_FDIV_TWO_NEWTON
     r = fma(fma(-b, r, 1.0), r, r);
 #endif
     const double q = a * r;
