@@ -1154,7 +1154,11 @@ template <int B, bool LOWER, int N>
 struct BandLoads {
     static constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
     static constexpr int ng = BT<B>::ng;
+#ifdef RRLW_KO_HALFG       // knock-out (timing only, wrong results): only the first half of a band's g-points is evaluated - the occupancy experiment of round 3
+    static constexpr int HP = (ng / 2 + 1) / 2;
+#else
     static constexpr int HP = ng / 2;                                    // 16-byte loads per table row
+#endif
     static constexpr int NK = N * HP;                                    // absorption-coefficient loads
     static constexpr int NL = NK;
     static constexpr int CH = RRLW_LOAD_CHUNK;
