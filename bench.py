@@ -276,7 +276,10 @@ def main():
         compute = None
         if kern:
             ktot = sum(v[1] for v in kern.values())                 # summed kernel milliseconds of the timed steps (this rank)
-            pach = bpc * ncol * args.steps / (ktot * 1e-3) / 1e9
+            # the path's time: the summed kernel time, or the wall time of the timed region where that is shorter (the sweep launches of
+            # the four band groups run on four streams and the per-column kernels on a fifth: their HIP-event times overlap)
+            tpath = min(ktot, 1e3 * dt)
+            pach = bpc * ncol * args.steps / (tpath * 1e-3) / 1e9
             # dominant kernel of the critical path: k_colprep / k_cloudscan / k_cloudlay run on the auxiliary stream underneath the previous
             # batch's k_layer / sweeps (driver.hip: run_pipelined) and are left out of the choice
             crit = {k: v for k, v in kern.items() if not (k.startswith("k_colprep") or k in ("k_cloudscan", "k_cloudlay"))} or kern
@@ -309,10 +312,11 @@ def main():
             roof = dict(bound="hbm", scope="path: all kernels of a step (sweep family = %.0f %% of it)" %
                         (100.0 * sum(v[1] for k, v in kern.items() if k.startswith("k_sweep")) / ktot),
                         achieved=round(pach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pach / HBM_PEAK_GBS, 5),
-                        algorithmic_bytes_per_column=bpc, kernels_ms_per_step=round(ktot / args.steps, 3),
+                        algorithmic_bytes_per_column=bpc, kernels_ms_per_step=round(ktot / args.steps, 3), path_ms_per_step=round(tpath / args.steps, 3),
                         traffic=path_traffic, traffic_scope="HBM bytes of ALL kernels of one step on this rank (PMC, per-column figure of the same configuration x columns)" if path_traffic else None,
                         traffic_over_algorithmic=round(path_traffic / (bpc * ncol), 3) if path_traffic else None, dominant=dom_d)
             path = dict(kernels_ms_per_step=round(ktot / args.steps, 3),
+                        note="HIP-event time per kernel; the sweeps of the four band groups and the per-column kernels run on their own streams, so the sum exceeds the step",
                         kernels={k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},
                         families={fam: round(sum(v[1] for k, v in kern.items() if k.startswith(fam)) / args.steps, 3)
                                   for fam in ("k_colprep", "k_subcol", "k_cloud", "k_layer", "k_sweepc", "k_sweepz", "k_flux")})

@@ -426,8 +426,8 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     // a partly filled last round (1-quad bands: 2.5 rounds); on separate streams the other launches' workgroups fill those CUs.
     // Measured: 10 000 columns 1.22 -> 0.98 ms; 125 000-column batches no gain (cloudy 98.9 -> 98.4 ms per 1e6 columns, McICA 115.5 -> 122.6).
 #ifndef RRLW_FANOUT_MAX
-#define RRLW_FANOUT_MAX 65536     // (for every batch size: 61.9 against 63.1 ms per 1e6 cloudy columns, inside the run-to-run spread; the per-kernel
-#endif                            // HIP-event times of overlapping launches stop meaning anything, so large batches stay on one stream)
+#define RRLW_FANOUT_MAX 0x7fffffff     // (round 3: for every batch size - 61.4 -> 60.2 ms per 1e6 cloudy columns, three runs each; deep clouds 87.7 -> 85.7.
+#endif                                 // The HIP-event times of the sweep kernels then overlap: their sum exceeds the wall time they take together)
     const bool fan = G.sweep_fanout && nb < RRLW_FANOUT_MAX;
     if (fan && !G.swq[0]) {
         for (int k = 0; k < 3; k++) {
