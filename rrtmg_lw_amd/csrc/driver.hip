@@ -744,16 +744,15 @@ int stage_in(std::vector<HostIn> &ins, size_t ncol, size_t col0, size_t nb, hipS
 // f(t, nt) on nt host threads (the host-pointer entries' own arithmetic on the caller's arrays: row scans, tauctot)
 int host_threads()
 {
-    static int nt = 0;
-    if (nt == 0) {
+    static const int nt = []() {         // (initialised once, thread-safe: the fan-out's worker threads all come through here)
         const char *e = getenv("RRTMG_LW_HOST_THREADS");
         int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
 #ifdef __linux__
         cpu_set_t set;
         if (!e && sched_getaffinity(0, sizeof set, &set) == 0) v = std::min(v, CPU_COUNT(&set));
 #endif
-        nt = std::max(1, std::min(v, 16));
-    }
+        return std::max(1, std::min(v, 16));
+    }();
     return nt;
 }
 template <class F>

@@ -1362,78 +1362,103 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     const size_t so0 = ((size_t)QS * nlay + (lay - 1)) * ncb + col;     // scratch cell of the band's first quad
     const size_t qstride = (size_t)nlay * ncb;
     // gas: series for od <= 0.06, else the table (rtrn :372-451; in a cloudy layer the branch taken for the gas terms depends on od alone)
+    auto gas_codes = [&]() {
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        scr4 c;
-        // the table index costs a float64 division (~16 instructions per cell, a third of k_layer's arithmetic); the 64 columns of a
-        // wave sit in the same layer, so thin g-points (upper atmosphere, band wings) are thin in all of them: a wave whose four cells
-        // of a quad all take the series branch skips the divisions (wave-uniform test; same values either way).  Per cell instead of
-        // per quad the 140 branches cost more than the divisions they skip (26.0 -> 27.3 ms per 1e6 cloudy columns).
-#if RRLW_SERIES_SKIP
-        const bool thick = od[4 * q] > 0.06 || od[4 * q + 1] > 0.06 || od[4 * q + 2] > 0.06 || od[4 * q + 3] > 0.06;
-        if (__builtin_amdgcn_ballot_w64(thick) == 0ull) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) c.v[k] = (scr_t)od[4 * q + k];
-        } else
-#endif
-        {
+        for (int q = 0; q < NQ; q++) {
+            scr4 c;
+            // the table index costs a float64 division (~14 instructions per cell, a third of k_layer's arithmetic); the compiler runs it
+            // under the exec mask of the thick cells and skips it for a wave whose cells are all thin (upper atmosphere, band wings)
 #pragma unroll
             for (int k = 0; k < 4; k++) c.v[k] = cell_code(od[4 * q + k], od[4 * q + k] <= 0.06, bpade);
+            if (incol) scr_store(W.scr[S_CODE], so0 + q * qstride, c);
         }
-        if (incol) scr_store(W.scr[S_CODE], so0 + q * qstride, c);
-    }
-    if (CLOUD && cloudy) {
-        // cloudy layer, the three sub-branches of rtrn :372-435:
+    };
+    if constexpr (CLOUD == 0) {
+        gas_codes();
+    } else {
+        // A wave with a cloudy lane (all 64 columns sit in the same layer) forms, per group of quads, the table index of the thick cells ONCE
+        // and uses it for the gas code and for the cloudy branch p3 (round 3: the two passes of round 2 divided twice; a cloudy layer cost
+        // 3.2 x a clear one).  The three sub-branches of rtrn :372-435:
         //   p1: odtot < 0.06              total from the series
         //   p2: else if odepth <= 0.06    total = odepth + odcld from the table
         //   p3: else                      odepth := tau_tbl(itgas), total from the table
         // (McICA, CLOUD 2 / 3: every g-point has its own cloud optical depth - eight more live doubles per quad in flight; with two quads
         // the kernel spilled 13-18 registers)
-        constexpr int QCW = CLOUD >= 2 ? 1 : RRLW_CLOUD_QUADS;
-        constexpr int QC = QCW < NQ ? QCW : NQ;
+        // (the per-g-point flavours keep the two passes: with the index held across the group they spilled 7-9 registers)
+        constexpr bool REUSE = CLOUD == 1;
+        const bool wave_cloudy = __builtin_amdgcn_ballot_w64(cloudy != 0) != 0ull;
+        if (!REUSE || !wave_cloudy) gas_codes();
+        if (wave_cloudy) {
+            constexpr int QCW = CLOUD >= 2 ? 1 : RRLW_CLOUD_QUADS;
+            constexpr int QC = QCW < NQ ? QCW : NQ;
 #pragma unroll
-        for (int q0 = 0; q0 < NQ; q0 += QC) {
-            constexpr int GC = 4 * QC;
-            double odc[GC], tg[GC];
+            for (int q0 = 0; q0 < NQ; q0 += QC) {
+                constexpr int GC = 4 * QC;
+                int ig[REUSE ? GC : 1];     // table index of the gas optical depth, 0 for a series cell
+                if constexpr (REUSE) {
 #pragma unroll
-            for (int k = 0; k < GC; k++) odc[k] = odcld;
-            if constexpr (CLOUD == 3) {
+                    for (int k = 0; k < GC; k++) {
+                        const int j = 4 * q0 + k;
+                        ig[k] = 0;
+                        if (j < ng) { if (!(od[j] <= 0.06)) ig[k] = lut_index(od[j], bpade); }
+                    }
 #pragma unroll
-                for (int k = 0; k < GC; k++) odc[k] = ((gbits >> (4 * q0 + k)) & 1u) ? odcld : 0.0;
-            }
-            if constexpr (CLOUD == 2) {
+                    for (int q = 0; q < QC; q++) {
+                        if (q0 + q < NQ) {
+                            scr4 c;
 #pragma unroll
-                for (int q = 0; q < QC; q++) {
-                    if (q0 + q < NQ) {
-                        const double2 *po = reinterpret_cast<const double2 *>(W.odg + (so0 + (q0 + q) * qstride) * 4);
-                        const double2 a = po[0], b = po[1];
-                        odc[4 * q] = a.x; odc[4 * q + 1] = a.y; odc[4 * q + 2] = b.x; odc[4 * q + 3] = b.y;
+                            for (int kk = 0; kk < 4; kk++) {
+                                const int j = 4 * (q0 + q) + kk;
+                                c.v[kk] = od[j < NP ? j : 0] <= 0.06 ? (scr_t)od[j < NP ? j : 0] : -(scr_t)ig[4 * q + kk];
+                            }
+                            if (incol) scr_store(W.scr[S_CODE], so0 + (q0 + q) * qstride, c);
+                        }
                     }
                 }
-            }
+                if (cloudy) {
+                    double odc[GC], tg[GC];
 #pragma unroll
-            for (int k = 0; k < GC; k++) {
-                const int j = 4 * q0 + k;
-                if (j < NP) {
-                    int ig = 0;
-                    const bool p3 = !(od[j] + odc[k] < 0.06) && !(od[j] <= 0.06);
-                    if (j < ng && p3) ig = lut_index(od[j], bpade);
-                    tg[k] = tau_tbl[ig];
-                }
-            }
+                    for (int k = 0; k < GC; k++) odc[k] = odcld;
+                    if constexpr (CLOUD == 3) {
 #pragma unroll
-            for (int q = 0; q < QC; q++) {
-                if (q0 + q < NQ) {
-                    scr4 c;
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int k = 4 * q + kk, j = 4 * (q0 + q) + kk;
-                        const bool p1 = od[j] + odc[k] < 0.06;
-                        const bool p3 = !p1 && !(od[j] <= 0.06);
-                        const double odtot = (p3 ? tg[k] : od[j]) + odc[k];
-                        c.v[kk] = j < ng ? cell_code(odtot, p1, bpade) : (scr_t)0;
+                        for (int k = 0; k < GC; k++) odc[k] = ((gbits >> (4 * q0 + k)) & 1u) ? odcld : 0.0;
                     }
-                    if (incol) scr_store(W.scr[S_CODET], so0 + (q0 + q) * qstride, c);
+                    if constexpr (CLOUD == 2) {
+#pragma unroll
+                        for (int q = 0; q < QC; q++) {
+                            if (q0 + q < NQ) {
+                                const double2 *po = reinterpret_cast<const double2 *>(W.odg + (so0 + (q0 + q) * qstride) * 4);
+                                const double2 a = po[0], b = po[1];
+                                odc[4 * q] = a.x; odc[4 * q + 1] = a.y; odc[4 * q + 2] = b.x; odc[4 * q + 3] = b.y;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < GC; k++) {
+                        const int j = 4 * q0 + k;
+                        if (j < NP) {
+                            const bool p3 = !(od[j] + odc[k] < 0.06) && !(od[j] <= 0.06);
+                            int igk = 0;
+                            if constexpr (REUSE) igk = p3 ? ig[k] : 0;
+                            else { if (j < ng && p3) igk = lut_index(od[j], bpade); }
+                            tg[k] = tau_tbl[igk];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < QC; q++) {
+                        if (q0 + q < NQ) {
+                            scr4 c;
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) {
+                                const int k = 4 * q + kk, j = 4 * (q0 + q) + kk;
+                                const bool p1 = od[j] + odc[k] < 0.06;
+                                const bool p3 = !p1 && !(od[j] <= 0.06);
+                                const double odtot = (p3 ? tg[k] : od[j]) + odc[k];
+                                c.v[kk] = j < ng ? cell_code(odtot, p1, bpade) : (scr_t)0;
+                            }
+                            if (incol) scr_store(W.scr[S_CODET], so0 + (q0 + q) * qstride, c);
+                        }
+                    }
                 }
             }
         }
