@@ -10,14 +10,16 @@
 //   k_cloudscan / k_cloudlay   cldprop, cloud optical depth per spectral band: the one quantity cldprop carries from layer
 //              to layer per column, then the per-layer physics        1 thread / column, 1 thread / (column, layer)
 //   k_cloudmc  cldprmc + the cloud set-up of rtrnmc (McICA)             1 thread / (column, layer)
-//   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for all bands (each band's absorption tables
-//              staged in LDS for the 256 columns of a workgroup, which share the layer), then for each cell the decision
-//              rtrn takes on its optical depth (series / table index) as a 4-byte code
+//   k_blocksort  the 64-column blocks of a batch ordered by their highest cloudy layer, one hand-off level per group of blocks
+//                                                                       1 workgroup / batch
+//   k_layer    everything that is LOCAL to a layer: inatm + setcoef + taumol for all bands (the bands' absorption tables staged
+//              in LDS, several bands per pass, for the 256 columns of a workgroup, which share the layer), then for each cell the
+//              decision rtrn takes on its optical depth (series / table index) as a 4-byte code
 //                                                                       1 thread / (column, layer)
 //   k_sweepc / k_sweepz   the only vertically serial part: the down/up recurrences of rtrn / rtrnmr / rtrnmc over the cell codes
-//              (transmittance table, the bands' Planck integrals and fractions in LDS); k_sweepc above the batch's highest cloud and
-//              for cloud-free calls (1 thread / (column, band)), k_sweepz in the cloud zone (1 thread / (column, quad)); a workgroup =
-//              the bands of one group, flux partials added over the group in LDS
+//              (transmittance table, the bands' Planck integrals and fractions in LDS); k_sweepc above the hand-off level of the
+//              wave's block group and for cloud-free calls (1 thread / (column, band)), k_sweepz in the cloud zone (1 thread /
+//              (column, quad)); a workgroup = the bands of one group, flux partials added over the group in LDS
 //   k_flux     group partials -> fluxes, net fluxes, heating rates           1 thread / (column, level)
 //   k_subcol_* McICA sub-column generator (bit masks), k_alpha           see the section below
 //
@@ -1143,9 +1145,6 @@ __device__ __forceinline__ void rows_to_lds(Rows<N> &rw, const unsigned (&delta)
 #ifndef RRLW_LOAD_CHUNK
 #define RRLW_LOAD_CHUNK 2       // loads in flight per pipeline stage.  From LDS two suffice (8 were needed through the vector L1) and the
 #endif                          // registers saved allow three waves per SIMD: 36.4 vs 40.9 ms per 1e6 cloudy columns
-#ifndef RRLW_SERIES_SKIP
-#define RRLW_SERIES_SKIP 0      // 1: a wave skips the table-index divisions of a quad whose cells are all thin (band_cells)
-#endif
 #ifndef RRLW_CLOUD_QUADS
 #define RRLW_CLOUD_QUADS 2      // quads of a band whose cloudy-layer look-ups are in flight together
 #endif
