@@ -38,7 +38,7 @@ struct State {
     bool ws_cloud = false, ws_mc = false;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk; double2 *ovl; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -292,6 +292,8 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         items.push_back({(void **)&ps.hblk, nblk * 4});
         items.push_back({(void **)&ps.order, nslot * 4});
         items.push_back({(void **)&ps.hgrp, (nslot / SORT_GROUP) * 4});
+        items.push_back({(void **)&ps.bbot, nblk * 4});
+        items.push_back({(void **)&ps.hbot, (nslot / SORT_GROUP) * 4});
     }
     if (cloud) items.push_back({(void **)&W.hand, (size_t)5 * NQUAD * 4 * n * 8});
     if (cloud) {
@@ -319,7 +321,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
         const State::PrepSet &ps = G.prep[0];
         W.percol = ps.percol; W.laytrop = ps.laytrop; W.ncbands = ps.ncbands; W.cflag = ps.cflag;
         W.odcld = ps.odcld; W.efcl = ps.efcl; W.ovl = ps.ovl;
-        W.btop = ps.btop; W.order = ps.order; W.hgrp = ps.hgrp; W.hblk = ps.hblk;
+        W.btop = ps.btop; W.order = ps.order; W.hgrp = ps.hgrp; W.hblk = ps.hblk; W.bbot = ps.bbot; W.hbot = ps.hbot;
     }
     G.ws_bytes = total;
     G.ws_nlay = nlay;
@@ -348,7 +350,7 @@ Workspace ws_for(int k)
     const State::PrepSet &ps = G.prep[k];
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
     w.odcld = ps.odcld; w.efcl = ps.efcl; w.ovl = ps.ovl;
-    w.btop = ps.btop; w.order = ps.order; w.hgrp = ps.hgrp; w.hblk = ps.hblk;
+    w.btop = ps.btop; w.order = ps.order; w.hgrp = ps.hgrp; w.hblk = ps.hblk; w.bbot = ps.bbot; w.hbot = ps.hbot;
     const State::ScrSet &ss = G.scrset[G.ws_two_scr ? k : 0];
     for (int a = 0; a < NSCR; a++) w.scr[a] = ss.scr[a];
     w.fw = ss.fw;

@@ -95,6 +95,8 @@ struct Workspace {
     int *order;         // [nslot] sorted position -> block (positions past the last block: nblk, i.e. columns past the end)
     int *hgrp;          // [nslot / SORT_GROUP] hand-off level of the group
     int *hblk;          // [nblk]  hand-off level of the block's group (k_flux)
+    int *bbot;          // [nblk]  lowest layer that holds cloud in any column of the block (nlay + 1: none)
+    int *hbot;          // [nslot / SORT_GROUP] lowest cloudy layer of the group: below it the cloud-zone sweep runs its clear-sky body without the cloudy-level inputs
     double *hand;       // [5][NQUAD][ncolb][4] radiances handed from sweep to sweep at the block's hand-off level: 0 downward (k_sweepc<.,1> -> k_sweepz), 1 / 2 upward
                         // total / clear (k_sweepz -> k_sweepc<.,2>), 3 / 4 their d/dT (idrv = 1)
     unsigned *scr[NSCR];   // [NQUAD][nlay][ncolb] quad records of CODE_WORDS words
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
     }
     W.ncbands[col] = 1;
     W.cflag[col] = 0;
-    if ((col & 63) == 0) W.btop[col >> 6] = 0;          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
+    if ((col & 63) == 0) { W.btop[col >> 6] = 0; W.bbot[col >> 6] = nlay + 1; }          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
     const int nlay = W.nlay;
     const double *cldfr = GCM ? g.cldfr : c.cldfrac;
     const double *ciwp_ = GCM ? g.cicewp : c.ciwp, *clwp_ = GCM ? g.cliqwp : c.clwp;
-    int ncbands = 1, anycloud = 0, top = 0;
+    int ncbands = 1, anycloud = 0, top = 0, bot = nlay + 1;
     const size_t ncb = W.ncolb;
     bool prevcld = false, rat1 = false, rat2 = false;       // upward sweep order = this loop's order
     double cfprev = 0.0;
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
             }
         }
         const int cloudy = cf >= 1.e-6;
+        if (cloudy && !anycloud) bot = lay;
         anycloud |= cloudy;
         if (cloudy) top = lay;
         int first = 0;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
             } else prevcld = false;
         }
     }
-    if (top > 0) atomicMax(&W.btop[col >> 6], top);       // (the 64 columns of a block are one wave of this kernel)
+    if (top > 0) { atomicMax(&W.btop[col >> 6], top); atomicMin(&W.bbot[col >> 6], bot); }       // (the 64 columns of a block are one wave of this kernel)
     W.ncbands[col] = ncbands;
     W.cflag[col] = anycloud ? 8 : 0;
     W.cflag[(size_t)(nlay + 1) * W.ncolb + col] = 0;
@@ -562,6 +565,13 @@ __global__ __launch_bounds__(256) void k_blocksort(Workspace W, int nblk)
         }
     }
     for (int p = nblk + tid; p < nslot; p += nth) W.order[p] = nblk;
+    __syncthreads();                    // (the order written by the first wave is read below)
+    // lowest cloudy layer of every group (a group without cloud: nlay + 1; its hand-off level is 0 and nothing is swept in the zone)
+    for (int g = tid; g < ngrp; g += nth) {
+        int b = nlay + 1;
+        for (int p = SORT_GROUP * g; p < SORT_GROUP * (g + 1) && p < nblk; p++) b = min(b, W.bbot[W.order[p]]);
+        W.hbot[g] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1883,6 +1893,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
     W.cflag[(size_t)lay * ncb + col] = any;
     if (any) atomicOr(&W.cflag[col], 8);
     if (any && lay > *reinterpret_cast<volatile int *>(&W.btop[col >> 6])) atomicMax(&W.btop[col >> 6], lay);
+    if (any && lay < *reinterpret_cast<volatile int *>(&W.bbot[col >> 6])) atomicMin(&W.bbot[col >> 6], lay);
     if (lay == 1) W.cflag[(size_t)(nlay + 1) * ncb + col] = 0;
     if (err) atomicCAS(W.err, 0, err);
 }
@@ -3053,12 +3064,15 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
 
     auto clampl = [&](int lev) { return min(max(lev, 1), nlay); };
     // the level's own inputs, one level ahead; zoff: 0 = interface below the layer (downward), 1 = above (upward)
-    auto fill_t = [&](auto bin_tag, int lev, int zoff, SweepzLev &q) {
+    // (LITE: a level below the group's lowest cloud - no column of the workgroup is cloudy there: its cloud fraction and flag word are not read)
+    auto fill_t = [&](auto bin_tag, auto lite_tag, int lev, int zoff, SweepzLev &q) {
         const int l = clampl(lev);
         q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8);
         q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8);
-        q.cf = bload_f64(cldf + (size_t)nct * (l - 1), off8);
-        q.flag = bload_u32(sFlag + (size_t)l * ncb, off4);
+        if constexpr (!decltype(lite_tag)::value) {
+            q.cf = bload_f64(cldf + (size_t)nct * (l - 1), off8);
+            q.flag = bload_u32(sFlag + (size_t)l * ncb, off4);
+        }
         if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
     };
     auto ld_c = [&](const unsigned *base, int lev, int k) -> pk4 { return bload_pk4_nt(base + ((size_t)k * qstride + (size_t)(clampl(lev) - 1) * ncb) * CODE_WORDS, offc); };
@@ -3174,7 +3188,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         const bool anycld = __builtin_amdgcn_ballot_w64(cloudy) != 0ull;       // (wave-uniform)
         unsigned gbits = 0u;
         if constexpr (MODE == 4) gbits = (unsigned)((((unsigned long long)mlo | ((unsigned long long)mhi << 32)) >> (ig0 & 31)) & ((1ull << nvalid) - 1ull));
-        fill_t(bin_tag, lev + dir, DN ? 0 : 1, cur);
+        fill_t(bin_tag, std::false_type{}, lev + dir, DN ? 0 : 1, cur);
         double qs[G], qsc[G];
 #pragma unroll
         for (int k = 0; k < G; k++) {
@@ -3276,34 +3290,103 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
             red_put(slot, 3, dsc);
         }
     };
-    auto sweep = [&](auto bin_tag, auto dn_tag) __attribute__((always_inline)) {
-        constexpr bool DN = decltype(dn_tag)::value;
+    // The same level below the lowest cloud of the workgroup's blocks (layers 1 .. lbot - 1: clear in every column): the clear-sky update of
+    // both streams - the arithmetic of the branch above that a wave without a cloudy lane takes, rtrnmr :617-627 / :705-716 - without the
+    // cloudy level's inputs (total-optical-depth codes, cloud fraction, flag word, overlap factors / emissivity / mask words).
+    auto level_lite = [&](auto bin_tag, auto dn_tag, int lev, int slot) __attribute__((always_inline)) {
+        constexpr bool BIN = decltype(bin_tag)::value, DN = decltype(dn_tag)::value;
         constexpr int dir = DN ? -1 : 1;
-        const int first = DN ? ltop : 1, count = ltop;
+        double fpl;
+        const double *row = frac_row(lev, cur.w, fpl);
+        const double blay = planck_at(tp0, tp0, cur.tl);
+        const double dpl = planck_at(tp0, (DN && alt16 && lev == 1) ? tp1 : tp0, cur.tz) - blay;
+        fill_t(bin_tag, std::true_type{}, lev + dir, DN ? 0 : 1, cur);
+        double qs[G], qsc[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            pk4 pk;
+#pragma unroll
+            for (int c = 0; c < NC; c++) if (c == slot) pk = cc[k][c];
+            const scr4 ck = unpack4(pk);
+            float2 e[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) e[jj] = RRLW_LUT_ENTRY(s_lut, code_index(ck.v[jj]));
+            {
+                const pk4 nx = ld_c(sC, lev + NC * dir, k);
+#pragma unroll
+                for (int c = 0; c < NC; c++) if (c == slot) cc[k][c] = nx;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * k + jj;
+                double atr, tfn;
+                decode(ck.v[jj], e[jj], atr, tfn);
+                double fr = row[j];
+                if constexpr (BIN) fr = fr + fpl * (row[16 + j] - fr);
+                const double bb = fr * (blay + tfn * dpl);
+                const double rad_s = rad[j] + (bb - rad[j]) * atr;
+                const double updc = radc[j] + (bb - radc[j]) * atr;
+                rad[j] = rad_s;
+                radc[j] = seen ? updc : rad_s;
+                if constexpr (IDRV && !DN) {
+                    drad[j] = drad[j] * (1.0 - atr);
+                    dradc[j] = seen ? dradc[j] * (1.0 - atr) : drad[j];
+                }
+            }
+            qs[k] = (rad[4 * k] + rad[4 * k + 1]) + (rad[4 * k + 2] + rad[4 * k + 3]);
+            qsc[k] = (radc[4 * k] + radc[4 * k + 1]) + (radc[4 * k + 2] + radc[4 * k + 3]);
+        }
+        if constexpr (G == 1) { red_put(slot, 0, qs[0]); red_put(slot, 1, qsc[0]); }
+        else { red_put(slot, 0, qs[0] + qs[1]); red_put(slot, 1, qsc[0] + qsc[1]); }
+        if constexpr (IDRV && !DN) {
+            double ds = 0.0, dsc = 0.0;
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                ds = ds + ((drad[4 * k] + drad[4 * k + 1]) + (drad[4 * k + 2] + drad[4 * k + 3]));
+                dsc = dsc + ((dradc[4 * k] + dradc[4 * k + 1]) + (dradc[4 * k + 2] + dradc[4 * k + 3]));
+            }
+            red_put(slot, 2, ds);
+            red_put(slot, 3, dsc);
+        }
+    };
+    // `count` levels from layer `first` in the sweep direction; LITE: the clear-sky levels below the lowest cloud
+    auto sweep = [&](auto bin_tag, auto dn_tag, auto lite_tag, int first, int count) __attribute__((always_inline)) {
+        constexpr bool DN = decltype(dn_tag)::value, LITE = decltype(lite_tag)::value;
+        constexpr int dir = DN ? -1 : 1;
+        if (count <= 0) return;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            if (c == NC - 1) fill_t(bin_tag, first, DN ? 0 : 1, cur);
+            if (c == NC - 1) fill_t(bin_tag, lite_tag, first, DN ? 0 : 1, cur);
 #pragma unroll
-            for (int k = 0; k < G; k++) { cc[k][c] = ld_c(sC, first + c * dir, k); if (c < NCT) ct[k][c] = ld_c(sCt, first + c * dir, k); }
+            for (int k = 0; k < G; k++) {
+                cc[k][c] = ld_c(sC, first + c * dir, k);
+                if constexpr (!LITE) { if (c < NCT) ct[k][c] = ld_c(sCt, first + c * dir, k); }
+            }
         }
+        auto one = [&](int lev, int slot) __attribute__((always_inline)) {
+            if constexpr (LITE) level_lite(bin_tag, dn_tag, lev, slot); else level(bin_tag, dn_tag, lev, slot);
+        };
         int n = 0;
         for (; n + NC <= count; n += NC) {
 #pragma unroll
-            for (int c = 0; c < NC; c++) level(bin_tag, dn_tag, first + (n + c) * dir, c);
+            for (int c = 0; c < NC; c++) one(first + (n + c) * dir, c);
             round_end(dn_tag, first + n * dir, NC);
         }
         const int rem = count - n;
 #pragma unroll
         for (int c = 0; c < NC - 1; c++) {
-            if (c < rem) level(bin_tag, dn_tag, first + (n + c) * dir, c);
+            if (c < rem) one(first + (n + c) * dir, c);
         }
         if (rem > 0) round_end(dn_tag, first + n * dir, rem);
     };
     using std::true_type;
     using std::false_type;
+    // the zone in two parts: layers lbot .. ltop with the cloudy-level machinery, layers 1 .. lbot - 1 below every cloud of the workgroup
+    const int lbot = ltop >= 1 ? min(max(__builtin_amdgcn_readfirstlane(W.hbot[(blockIdx.x * nsb) / SORT_GROUP]), 1), ltop) : 1;
 
-    // ------------------------------------------------------------------ downward: layers ltop .. 1
-    if (any_bin) sweep(true_type{}, true_type{}); else sweep(false_type{}, true_type{});
+    // ------------------------------------------------------------------ downward: layers ltop .. lbot, then lbot - 1 .. 1
+    if (any_bin) { sweep(true_type{}, true_type{}, false_type{}, ltop, ltop - lbot + 1); sweep(true_type{}, true_type{}, true_type{}, lbot - 1, lbot - 1); }
+    else { sweep(false_type{}, true_type{}, false_type{}, ltop, ltop - lbot + 1); sweep(false_type{}, true_type{}, true_type{}, lbot - 1, lbot - 1); }
     // ------------------------------------------------------------------ surface: rtrnmr :629-652
     {
         const double reflect = 1. - a.emis[gc + (size_t)nct * (B - 1)];
@@ -3329,8 +3412,9 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         round_end(false_type{}, 0, 1);              // level 0
     }
     seen = colcloud;
-    // ------------------------------------------------------------------ upward: layers 1 .. ltop
-    if (any_bin) sweep(true_type{}, false_type{}); else sweep(false_type{}, false_type{});
+    // ------------------------------------------------------------------ upward: layers 1 .. lbot - 1, then lbot .. ltop
+    if (any_bin) { sweep(true_type{}, false_type{}, true_type{}, 1, lbot - 1); sweep(true_type{}, false_type{}, false_type{}, lbot, ltop - lbot + 1); }
+    else { sweep(false_type{}, false_type{}, true_type{}, 1, lbot - 1); sweep(false_type{}, false_type{}, false_type{}, lbot, ltop - lbot + 1); }
     if (incol) {                    // upward radiances at level ltop for k_sweepc<., 2>
         // (the hand-off address is formed again from the lane's column offset, hidden from common-subexpression elimination: held in
         // registers from the first use at the top of the kernel it cost the rtrnmr instantiations the two registers they were over budget)

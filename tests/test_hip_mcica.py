@@ -177,7 +177,8 @@ def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld):
     from test_hip_parity import _block_top_inputs, _compare_thin_layers
     nlay = 60
     ncol = 64 * 27 + 9
-    d = _block_top_inputs(ncol, nlay, [0, 14, nlay, 1, 30, 0, 14, 59, 2, 45, 14, 14, 7], seed=9)
+    d = _block_top_inputs(ncol, nlay, [0, 14, nlay, 1, 30, 0, 14, 59, 2, 45, 14, 14, 7], seed=9,
+                          bases=[1, 9, 40, 1, 30, 1, 1, 50, 2, 20, 14, 3, 7])          # (cloud bases change from block to block as well: k_sweepz's lbot)
     dz, lat = _geometry(ncol, nlay)
     alpha = oracle.get_alpha(ncol, nlay, icld, 0, 2500.0, dz, lat, 100, d["cldfr"])
     dd = _with_subcolumns(oracle, d, icld, alpha=alpha)

@@ -277,14 +277,16 @@ def _compare_thin_layers(got, ref, d, idrv, tag):
     assert got["icld"] == ref["icld"]
 
 
-def _block_top_inputs(ncol, nlay, tops, seed=5):
+def _block_top_inputs(ncol, nlay, tops, seed=5, bases=None):
     """Cloud decks whose top layer changes from one 64-column block to the next: block b reaches layer tops[b % len(tops)] (0 = the
-    block holds no cloud), a third of its columns cloud-free, gaps inside the decks."""
+    block holds no cloud), a third of its columns cloud-free, gaps inside the decks.  bases: the lowest cloudy layer of the block's
+    decks (default 1), changing from block to block as well."""
     d = make_gcm_inputs(ncol, nlay, "cloudy", col0=17)
     rng = np.random.default_rng(seed)
     top = np.array([tops[(c // 64) % len(tops)] for c in range(ncol)])
+    base = np.array([(bases[(c // 64) % len(bases)] if bases else 1) for c in range(ncol)])
     lay = np.arange(1, nlay + 1)[None, :]
-    inside = (lay <= top[:, None]) & (rng.random((ncol, 1)) < 0.67) & (rng.random((ncol, nlay)) < 0.8)
+    inside = (lay <= top[:, None]) & (lay >= base[:, None]) & (rng.random((ncol, 1)) < 0.67) & (rng.random((ncol, nlay)) < 0.8)
     # one column per cloudy block reaches the block's top for certain
     for b in range((ncol + 63) // 64):
         t = tops[b % len(tops)]
@@ -311,6 +313,22 @@ def test_cloud_top_changes_from_block_to_block(hip, oracle, icld, idrv):
     got = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
     ref = oracle.rrtmg_lw(ncol, nlay, icld, idrv, d)
     _compare_thin_layers(got, ref, d, idrv, f"block tops icld={icld} idrv={idrv}")
+    assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
+
+
+@pytest.mark.parametrize("icld", [1, 2])
+@pytest.mark.parametrize("idrv", [0, 1])
+def test_cloud_base_changes_from_block_to_block(hip, oracle, icld, idrv):
+    """Below the lowest cloud of a group of blocks the cloud-zone sweep runs its clear-sky levels without the cloudy-level inputs
+    (k_sweepz, layers 1 .. lbot - 1): decks with bases at layers 1 / 9 / 30 / top (one-layer decks) / nlay, next to blocks without cloud."""
+    nlay = 60
+    ncol = 64 * 29 + 11
+    tops = [14, 20, 45, 30, 0, nlay, 12, 33, 9, 59, 25, 40, 16]
+    bases = [1, 9, 30, 30, 1, nlay, 12, 2, 9, 50, 3, 39, 15]
+    d = _block_top_inputs(ncol, nlay, tops, seed=13, bases=bases)
+    got = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, idrv, d)
+    _compare_thin_layers(got, ref, d, idrv, f"block bases icld={icld} idrv={idrv}")
     assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
 
 
