@@ -2641,6 +2641,9 @@ __host__ __device__ constexpr int sweepc_nt(int NQ, int PHASE, bool IDRV)
     // per SIMD.  Three threads of one quad (RRLW_SWEEPC_SPLIT3 = 1: three waves per SIMD, nothing spilled) repeat the level's Planck terms,
     // fraction rows and temperature loads three times: 8.26 ms against 5.59 per 5e5 137-layer columns - the one-wave form stays.
     if (RRLW_SWEEPC_SPLIT3 && NQ == 3 && PHASE == 2 && IDRV) return 3;
+#ifdef RRLW_SWEEPC_SPLIT_P1       // measurement: the downward clear-sky sweep of the 16-g-point bands on two threads as well
+    if (RRLW_SWEEPC_SPLIT && NQ == 4) return 2;
+#endif
     return (RRLW_SWEEPC_SPLIT && NQ == 4 && (PHASE == 2 || PHASE == 0)) ? 2 : 1;
 }
 // bands per group: what fits the wave slots of the most register-hungry instantiation (phase 2 with d/dT)
