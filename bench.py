@@ -218,7 +218,7 @@ def main():
 
         def host_rate(cfg):
             """columns/s of the host-pointer entry on `cfg` columns: pageable numpy arrays, then every array pinned once
-            (rrtmg_lw_hip_host_register), as a host model with persistent arrays would have them"""
+            (rrtmg_lw_hip_host_register); input and output arrays persist across the calls, as a host model's do"""
             dh = make_gcm_inputs(nh, nlay, cfg, col0=col0)
             hidrv = dh["idrv"]
             hbytes = algo_bytes_per_col(nlay, hidrv) * nh
@@ -230,10 +230,10 @@ def main():
                     api.rrtmg_lw_from_dict(dh, out=out)
                 return (time.perf_counter() - t1) / reps
 
-            th = timed()
+            hout = api._out_arrays(nh, nlay, hidrv)                      # persistent arrays in both legs (a host model's live for the whole run)
+            th = timed(out=hout)
             r = dict(value=round(nh / th, 1), unit="columns/s", columns=nh, ms=round(1e3 * th, 2), host_GBps=round(hbytes / th / 1e9, 2))
             try:
-                hout = api._out_arrays(nh, nlay, hidrv)
                 pinned = [v for v in list(dh.values()) + list(hout.values()) if isinstance(v, np.ndarray) and v.flags.f_contiguous and v.dtype == np.float64]
                 for v in pinned:
                     api.host_register(v)
@@ -246,9 +246,10 @@ def main():
             return r
 
         e2e = host_rate(args.config)
-        e2e["note"] = ("rrtmg_lw_hip_run_nomcica with host arrays: H2D | kernels | D2H pipelined over the column batches; all-zero "
-                       "(layer, band) rows of tauaer are not copied and taucld travels as its band sum (inflglw >= 1); host_GBps counts the "
-                       "interface's bytes, not the bytes copied")
+        e2e["note"] = ("rrtmg_lw_hip_run_nomcica with host arrays: scan + pack | H2D | kernels | D2H | unpack pipelined over the column batches; "
+                       "rows holding one value for a batch's columns (zero aerosol / cloud rows, well-mixed gases) are filled on the device instead of "
+                       "copied, taucld travels as its band sum (inflglw >= 1), pageable arrays go through pinned staging packed by host threads; "
+                       "host_GBps counts the interface's bytes, not the bytes copied - the entry is bound by the host threads' reads of them")
         if args.config != "aer_idrv":
             # the same with aerosol optical depths in layers 1-12 of every band (192 of the 1152 rows non-zero) and idrv = 1
             e2e["with_aerosol_idrv1"] = host_rate("aer_idrv")

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -22,7 +23,8 @@ namespace {
 using namespace rrlw;
 
 constexpr int BLOCK = 256;
-constexpr int HOST_BATCH = 32768;      // columns per batch of the host-pointer entries (H2D | kernels | D2H pipeline)
+// columns per batch of the host-pointer entries (H2D | kernels | D2H pipeline); RRTMG_LW_HOST_BATCH overrides (measurements)
+const int HOST_BATCH = []() { const char *e = getenv("RRTMG_LW_HOST_BATCH"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 16384; }();     // 16 384: the entries are bound by the host threads, short batches fill and drain the pipeline sooner (524 288 columns pinned: 93.8 ms against 119.6 with 32 768)
 
 struct State {
     bool init = false;
@@ -67,7 +69,10 @@ struct State {
     hipStream_t cp_in = nullptr, cp_out = nullptr;      // host-pointer entries: H2D and D2H copy streams
     double *h_tot = nullptr;                            // pinned host scratch of the non-McICA host entry: tauctot of two column batches
     size_t h_tot_doubles = 0;
-    std::vector<unsigned char> zrow[2];                 // ... and the zero-row flags of tauaer and taucld
+    // pinned host staging of the host-pointer entries, two sets like the device staging: `in` = the rows of the caller's PAGEABLE input
+    // arrays that travel (packed by the host threads, then one DMA per run of rows), `out` = the pageable output arrays' rows (DMA, then
+    // unpacked by the host threads), `fill` = the table of k_fill_rows (rows that do not travel)
+    struct HostSet { char *in = nullptr; size_t in_cap = 0; char *out = nullptr; size_t out_cap = 0; char *fill = nullptr; size_t fill_cap = 0; } hset[2];
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
     std::string err;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -704,11 +709,14 @@ int check_common(int ncol, int nlay)
 // ---- host-pointer staging ---------------------------------------------------------------------------
 // Every array of the interface is [rows][ncol][inner] with `inner` fastest (inner = 1 for (ncol,nlay) arrays,
 // 16 for taucld, 140 for the McICA sub-column arrays); a column block is therefore one 2-D copy.
-// prepared = the device copy is filled by the entry itself (host-side reduction of the array: tauctot), not copied from h;
-// rowzero = per-row flags of the CURRENT column batch: a row whose values are all +0.0 is not copied - the device copy is zeroed
-// with one memset and only the runs of other rows travel (aerosol / in-cloud optical depths are zero in most (layer, band) rows).
-struct HostIn { const double *h; size_t inner, rows; double *d; bool prepared = false; const unsigned char *rowzero = nullptr; };
-struct HostOut { double *h; size_t rows; double *d; bool active; };
+// The pipelined entries (host_pipeline) fill `src` per batch: where the batch's rows are read from - the caller's array, or an entry's
+// own pinned scratch for an array it reduces on the host (tauctot).
+struct HostIn {
+    const double *h; size_t inner, rows; double *d;
+    bool pinned = false;                                  // h is page-locked (rrtmg_lw_hip_host_register, or pinned by the caller's own means)
+    const double *src = nullptr; size_t src_ncol = 0, src_col0 = 0; bool src_pinned = false;
+};
+struct HostOut { double *h; size_t rows; double *d; bool active; bool pinned = false; };
 
 int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
 {
@@ -722,28 +730,29 @@ int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
     return 0;
 }
 
+// the plain form (small one-batch entries: get_alpha, the stand-alone generator)
 int stage_in(std::vector<HostIn> &ins, size_t ncol, size_t col0, size_t nb, hipStream_t s)
 {
     for (auto &a : ins) {
-        if (!a.h || a.prepared) continue;
+        if (!a.h) continue;
         const size_t w = a.inner * nb * 8, sp = a.inner * ncol * 8;
-        if (!a.rowzero) {
-            HIP_TRY(hipMemcpy2DAsync(a.d, w, a.h + a.inner * col0, sp, w, a.rows, hipMemcpyHostToDevice, s));
-            continue;
-        }
-        HIP_TRY(hipMemsetAsync(a.d, 0, w * a.rows, s));
-        for (size_t r0 = 0; r0 < a.rows;) {
-            if (a.rowzero[r0]) { r0++; continue; }
-            size_t r1 = r0 + 1;
-            while (r1 < a.rows && !a.rowzero[r1]) r1++;
-            HIP_TRY(hipMemcpy2DAsync(a.d + a.inner * nb * r0, w, a.h + a.inner * (col0 + ncol * r0), sp, w, r1 - r0, hipMemcpyHostToDevice, s));
-            r0 = r1;
-        }
+        HIP_TRY(hipMemcpy2DAsync(a.d, w, a.h + a.inner * col0, sp, w, a.rows, hipMemcpyHostToDevice, s));
     }
     return 0;
 }
 
-// f(t, nt) on nt host threads (the host-pointer entries' own arithmetic on the caller's arrays: row scans, tauctot)
+int stage_out(std::vector<HostOut> &outs, size_t ncol, size_t col0, size_t nb, hipStream_t s)
+{
+    for (auto &a : outs) {
+        if (!a.active || !a.h) continue;
+        const size_t w = nb * 8, sp = ncol * 8;
+        HIP_TRY(hipMemcpy2DAsync(a.h + col0, sp, a.d, w, w, a.rows, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// f(t, nt) on nt host threads (the host-pointer entries' own work on the caller's arrays: row scans, packing, tauctot)
 int host_threads()
 {
     static const int nt = []() {         // (initialised once, thread-safe: the fan-out's worker threads all come through here)
@@ -769,31 +778,30 @@ void host_parallel(size_t work_bytes, F f)
     for (auto &x : th) x.join();
 }
 
-// flags[r] = 1 when row r of the column batch [col0, col0 + nb) of a (rows, ncol, inner) array holds nothing but +0.0
-void scan_zero_rows(const double *h, size_t inner, size_t rows, size_t ncol, size_t col0, size_t nb, unsigned char *flags)
+// ranges the caller pinned through rrtmg_lw_hip_host_register; arrays pinned by other means (hipHostMalloc, a framework's pinned
+// allocator) are recognised by the runtime's pointer attributes
+std::vector<std::pair<const char *, size_t>> g_pinned;
+bool host_range_pinned(const void *p, size_t bytes)
 {
-    host_parallel(inner * rows * nb * 8, [&](int t, int nt) {
-        for (size_t r = rows * t / nt; r < rows * (t + 1) / nt; r++) {
-            const uint64_t *p = reinterpret_cast<const uint64_t *>(h + inner * (col0 + ncol * r));
-            const size_t n = inner * nb;
-            uint64_t acc = 0;
-            size_t i = 0;
-            for (; i + 64 <= n && acc == 0; i += 64)
-                for (size_t k = 0; k < 64; k++) acc |= p[i + k];
-            for (; i < n; i++) acc |= p[i];
-            flags[r] = acc == 0;
-        }
-    });
+    const char *a = (const char *)p;
+    if (!a || bytes == 0) return false;
+    for (auto &r : g_pinned)
+        if (a >= r.first && a + bytes <= r.first + r.second) return true;
+    for (const char *q : {a, a + bytes - 1}) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
 }
 
-int stage_out(std::vector<HostOut> &outs, size_t ncol, size_t col0, size_t nb, hipStream_t s)
+int ensure_hostbuf(char **p, size_t *cap, size_t bytes)
 {
-    for (auto &a : outs) {
-        if (!a.active || !a.h) continue;
-        const size_t w = nb * 8, sp = ncol * 8;
-        HIP_TRY(hipMemcpy2DAsync(a.h + col0, sp, a.d, w, w, a.rows, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
+    if (*cap >= bytes) return 0;
+    if (*p) { HIP_TRY(hipHostFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocDefault));
+    *cap = want;
     return 0;
 }
 
@@ -810,58 +818,225 @@ int ensure_copy_streams()
     return 0;
 }
 
+// One column batch of the input arrays -> device staging (stream s), moving only what has to move:
+//  * a row (one layer, or one (layer, band) of tauaer) whose nb x inner values all hold the same 8-byte pattern does not travel: runs of
+//    such rows become entries of the k_fill_rows table.  Well-mixed gases handed over as constants, cloud arrays outside the cloudy
+//    layers and aerosol optical depths outside the aerosol layers are most of a GCM call's bytes; the device arrays are bit-identical
+//    to copied ones.  A row that is not uniform leaves the scan at its first 64 values.
+//  * rows of a PAGEABLE array are packed into the pinned set by the host threads and leave as one asynchronous DMA per run of rows
+//    (the runtime's own pageable path is one blocking, single-threaded staging copy per call); rows of a pinned array leave from
+//    where they lie.
+// The pinned set k is free: the caller has waited for the DMAs of the batch that used it last.
+struct StagedRow { unsigned arr, row; bool uniform; uint64_t bits; size_t off; };
+int stage_rows(std::vector<HostIn> &ins, size_t nb, int k, hipStream_t s)
+{
+    static thread_local std::vector<StagedRow> tl_rows;
+    std::vector<StagedRow> &rows = tl_rows;          // (the host threads below must see THIS thread's list)
+    rows.clear();
+    size_t bytes = 0, nrows = 0;
+    for (auto &a : ins) nrows += a.h ? a.rows : 0;
+    rows.reserve(nrows);
+    for (size_t ai = 0; ai < ins.size(); ai++) {
+        const HostIn &a = ins[ai];
+        if (!a.h) continue;
+        for (size_t r = 0; r < a.rows; r++) rows.push_back({(unsigned)ai, (unsigned)r, false, 0, 0});
+        bytes += a.inner * a.rows * nb * 8;
+    }
+    auto row_src = [&](const StagedRow &q) { const HostIn &a = ins[q.arr]; return a.src + a.inner * (a.src_col0 + a.src_ncol * q.row); };
+    host_parallel(bytes, [&](int t, int nt) {
+        for (size_t j = (size_t)t; j < rows.size(); j += (size_t)nt) {
+            StagedRow &q = rows[j];
+            const uint64_t *p = reinterpret_cast<const uint64_t *>(row_src(q));
+            const size_t n = ins[q.arr].inner * nb;
+            const uint64_t v = p[0];
+            uint64_t acc = 0;
+            size_t i = 0;
+            for (; i + 64 <= n && acc == 0; i += 64)
+                for (size_t e = 0; e < 64; e++) acc |= p[i + e] ^ v;
+            for (; i < n; i++) acc |= p[i] ^ v;
+            q.uniform = acc == 0;
+            q.bits = v;
+        }
+    });
+    size_t need = 0;
+    for (auto &q : rows)
+        if (!q.uniform && !ins[q.arr].src_pinned) { q.off = need; need += ins[q.arr].inner * nb * 8; }
+    auto &hs = G.hset[k];
+    if (int rc = ensure_hostbuf(&hs.in, &hs.in_cap, need)) return rc;
+    if (need)
+        host_parallel(2 * need, [&](int t, int nt) {
+            for (size_t j = (size_t)t; j < rows.size(); j += (size_t)nt) {
+                const StagedRow &q = rows[j];
+                if (!q.uniform && !ins[q.arr].src_pinned) memcpy(hs.in + q.off, row_src(q), ins[q.arr].inner * nb * 8);
+            }
+        });
+    RowFill *tab = reinterpret_cast<RowFill *>(hs.fill);
+    size_t nf = 0;
+    for (size_t j = 0; j < rows.size();) {
+        const StagedRow &q = rows[j];
+        const HostIn &a = ins[q.arr];
+        const size_t w = a.inner * nb;                    // values per row
+        size_t j1 = j + 1;
+        while (j1 < rows.size() && rows[j1].arr == q.arr && rows[j1].uniform == q.uniform && (!q.uniform || rows[j1].bits == q.bits)) j1++;
+        const size_t nr = j1 - j;
+        double *dst = a.d + w * q.row;
+        if (q.uniform) {
+            for (size_t done = 0; done < nr * w; done += FILL_MAX)
+                tab[nf++] = RowFill{reinterpret_cast<unsigned long long *>(dst + done), std::min<unsigned long long>(FILL_MAX, nr * w - done), q.bits};
+        } else if (a.src_pinned) {
+            HIP_TRY(hipMemcpy2DAsync(dst, w * 8, row_src(q), a.inner * a.src_ncol * 8, w * 8, nr, hipMemcpyHostToDevice, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(dst, hs.in + q.off, nr * w * 8, hipMemcpyHostToDevice, s));
+        }
+        j = j1;
+    }
+    for (size_t f0 = 0; f0 < nf; f0 += 65535)
+        hipLaunchKernelGGL(k_fill_rows, dim3(FILL_BLOCKS, (unsigned)std::min<size_t>(65535, nf - f0)), dim3(256), 0, s, (const RowFill *)(tab + f0));
+    return 0;
+}
+
 // Host-pointer entries as a three-stage pipeline over the column batches: H2D of batch i+1 (copy stream) | kernels of
-// batch i (G.stream) | D2H of batch i-1 (second copy stream), two staging sets.  With pageable host arrays the copies
-// block the calling thread, which still overlaps them with the kernels of the previous batch; with arrays pinned through
-// rrtmg_lw_hip_host_register they are asynchronous DMA at PCIe rate.  body(stream, nb, in_ptrs, out_ptrs) enqueues the
-// kernels of one batch whose staged arrays start at column 0.
+// batch i (G.stream) | D2H of batch i-1 (second copy stream), two staging sets on the device and two pinned sets on the host.
+// The calling thread (with the host threads) scans and packs batch i+1 and unpacks the outputs of batch i-1 while the DMAs and
+// kernels of the batches between are in flight; nothing it calls blocks on a copy.  body(stream, nb, col0, in, out) enqueues the
+// kernels of one batch whose staged arrays start at column 0; prep(k, col0, nb, stream) is the entry's own host work for the batch.
+// RRTMG_LW_STAGE_TIMING=1: per call, the pipeline prints where its time went (host phases by the clock, device stages by events)
+const bool g_stage_timing = []() { const char *e = getenv("RRTMG_LW_STAGE_TIMING"); return e && atoi(e) != 0; }();
+struct StageClock {
+    double t[8] = {};          // 0 wait h2d, 1 unpack (incl. wait for the D2H), 2 prep, 3 scan + pack + enqueue, 4 body enqueue, 5 copy_out enqueue, 6 final drain
+    std::chrono::steady_clock::time_point last;
+    void start() { last = std::chrono::steady_clock::now(); }
+    void lap(int k) { auto n = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double, std::milli>(n - last).count(); last = n; }
+};
 struct NoPrep { int operator()(int, int, int, hipStream_t) const { return 0; } };
 template <class Body, class Prep = NoPrep>
 int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body, Prep prep = Prep())
 {   // columns [c0, c1) of arrays that are ncol columns wide
     if (int rc = ensure_copy_streams()) return rc;
-    size_t set = 0;
-    for (auto &a : ins) set += a.h ? a.inner * a.rows * (size_t)nbmax : 0;
-    for (auto &a : outs) set += a.rows * (size_t)nbmax;
+    size_t set = 0, nrows = 0, out_pageable = 0;
+    for (auto &a : ins) {
+        set += a.h ? a.inner * a.rows * (size_t)nbmax : 0;
+        nrows += a.h ? a.rows + a.inner * a.rows * (size_t)nbmax / FILL_MAX + 1 : 0;
+        a.pinned = a.h && host_range_pinned(a.h, a.inner * (size_t)ncol * a.rows * 8);
+    }
+    for (auto &a : outs) {
+        set += a.rows * (size_t)nbmax;
+        a.pinned = a.active && a.h && host_range_pinned(a.h, (size_t)ncol * a.rows * 8);
+        if (a.active && a.h && !a.pinned) out_pageable += a.rows * (size_t)nbmax * 8;
+    }
     set = align_up(set * 8, 256);
     if (int rc = ensure_stage(2 * set + 4096)) return rc;
+    for (auto &hs : G.hset) {
+        if (int rc = ensure_hostbuf(&hs.fill, &hs.fill_cap, nrows * sizeof(RowFill))) return rc;
+        if (int rc = ensure_hostbuf(&hs.out, &hs.out_cap, out_pageable)) return rc;
+    }
     auto bind = [&](int k) {                 // point the descriptors at staging set k
         double *p = (double *)((char *)G.stage_base + (size_t)k * set);
         for (auto &a : ins) { a.d = a.h ? p : nullptr; p += a.h ? a.inner * a.rows * (size_t)nbmax : 0; }
         for (auto &a : outs) { a.d = p; p += a.rows * (size_t)nbmax; }
     };
+    struct Pending { bool on = false; int col0 = 0, nb = 0; } pend[2];
     auto copy_out = [&](int k, int col0, int nb) -> int {
         bind(k);
         HIP_TRY(hipStreamWaitEvent(G.cp_out, G.ev_cmp[k], 0));
+        char *p = G.hset[k].out;
+        bool any = false;
         for (auto &a : outs) {
             if (!a.active || !a.h) continue;
             const size_t w = (size_t)nb * 8, sp = (size_t)ncol * 8;
-            HIP_TRY(hipMemcpy2DAsync(a.h + col0, sp, a.d, w, w, a.rows, hipMemcpyDeviceToHost, G.cp_out));
+            if (a.pinned) { HIP_TRY(hipMemcpy2DAsync(a.h + col0, sp, a.d, w, w, a.rows, hipMemcpyDeviceToHost, G.cp_out)); continue; }
+            HIP_TRY(hipMemcpyAsync(p, a.d, a.rows * w, hipMemcpyDeviceToHost, G.cp_out));
+            p += a.rows * w;
+            any = true;
         }
         HIP_TRY(hipEventRecord(G.ev_d2h[k], G.cp_out));
+        pend[k] = Pending{any, col0, nb};
         return 0;
     };
+    auto unpack = [&](int k) -> int {        // the pageable output arrays' rows of the batch that used set k last: pinned set -> the caller's arrays
+        if (!pend[k].on) return 0;
+        pend[k].on = false;
+        HIP_TRY(hipEventSynchronize(G.ev_d2h[k]));
+        const size_t nb = (size_t)pend[k].nb, col0 = (size_t)pend[k].col0;
+        struct Seg { double *dst; const double *src; size_t rows; };
+        std::vector<Seg> segs;
+        size_t tot = 0;
+        const char *p = G.hset[k].out;
+        for (auto &a : outs) {
+            if (!a.active || !a.h || a.pinned) continue;
+            segs.push_back({a.h + col0, (const double *)p, a.rows});
+            p += a.rows * nb * 8;
+            tot += a.rows;
+        }
+        host_parallel(2 * tot * nb * 8, [&](int t, int nt) {
+            const size_t r0 = tot * (size_t)t / (size_t)nt, r1 = tot * (size_t)(t + 1) / (size_t)nt;
+            size_t base = 0;
+            for (auto &sg : segs) {
+                for (size_t r = std::max(r0, base); r < std::min(r1, base + sg.rows); r++)
+                    memcpy(sg.dst + (size_t)ncol * (r - base), sg.src + nb * (r - base), nb * 8);
+                base += sg.rows;
+            }
+        });
+        return 0;
+    };
+    StageClock clk;
+    std::vector<hipEvent_t> tev;             // (timing) per batch: H2D begin / end, kernels begin / end
+    auto tmark = [&](hipStream_t st) { if (!g_stage_timing) return; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); tev.push_back(e); };
+    const auto t_call = std::chrono::steady_clock::now();
     int i = 0, prev_col0 = 0, prev_nb = 0;
     for (int col0 = c0; col0 < c1; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, c1 - col0), k = i & 1;
         bind(k);
-        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.cp_in, G.ev_cmp[k], 0));          // kernels of batch i-2 have read staging set k
-        // the entry's own host work for this batch (row scans, reductions; its results go to staging set k through G.cp_in): it runs on
-        // the calling thread while the copies and kernels of the batches before are in flight
+        clk.start();
+        if (i >= 2) {
+            HIP_TRY(hipStreamWaitEvent(G.cp_in, G.ev_cmp[k], 0));          // kernels of batch i-2 have read staging set k
+            HIP_TRY(hipEventSynchronize(G.ev_h2d[k]));                     // its DMAs have left the pinned set k (this thread runs ahead of the device)
+            clk.lap(0);
+            if (int rc = unpack(k)) return rc;
+            clk.lap(1);
+        }
+        for (auto &a : ins) { a.src = a.h; a.src_ncol = (size_t)ncol; a.src_col0 = (size_t)col0; a.src_pinned = a.pinned; }
+        // the entry's own host work for this batch (reductions into its pinned scratch set k, which it then names as an array's source)
         if (int rc = prep(k, col0, nb, G.cp_in)) return rc;
-        if (int rc = stage_in(ins, (size_t)ncol, (size_t)col0, (size_t)nb, G.cp_in)) return rc;
+        clk.lap(2);
+        tmark(G.cp_in);
+        if (int rc = stage_rows(ins, (size_t)nb, k, G.cp_in)) return rc;
+        tmark(G.cp_in);
         HIP_TRY(hipEventRecord(G.ev_h2d[k], G.cp_in));
+        clk.lap(3);
         HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_h2d[k], 0));
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_d2h[k], 0));         // outputs of batch i-2 have left staging set k
-        if (int rc = body(G.stream, nb, ins, outs)) return rc;
+        tmark(G.stream);
+        if (int rc = body(G.stream, nb, col0, ins, outs)) return rc;
+        tmark(G.stream);
         HIP_TRY(hipEventRecord(G.ev_cmp[k], G.stream));
+        clk.lap(4);
         if (i >= 1)
             if (int rc = copy_out(k ^ 1, prev_col0, prev_nb)) return rc;
+        clk.lap(5);
         prev_col0 = col0; prev_nb = nb;
     }
+    clk.start();
     if (int rc = copy_out((i - 1) & 1, prev_col0, prev_nb)) return rc;
+    if (int rc = unpack(i & 1)) return rc;               // (the batch before the last, if any)
+    if (int rc = unpack((i - 1) & 1)) return rc;
     HIP_TRY(hipStreamSynchronize(G.cp_out));
     HIP_TRY(hipStreamSynchronize(G.stream));
+    clk.lap(6);
+    if (g_stage_timing) {
+        double h2d = 0.0, ker = 0.0;
+        for (size_t e = 0; e + 3 < tev.size(); e += 4) {
+            float a = 0.f, b = 0.f;
+            (void)hipEventElapsedTime(&a, tev[e], tev[e + 1]);
+            (void)hipEventElapsedTime(&b, tev[e + 2], tev[e + 3]);
+            h2d += a; ker += b;
+        }
+        for (auto e : tev) (void)hipEventDestroy(e);
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        fprintf(stderr, "[rrtmg_lw_hip stage] %d columns in %d batches of <= %d: wall %.2f ms | host: wait-h2d %.2f unpack(+wait d2h) %.2f prep %.2f scan+pack+enqueue %.2f "
+                        "body-enqueue %.2f copy_out-enqueue %.2f drain %.2f | device: H2D stream busy %.2f kernels %.2f\n",
+                c1 - c0, i, nbmax, wall, clk.t[0], clk.t[1], clk.t[2], clk.t[3], clk.t[4], clk.t[5], clk.t[6], h2d, ker);
+    }
     return 0;
 }
 
@@ -1234,6 +1409,11 @@ static void finalize_state()
         (void)hipEventDestroy(G.ev_swq_go);
     }
     if (G.h_tot) (void)hipHostFree(G.h_tot);
+    for (auto &hs : G.hset) {
+        if (hs.in) (void)hipHostFree(hs.in);
+        if (hs.out) (void)hipHostFree(hs.out);
+        if (hs.fill) (void)hipHostFree(hs.fill);
+    }
     G = State();
 }
 
@@ -1398,13 +1578,13 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
     // What the copies need not carry (62 % of a column's bytes are taucld and tauaer, 2 x 16 nlay values):
     //  * with inflglw >= 1 cldprop reads taucld only through the sum over the bands, tauctot (src/rrtmg_lw_cldprop.f90:173-186): the sum is
     //    formed here, in the reference's order, on the host threads - one value per (column, layer) travels instead of sixteen;
-    //  * a (layer, band) row of tauaer - and with inflglw = 0 a layer of taucld - that is all zero for the batch's columns is not copied.
+    //  * rows that hold one value for all columns of a batch - zero aerosol / cloud rows, well-mixed gases - are not copied (stage_rows).
     const bool use_tot = cloud && inflglw != 0;
     std::vector<HostIn> ins = {
         {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
         {h2ovmr, 1, L, 0}, {o3vmr, 1, L, 0}, {co2vmr, 1, L, 0}, {ch4vmr, 1, L, 0}, {n2ovmr, 1, L, 0}, {o2vmr, 1, L, 0},
         {cfc11vmr, 1, L, 0}, {cfc12vmr, 1, L, 0}, {cfc22vmr, 1, L, 0}, {ccl4vmr, 1, L, 0}, {emis, 1, 16, 0}, {tauaer, 1, 16 * L, 0},
-        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, (size_t)(use_tot ? 1 : NBND), L, 0, use_tot}, {cloud ? cicewp : nullptr, 1, L, 0},
+        {cloud ? cldfr : nullptr, 1, L, 0}, {cloud ? taucld : nullptr, (size_t)(use_tot ? 1 : NBND), L, 0}, {cloud ? cicewp : nullptr, 1, L, 0},
         {cloud ? cliqwp : nullptr, 1, L, 0}, {cloud ? reice : nullptr, 1, L, 0}, {cloud ? reliq : nullptr, 1, L, 0}};
     for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
@@ -1413,36 +1593,26 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
         HIP_TRY(hipHostMalloc((void **)&G.h_tot, 2 * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
         G.h_tot_doubles = 2 * L * (size_t)nbmax;
     }
-    for (auto &z : G.zrow) z.assign(17 * L, 0);
-    auto prep = [&](int k, int col0, int nb, hipStream_t cs) -> int {
-        unsigned char *zf = G.zrow[k].data();
-        scan_zero_rows(tauaer, 1, 16 * L, (size_t)ncol, (size_t)col0, (size_t)nb, zf);
-        ins[16].rowzero = zf;
-        if (cloud && !use_tot) {
-            scan_zero_rows(taucld, NBND, L, (size_t)ncol, (size_t)col0, (size_t)nb, zf + 16 * L);
-            ins[18].rowzero = zf + 16 * L;
-        }
-        if (use_tot) {
-            HIP_TRY(hipEventSynchronize(G.ev_h2d[k]));       // the copy of batch i - 2 has left the pinned scratch set k (this thread runs ahead of the device)
-            double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;
-            host_parallel((size_t)NBND * L * (size_t)nb * 8, [&](int t, int nt) {
-                const size_t n = L * (size_t)nb;
-                for (size_t e = n * t / nt; e < n * (t + 1) / nt; e++) {
-                    const size_t lay = e / (size_t)nb, c = e % (size_t)nb;
-                    const double *p = taucld + (size_t)NBND * ((size_t)col0 + c + (size_t)ncol * lay);
-                    double sum = 0.0;
-                    for (int ib = 0; ib < NBND; ib++) sum = sum + p[ib];
-                    tot[e] = sum;
-                }
-            });
-            HIP_TRY(hipMemcpyAsync(ins[18].d, tot, L * (size_t)nb * sizeof(double), hipMemcpyHostToDevice, cs));
-        }
+    auto prep = [&](int k, int col0, int nb, hipStream_t) -> int {
+        if (!use_tot) return 0;
+        double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;        // (the pipeline has waited for the copies that read scratch set k last)
+        host_parallel((size_t)NBND * L * (size_t)nb * 8, [&](int t, int nt) {
+            const size_t n = L * (size_t)nb;
+            for (size_t e = n * t / nt; e < n * (t + 1) / nt; e++) {
+                const size_t lay = e / (size_t)nb, c = e % (size_t)nb;
+                const double *p = taucld + (size_t)NBND * ((size_t)col0 + c + (size_t)ncol * lay);
+                double sum = 0.0;
+                for (int ib = 0; ib < NBND; ib++) sum = sum + p[ib];
+                tot[e] = sum;
+            }
+        });
+        ins[18].src = tot; ins[18].src_ncol = (size_t)nb; ins[18].src_col0 = 0; ins[18].src_pinned = true;      // rows of nb sums, from the pinned scratch
         return 0;
     };
     std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
     for (size_t k = 0; k < 6; k++) if (!outs[k].h) return fail(RRTMG_LW_HIP_EARG, "null output array");
-    auto body = [&](hipStream_t s, int nb, std::vector<HostIn> &in, std::vector<HostOut> &out_) -> int {
+    auto body = [&](hipStream_t s, int nb, int, std::vector<HostIn> &in, std::vector<HostOut> &out_) -> int {
         GcmIn g{in[0].d, in[1].d, in[2].d, in[3].d, in[4].d, in[5].d, in[6].d, in[7].d, in[8].d, in[9].d, in[10].d,
                 in[11].d, in[12].d, in[13].d, in[14].d, in[15].d, in[17].d, use_tot ? nullptr : in[18].d, in[19].d, in[20].d, in[21].d, in[22].d, in[16].d,
                 use_tot ? in[18].d : nullptr};
@@ -1630,6 +1800,7 @@ int rrtmg_lw_hip_host_register(void *ptr, long long bytes)
     if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
     if (!ptr || bytes <= 0) return fail(RRTMG_LW_HIP_EARG, "bad host range");
     HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    g_pinned.emplace_back((const char *)ptr, (size_t)bytes);
     return 0;
 }
 
@@ -1638,6 +1809,8 @@ int rrtmg_lw_hip_host_unregister(void *ptr)
     ENTRY_LOCK;
     if (!ptr) return fail(RRTMG_LW_HIP_EARG, "null pointer");
     HIP_TRY(hipHostUnregister(ptr));
+    for (size_t i = 0; i < g_pinned.size(); i++)
+        if (g_pinned[i].first == (const char *)ptr) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
     return 0;
 }
 
@@ -1857,8 +2030,8 @@ int rrtmg_lw_hip_run_mcica(
     if (int rc = check_common(ncol, nlay)) return rc;
     HIP_TRY(hipDeviceSynchronize());        // asynchronous device-entry work of earlier calls shares the workspace
     // the sub-column arrays are 4 x 140 x nlay doubles per column: bound the batch so that staging stays below ~4 GB
-    const int mcmax = (int)std::max<size_t>(64, ((size_t)4 << 30) / ((size_t)4 * NGPT * nlay * 8));
-    const int nbmax = std::min(c1 - c0, cloud ? std::min(G.batch, mcmax) : G.batch);
+    const int mcmax = (int)std::max<size_t>(64, ((size_t)2 << 30) / ((size_t)4 * NGPT * nlay * 8));        // (two staging sets)
+    const int nbmax = balanced_batch(c1 - c0, std::min(std::min(G.batch, HOST_BATCH), cloud ? mcmax : HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud)) return rc;
     const size_t L = (size_t)nlay;
     std::vector<HostIn> ins = {
@@ -1871,19 +2044,16 @@ int rrtmg_lw_hip_run_mcica(
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null McICA cloud array");
     std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
-    if (int rc = stage_alloc(ins, outs, (size_t)nbmax)) return rc;
-    hipStream_t s = G.stream;
-    for (int col0 = c0; col0 < c1; col0 += nbmax) {
-        const int nb = std::min(nbmax, c1 - col0);
-        if (int rc = stage_in(ins, (size_t)ncol, (size_t)col0, (size_t)nb, s)) return rc;
-        GcmIn g{ins[0].d, ins[1].d, ins[2].d, ins[3].d, ins[4].d, ins[5].d, ins[6].d, ins[7].d, ins[8].d, ins[9].d, ins[10].d,
-                ins[11].d, ins[12].d, ins[13].d, ins[14].d, ins[15].d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ins[16].d};
-        McIn m{ins[17].d, ins[18].d, ins[19].d, ins[20].d, ins[21].d, ins[22].d};
+    auto body = [&](hipStream_t s, int nb, int, std::vector<HostIn> &in, std::vector<HostOut> &out_) -> int {
+        GcmIn g{in[0].d, in[1].d, in[2].d, in[3].d, in[4].d, in[5].d, in[6].d, in[7].d, in[8].d, in[9].d, in[10].d,
+                in[11].d, in[12].d, in[13].d, in[14].d, in[15].d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, in[16].d};
+        McIn m{in[17].d, in[18].d, in[19].d, in[20].d, in[21].d, in[22].d};
         ColIn c{};
-        FluxOut out{outs[0].d, outs[1].d, outs[2].d, outs[3].d, outs[4].d, outs[5].d, outs[6].d, outs[7].d, nullptr, nullptr};
-        if (int rc = run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, &m)) return rc;
-        if (int rc = stage_out(outs, (size_t)ncol, (size_t)col0, (size_t)nb, s)) return rc;
-    }
+        FluxOut out{out_[0].d, out_[1].d, out_[2].d, out_[3].d, out_[4].d, out_[5].d, out_[6].d, out_[7].d, nullptr, nullptr};
+        return run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, &m);
+    };
+    if (int rc = host_pipeline(ncol, c0, c1, nbmax, ins, outs, body)) return rc;
+    hipStream_t s = G.stream;
     return read_physics_error(s);
     });
 }
@@ -2021,7 +2191,7 @@ int rrtmg_lw_hip_run_mcica_subcol(
     if (*icld > 3) *icld = 2;
     const int mode = icld_gen == 0 ? 0 : 3;
     const bool cloud = mode == 3, two = icld_gen == 4 || icld_gen == 5;
-    const int nbmax = balanced_batch(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, std::min(G.batch, HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, cloud, false)) return rc;
     const size_t L = (size_t)nlay, n = (size_t)ncol;
     hipStream_t s = G.stream;
@@ -2050,17 +2220,17 @@ int rrtmg_lw_hip_run_mcica_subcol(
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
     std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
-    if (int rc = stage_alloc(ins, outs, (size_t)nbmax)) return rc;
-    for (int col0 = 0; col0 < ncol; col0 += nbmax) {
-        const int nb = std::min(nbmax, ncol - col0);
-        if (int rc = stage_in(ins, n, (size_t)col0, (size_t)nb, s)) return rc;
-        GcmIn g{ins[0].d, ins[1].d, ins[2].d, ins[3].d, ins[4].d, ins[5].d, ins[6].d, ins[7].d, ins[8].d, ins[9].d, ins[10].d,
-                ins[11].d, ins[12].d, ins[13].d, ins[14].d, ins[15].d, ins[17].d, ins[18].d, ins[19].d, ins[20].d, ins[21].d, ins[22].d, ins[16].d};
+    auto body = [&](hipStream_t bs, int nb, int col0, std::vector<HostIn> &in, std::vector<HostOut> &out_) -> int {
+        GcmIn g{in[0].d, in[1].d, in[2].d, in[3].d, in[4].d, in[5].d, in[6].d, in[7].d, in[8].d, in[9].d, in[10].d,
+                in[11].d, in[12].d, in[13].d, in[14].d, in[15].d, in[17].d, in[18].d, in[19].d, in[20].d, in[21].d, in[22].d, in[16].d};
         ColIn c{};
-        FluxOut out{outs[0].d, outs[1].d, outs[2].d, outs[3].d, outs[4].d, outs[5].d, outs[6].d, outs[7].d, nullptr, nullptr};
+        FluxOut out{out_[0].d, out_[1].d, out_[2].d, out_[3].d, out_[4].d, out_[5].d, out_[6].d, out_[7].d, nullptr, nullptr};
         G.W.mask_col0 = (size_t)col0;                             // staged arrays start at column 0, the mask holds all columns
-        if (int rc = run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, nullptr)) return rc;
-        if (int rc = stage_out(outs, n, (size_t)col0, (size_t)nb, s)) return rc;
+        return run_batch<true>(bs, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, nullptr);
+    };
+    {
+        const int rc = host_pipeline(ncol, 0, ncol, nbmax, ins, outs, body);
+        if (rc) { G.W.mask_col0 = 0; return rc; }
     }
     G.W.mask_col0 = 0;
     return read_physics_error(s);

@@ -3674,4 +3674,18 @@ __global__ __launch_bounds__(256) void k_calibrate(const double2 *__restrict__ i
     if (i < n) { double2 v = in[i]; v.x += 1.0; out[i] = v; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_fill_rows : the host-pointer entries do not copy a row of an input array whose values are all the same for the columns of a batch
+//               (well-mixed gases, cloud and aerosol arrays outside the cloudy / dusty layers): entry blockIdx.y of the table (pinned host
+//               memory, written by the entry's host threads) names a run of such rows and the 8-byte pattern they hold.
+// ------------------------------------------------------------------------------------------------
+struct RowFill { unsigned long long *dst; unsigned long long n, bits; };
+constexpr int FILL_BLOCKS = 64;
+constexpr unsigned long long FILL_MAX = 1ull << 20;      // values per table entry (a longer run is several entries)
+__global__ __launch_bounds__(256) void k_fill_rows(const RowFill *__restrict__ tab)
+{
+    const RowFill e = tab[blockIdx.y];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (unsigned long long)FILL_BLOCKS * 256) e.dst[i] = e.bits;
+}
+
 }  // namespace rrlw

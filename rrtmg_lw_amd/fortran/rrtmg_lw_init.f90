@@ -28,6 +28,17 @@
             integer(c_int), intent(in) :: devices(*)
             integer(c_int) :: rc
          end function rrtmg_lw_hip_init_devices
+         function rrtmg_lw_hip_host_register(ptr, bytes) bind(C, name='rrtmg_lw_hip_host_register') result(rc)
+            import :: c_ptr, c_long_long, c_int
+            type(c_ptr), value :: ptr
+            integer(c_long_long), value :: bytes
+            integer(c_int) :: rc
+         end function rrtmg_lw_hip_host_register
+         function rrtmg_lw_hip_host_unregister(ptr) bind(C, name='rrtmg_lw_hip_host_unregister') result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: ptr
+            integer(c_int) :: rc
+         end function rrtmg_lw_hip_host_unregister
          function rrtmg_lw_hip_last_error() bind(C, name='rrtmg_lw_hip_last_error') result(p)
             import :: c_ptr
             type(c_ptr) :: p
@@ -81,6 +92,22 @@
       endif
       if (rc /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_ini')
       end subroutine rrtmg_lw_ini
+
+!  Optional, for a host model whose profile / flux arrays live for the whole run: page-lock an array once (after rrtmg_lw_ini), and
+!  rrtmg_lw's copies of it are direct DMA - no packing through the library's pinned staging by host threads.
+!      call rrtmg_lw_pin(play, size(play))   ...   call rrtmg_lw_unpin(play)      (before the array is deallocated)
+!  `a` is any contiguous real(rb) array (sequence association), `n` its number of elements.
+      subroutine rrtmg_lw_pin(a, n)
+      real(kind=rb), intent(in), target :: a(*)
+      integer, intent(in) :: n
+      if (n < 1) return
+      if (rrtmg_lw_hip_host_register(c_loc(a), int(n, c_long_long) * 8_c_long_long) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_pin')
+      end subroutine rrtmg_lw_pin
+
+      subroutine rrtmg_lw_unpin(a)
+      real(kind=rb), intent(in), target :: a(*)
+      if (rrtmg_lw_hip_host_unregister(c_loc(a)) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_unpin')
+      end subroutine rrtmg_lw_unpin
 
 !  Turns a non-zero status of the C ABI into the reference's behaviour: print the message and stop.
       subroutine rrtmg_lw_hip_abort(where)

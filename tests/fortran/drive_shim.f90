@@ -2,7 +2,7 @@
 ! (use rrtmg_lw_init / use rrtmg_lw_rad), reading its inputs from a stream file written by tests/test_fortran_shim.py.
 program drive_shim
   use parkind, only: im => kind_im, rb => kind_rb
-  use rrtmg_lw_init, only: rrtmg_lw_ini
+  use rrtmg_lw_init, only: rrtmg_lw_ini, rrtmg_lw_pin, rrtmg_lw_unpin
   use rrtmg_lw_rad, only: rrtmg_lw
   implicit none
   integer(im) :: ncol, nlay, icld, idrv, inflg, iceflg, liqflg
@@ -11,6 +11,8 @@ program drive_shim
   real(rb), allocatable :: cld(:,:,:), taucld(:,:,:), tauaer(:,:,:)
   real(rb), allocatable :: uflx(:,:), dflx(:,:), hr(:,:), uflxc(:,:), dflxc(:,:), hrc(:,:), du(:,:), duc(:,:)
   character(len=512) :: fin, fout
+  character(len=8) :: pin
+  integer :: lpin
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
@@ -26,6 +28,16 @@ program drive_shim
   du = 0._rb; duc = 0._rb
 
   call rrtmg_lw_ini(1004.0_rb)
+  ! DRIVE_PIN=1: a host model that page-locks its persistent arrays once (rrtmg_lw_pin); the copies are then direct DMA
+  call get_environment_variable('DRIVE_PIN', pin, lpin)
+  if (lpin > 0) then
+     call rrtmg_lw_pin(play, size(play)); call rrtmg_lw_pin(plev, size(plev)); call rrtmg_lw_pin(tlay, size(tlay))
+     call rrtmg_lw_pin(tlev, size(tlev)); call rrtmg_lw_pin(tsfc, size(tsfc)); call rrtmg_lw_pin(gas, size(gas))
+     call rrtmg_lw_pin(emis, size(emis)); call rrtmg_lw_pin(cld, size(cld)); call rrtmg_lw_pin(taucld, size(taucld))
+     call rrtmg_lw_pin(tauaer, size(tauaer)); call rrtmg_lw_pin(uflx, size(uflx)); call rrtmg_lw_pin(dflx, size(dflx))
+     call rrtmg_lw_pin(hr, size(hr)); call rrtmg_lw_pin(uflxc, size(uflxc)); call rrtmg_lw_pin(dflxc, size(dflxc))
+     call rrtmg_lw_pin(hrc, size(hrc)); call rrtmg_lw_pin(du, size(du)); call rrtmg_lw_pin(duc, size(duc))
+  endif
   ! gas order in the file: h2o, o3, co2, ch4, n2o, o2, cfc11, cfc12, cfc22, ccl4 ; cld: cldfr, cicewp, cliqwp, reice, reliq
   call rrtmg_lw(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, &
                 gas(:,:,1), gas(:,:,2), gas(:,:,3), gas(:,:,4), gas(:,:,5), gas(:,:,6), &
@@ -33,6 +45,12 @@ program drive_shim
                 cld(:,:,1), taucld, cld(:,:,2), cld(:,:,3), cld(:,:,4), cld(:,:,5), tauaer, &
                 uflx, dflx, hr, uflxc, dflxc, hrc, du, duc)
 
+  if (lpin > 0) then
+     call rrtmg_lw_unpin(play); call rrtmg_lw_unpin(plev); call rrtmg_lw_unpin(tlay); call rrtmg_lw_unpin(tlev); call rrtmg_lw_unpin(tsfc)
+     call rrtmg_lw_unpin(gas); call rrtmg_lw_unpin(emis); call rrtmg_lw_unpin(cld); call rrtmg_lw_unpin(taucld); call rrtmg_lw_unpin(tauaer)
+     call rrtmg_lw_unpin(uflx); call rrtmg_lw_unpin(dflx); call rrtmg_lw_unpin(hr); call rrtmg_lw_unpin(uflxc); call rrtmg_lw_unpin(dflxc)
+     call rrtmg_lw_unpin(hrc); call rrtmg_lw_unpin(du); call rrtmg_lw_unpin(duc)
+  endif
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
   write(u) int(icld), uflx, dflx, hr, uflxc, dflxc, hrc, du, duc
   close(u)

@@ -51,10 +51,11 @@ def test_mcica_shim_modules_compile(tmp_path):
 
 @needs_flang
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,icld,ndev", [("cloudy", 2, 1), ("aer_idrv", 1, 1), ("cloudy", 2, 3)])
-def test_fortran_host_model_matches_oracle(tmp_path, oracle, config, icld, ndev):
+@pytest.mark.parametrize("config,icld,ndev,pin", [("cloudy", 2, 1, False), ("aer_idrv", 1, 1, False), ("cloudy", 2, 3, False), ("aer_idrv", 2, 1, True)])
+def test_fortran_host_model_matches_oracle(tmp_path, oracle, config, icld, ndev, pin):
     """ndev = 3: RRTMG_LW_NDEV makes rrtmg_lw_ini set up three devices (virtual ones: all on GPU 0) and rrtmg_lw split its columns
-    over them - blocks of 128, 128 and 44 columns."""
+    over them - blocks of 128, 128 and 44 columns.  pin: the host model page-locks its arrays with rrtmg_lw_pin (gas and cloud
+    arrays are sections of rank-3 arrays pinned as a whole)."""
     tmp = str(tmp_path)
     exe = _compile(tmp, link=True)
     ncol, nlay = (96, 60) if ndev == 1 else (300, 60)
@@ -74,6 +75,8 @@ def test_fortran_host_model_matches_oracle(tmp_path, oracle, config, icld, ndev)
                RRTMG_LW_KDATA=os.path.join(ROOT, "rrtmg_lw_amd", "data", "standin.kdata.bin"))
     if ndev > 1:
         env.update(RRTMG_LW_NDEV=str(ndev), RRTMG_LW_VIRTUAL_DEVICES="1")
+    if pin:
+        env.update(DRIVE_PIN="1")
     subprocess.run([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")], check=True, env=env, cwd=tmp, timeout=300)
     raw = open(os.path.join(tmp, "out.bin"), "rb").read()
     icld_out = int(np.frombuffer(raw, dtype=np.int32, count=1)[0])

@@ -377,6 +377,54 @@ def test_host_entry_skips_zero_rows_and_sums_taucld(hip, oracle):
         hip.set_batch(262144)
 
 
+def test_host_entry_rows_that_do_not_travel(hip, oracle):
+    """The host-pointer entry scans every row of every input array per column batch: a row holding ONE 8-byte pattern is filled on
+    the device (k_fill_rows) instead of copied, the other rows are packed into pinned staging by host threads (pageable arrays) or
+    leave from where they lie (pinned arrays).  Bit-equality of the three routes - device-resident inputs, pageable host arrays,
+    pinned host arrays - on inputs with: well-mixed gases as constants, a gas row that is uniform in the first batch only, a row
+    that differs in its LAST column only, a uniform row of -0.0 and one of a NaN-free denormal, uniform and non-uniform rows
+    alternating (many short copy runs), a short last batch."""
+    import torch
+    from rrtmg_lw_amd.shard import output_rows, output_views
+    ncol, nlay = 1000, 44
+    d = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=21)
+    rng = np.random.default_rng(12)
+    for k, v in (("co2vmr", 4.1e-4), ("ch4vmr", 1.8e-6), ("n2ovmr", 3.2e-7), ("o2vmr", 0.209), ("cfc11vmr", 2.3e-10), ("cfc22vmr", 0.0)):
+        d[k] = np.asfortranarray(np.full((ncol, nlay), v))
+    h2o = np.array(d["h2ovmr"]); h2o[:256, 30] = h2o[0, 30]; h2o[:, 31] = h2o[0, 31]; h2o[ncol - 1, 31] *= 1.01
+    o3 = np.array(d["o3vmr"]); o3[:, ::2] = o3[0:1, ::2]                  # every other layer uniform
+    d["h2ovmr"], d["o3vmr"] = np.asfortranarray(h2o), np.asfortranarray(o3)
+    ta = np.array(d["tauaer"]); ta[:, 5, 3] = -0.0; ta[:, 6, 3] = 5e-324; ta[:, 7, :] = 0.013; ta[700:, 8, 2] = 0.02 * rng.random(300)
+    d["tauaer"] = np.asfortranarray(ta)
+    e = np.array(d["emis"]); e[:, 4] = 0.97
+    d["emis"] = np.asfortranarray(e)
+    dev = torch.device("cuda", 0)
+    # device-resident copies with the Fortran arrays' memory order (the transpose of an F-ordered array is a C-ordered view of the same bytes)
+    dd = {k: (torch.from_numpy(np.asfortranarray(v).T).to(dev) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+    hip.set_batch(256)
+    try:
+        plain = hip.rrtmg_lw_from_dict(d)
+        out = hip._out_arrays(ncol, nlay, d["idrv"])
+        pinned = [v for v in list(d.values()) + list(out.values()) if isinstance(v, np.ndarray) and v.flags.f_contiguous and v.dtype == np.float64]
+        for v in pinned:
+            hip.host_register(v)
+        got = hip.rrtmg_lw_from_dict(d, out=out)
+        for v in pinned:
+            hip.host_unregister(v)
+        outbuf = torch.full((output_rows(nlay), ncol), float("nan"), dtype=torch.float64, device=dev)
+        oview = output_views(outbuf, nlay)
+        hip.rrtmg_lw_device(dd, oview)
+        hip.check()
+    finally:
+        hip.set_batch(131072)
+    names = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")
+    for k in names:
+        assert np.array_equal(got[k], plain[k]), k
+        assert np.array_equal(oview[k].T.cpu().numpy(), plain[k]), k
+    ref = oracle.rrtmg_lw(ncol, nlay, d["icld"], d["idrv"], d)
+    _compare(plain, ref, d["idrv"], "rows that do not travel")
+
+
 def test_several_devices_from_one_process(hip, oracle):
     """rrtmg_lw_hip_init_devices: the host-pointer entries split their columns over the devices, one host thread each.  One GPU is
     reachable here, so the three devices are virtual ones on GPU 0 (separate workspaces, streams, table copies): results must equal

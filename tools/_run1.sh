@@ -1,7 +1,12 @@
-export RRTMG_LW_ALLOW_STANDIN=1
-for l in lbot p1split lbot p1split; do echo "== $l"; RRTMG_LW_HIP_LIB=$PWD/exp/lib_$l.so timeout -k 10 300 python bench.py --check --no-cpu-baseline --host-cols 0 --steps 8 --warmup 2 2> gpurun_out/_err.txt | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('ms/step',d['ms_per_step'], {k:v for k,v in d['path']['kernels'].items() if 'sweepc<4' in k})
-"; grep "check vs" gpurun_out/_err.txt; done
+#!/bin/bash
+# scratch: run through gpurun
+set -o pipefail
+mkdir -p gpurun_out/stage
+timeout -k 10 900 python -m pytest tests/test_fortran_shim.py tests/test_hip_parity.py tests/test_hip_mcica.py -m gpu -x -q > gpurun_out/stage/pytest.log 2>&1; rc=$?
+tail -5 gpurun_out/stage/pytest.log
+[ $rc -ne 0 ] && exit $rc
+for cfg in cloudy aer_idrv; do
+  timeout -k 10 200 python tools/e2e_timing.py $cfg 131072 72 || exit 1
+  timeout -k 10 200 python tools/e2e_timing.py $cfg 524288 72 || exit 1
+done
+timeout -k 10 200 python tools/e2e_timing.py aer_idrv 262144 137 || exit 1
