@@ -1546,6 +1546,10 @@ using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6>, BandList<8, 10, 14, 16
 #elif defined(RRLW_LAYER_PASS_PER_BAND)       // measurement: one staging round per band, as before round 3
 using LayerPasses = std::tuple<BandList<1>, BandList<2>, BandList<11>, BandList<15>, BandList<6>, BandList<8>, BandList<10>, BandList<14>, BandList<16>,
                                BandList<12>, BandList<13>, BandList<4>, BandList<9>, BandList<7>, BandList<3>, BandList<5>>;
+#elif defined(RRLW_LAYER_PASSES_3)              // measurement: 384-thread workgroups with a 9 000-double buffer (two per CU)
+using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13, 4>, BandList<9, 7, 3>, BandList<5>>;
+#elif defined(RRLW_LAYER_PASSES_1)              // measurement: one 768-thread workgroup per CU, every table of the region staged at once
+using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13, 4, 9, 7, 3, 5>>;
 #else
 using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13>, BandList<4, 9>, BandList<7, 3>, BandList<5>>;
 #endif
