@@ -11,6 +11,8 @@
 #include <mutex>
 #include <string>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -766,12 +768,70 @@ int host_threads()
     }();
     return nt;
 }
+// The host threads persist (a batch of the host-pointer entries has three parallel regions of a millisecond or two each: fifteen thread
+// starts per region cost a fifth of that).  One region at a time: a second caller - the worker thread of another device of the fan-out -
+// starts its own threads instead of waiting.
+class HostPool {
+    std::mutex use_, mu_;
+    std::condition_variable go_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int, int)> *job_ = nullptr;
+    int nt_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+    void worker(int t)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *job;
+            int nt;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                go_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_; job = job_; nt = nt_;
+            }
+            if (t < nt) {
+                (*job)(t, nt);
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+public:
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        go_.notify_all();
+        for (auto &x : th_) x.join();
+    }
+    // f(t, nt) for t = 0 .. nt - 1 (t = 0 on the calling thread); false when the pool is in use
+    bool run(int nt, const std::function<void(int, int)> &f)
+    {
+        std::unique_lock<std::mutex> use(use_, std::try_to_lock);
+        if (!use.owns_lock()) return false;
+        while ((int)th_.size() < nt - 1) { const int t = (int)th_.size() + 1; th_.emplace_back([this, t] { worker(t); }); }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &f; nt_ = nt; pending_ = nt - 1; gen_++;
+        }
+        go_.notify_all();
+        f(0, nt);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        return true;
+    }
+};
+HostPool g_pool;
+
 template <class F>
 void host_parallel(size_t work_bytes, F f)
 {
-    // (a thread per MB of host data at least: a call of a few columns must not pay for sixteen thread starts)
+    // (a thread per MB of host data at least: a call of a few columns does not wake sixteen threads)
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), work_bytes >> 20));
     if (nt == 1) { f(0, 1); return; }
+    const std::function<void(int, int)> fn = [&f](int t, int n) { f(t, n); };
+    if (g_pool.run(nt, fn)) return;
     std::vector<std::thread> th;
     for (int t = 1; t < nt; t++) th.emplace_back([=, &f]() { f(t, nt); });
     f(0, nt);
