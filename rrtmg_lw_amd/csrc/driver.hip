@@ -717,6 +717,7 @@ struct HostIn {
     const double *h; size_t inner, rows; double *d;
     bool pinned = false;                                  // h is page-locked (rrtmg_lw_hip_host_register, or pinned by the caller's own means)
     const double *src = nullptr; size_t src_ncol = 0, src_col0 = 0; bool src_pinned = false;
+    const unsigned char *skip = nullptr;                  // per batch, set by the entry's prep step: rows nothing reads (a cloud array's layers without cloud) - not scanned, zero-filled
 };
 struct HostOut { double *h; size_t rows; double *d; bool active; bool pinned = false; };
 
@@ -838,6 +839,28 @@ void host_parallel(size_t work_bytes, F f)
     for (auto &x : th) x.join();
 }
 
+// flags[r] = 1 when every value of row r of the column batch [col0, col0 + nb) of a (rows, ncol, inner) array is below `thr` (a NaN is not).
+// With thr = cldmin: a layer of the cloud fraction without cloud in any column of the batch - cldprop / cldprmc then read nothing else of that
+// layer (src/rrtmg_lw_cldprop.f90:185-186, src/rrtmg_lw_cldprmc.f90:182-183), so the other cloud arrays' rows of that layer need not be read here.
+void rows_below(const double *h, size_t inner, size_t rows, size_t ncol, size_t col0, size_t nb, double thr, unsigned char *flags)
+{
+    host_parallel(inner * rows * nb * 8, [&](int t, int nt) {
+        for (size_t r = (size_t)t; r < rows; r += (size_t)nt) {
+            const double *p = h + inner * (col0 + ncol * r);
+            const size_t n = inner * nb;
+            bool below = true;
+            size_t i = 0;
+            for (; i + 64 <= n && below; i += 64) {
+                int ok = 1;
+                for (size_t e = 0; e < 64; e++) ok &= (int)(p[i + e] < thr);
+                below = ok != 0;
+            }
+            for (; i < n && below; i++) below = p[i] < thr;
+            flags[r] = below ? 1 : 0;
+        }
+    });
+}
+
 // ranges the caller pinned through rrtmg_lw_hip_host_register; arrays pinned by other means (hipHostMalloc, a framework's pinned
 // allocator) are recognised by the runtime's pointer attributes
 std::vector<std::pair<const char *, size_t>> g_pinned;
@@ -906,6 +929,7 @@ int stage_rows(std::vector<HostIn> &ins, size_t nb, int k, hipStream_t s)
     host_parallel(bytes, [&](int t, int nt) {
         for (size_t j = (size_t)t; j < rows.size(); j += (size_t)nt) {
             StagedRow &q = rows[j];
+            if (ins[q.arr].skip && ins[q.arr].skip[q.row]) { q.uniform = true; q.bits = 0; continue; }
             const uint64_t *p = reinterpret_cast<const uint64_t *>(row_src(q));
             const size_t n = ins[q.arr].inner * nb;
             const uint64_t v = p[0];
@@ -1055,7 +1079,7 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
             if (int rc = unpack(k)) return rc;
             clk.lap(1);
         }
-        for (auto &a : ins) { a.src = a.h; a.src_ncol = (size_t)ncol; a.src_col0 = (size_t)col0; a.src_pinned = a.pinned; }
+        for (auto &a : ins) { a.src = a.h; a.src_ncol = (size_t)ncol; a.src_col0 = (size_t)col0; a.src_pinned = a.pinned; a.skip = nullptr; }
         // the entry's own host work for this batch (reductions into its pinned scratch set k, which it then names as an array's source)
         if (int rc = prep(k, col0, nb, G.cp_in)) return rc;
         clk.lap(2);
@@ -1653,17 +1677,32 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
         HIP_TRY(hipHostMalloc((void **)&G.h_tot, 2 * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
         G.h_tot_doubles = 2 * L * (size_t)nbmax;
     }
+    std::vector<unsigned char> cloudfree(L, 0);
     auto prep = [&](int k, int col0, int nb, hipStream_t) -> int {
+        if (!cloud) return 0;
+        // layers without cloud in any column of the batch: the other five cloud arrays are not read there (nor summed, nor scanned, nor copied)
+        rows_below(cldfr, 1, L, (size_t)ncol, (size_t)col0, (size_t)nb, 1.e-20, cloudfree.data());
+        for (size_t a = 18; a < ins.size(); a++) ins[a].skip = cloudfree.data();
         if (!use_tot) return 0;
         double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;        // (the pipeline has waited for the copies that read scratch set k last)
-        host_parallel((size_t)NBND * L * (size_t)nb * 8, [&](int t, int nt) {
-            const size_t n = L * (size_t)nb;
-            for (size_t e = n * t / nt; e < n * (t + 1) / nt; e++) {
-                const size_t lay = e / (size_t)nb, c = e % (size_t)nb;
-                const double *p = taucld + (size_t)NBND * ((size_t)col0 + c + (size_t)ncol * lay);
-                double sum = 0.0;
-                for (int ib = 0; ib < NBND; ib++) sum = sum + p[ib];
-                tot[e] = sum;
+        size_t cloudy_layers = 0;
+        for (size_t l = 0; l < L; l++) cloudy_layers += cloudfree[l] ? 0 : 1;
+        host_parallel((size_t)NBND * cloudy_layers * (size_t)nb * 8, [&](int t, int nt) {
+            // (pieces of 4 096 columns of a layer, dealt round-robin: the cloudy layers are few)
+            const size_t piece = 4096, per = ((size_t)nb + piece - 1) / piece;
+            size_t task = 0;
+            for (size_t lay = 0; lay < L; lay++) {
+                if (cloudfree[lay]) continue;
+                for (size_t pc = 0; pc < per; pc++, task++) {
+                    if (task % (size_t)nt != (size_t)t) continue;
+                    const size_t c1 = std::min((size_t)nb, (pc + 1) * piece);
+                    for (size_t c = pc * piece; c < c1; c++) {
+                        const double *p = taucld + (size_t)NBND * ((size_t)col0 + c + (size_t)ncol * lay);
+                        double sum = 0.0;
+                        for (int ib = 0; ib < NBND; ib++) sum = sum + p[ib];
+                        tot[lay * (size_t)nb + c] = sum;
+                    }
+                }
             }
         });
         ins[18].src = tot; ins[18].src_ncol = (size_t)nb; ins[18].src_col0 = 0; ins[18].src_pinned = true;      // rows of nb sums, from the pinned scratch
@@ -2112,7 +2151,15 @@ int rrtmg_lw_hip_run_mcica(
         FluxOut out{out_[0].d, out_[1].d, out_[2].d, out_[3].d, out_[4].d, out_[5].d, out_[6].d, out_[7].d, nullptr, nullptr};
         return run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, &m);
     };
-    if (int rc = host_pipeline(ncol, c0, c1, nbmax, ins, outs, body)) return rc;
+    // layers whose sub-column cloud fractions are all below cldmin for the batch: cldprmc reads nothing else of them (src/rrtmg_lw_cldprmc.f90:182-183)
+    std::vector<unsigned char> cloudfree(L, 0);
+    auto prep = [&](int, int col0, int nb, hipStream_t) -> int {
+        if (!cloud) return 0;
+        rows_below(cldfmcl, NGPT, L, (size_t)ncol, (size_t)col0, (size_t)nb, 1.e-20, cloudfree.data());
+        for (size_t a = 18; a < ins.size(); a++) ins[a].skip = cloudfree.data();
+        return 0;
+    };
+    if (int rc = host_pipeline(ncol, c0, c1, nbmax, ins, outs, body, prep)) return rc;
     hipStream_t s = G.stream;
     return read_physics_error(s);
     });

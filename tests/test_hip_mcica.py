@@ -169,6 +169,36 @@ def test_mcica_entry_matches_oracle(hip, oracle, config, nlay, icld, ncol, flags
     assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0 or flags == (0, 0, 0)      # clouds actually matter
 
 
+def test_mcica_entry_ignores_subcolumn_arrays_where_no_subcolumn_has_cloud(hip, oracle):
+    """Layers whose sub-column cloud fractions are all below cldmin for a column batch: cldprmc reads nothing else of them
+    (src/rrtmg_lw_cldprmc.f90:182-183) and the host-pointer entry does not scan or copy the other sub-column arrays there - junk in
+    them changes nothing.  Several batches; a layer that is cloud-free in the first batch only."""
+    ncol, nlay = 500, 40
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=31)
+    cf = np.array(d["cldfr"]); cf[:200, 9] = 0.0; cf[200:, 9] = 0.6
+    for k in ("cicewp", "cliqwp"):
+        a = np.array(d[k]); a[200:, 9] = 15.0; d[k] = np.asfortranarray(a)
+    d["cldfr"] = np.asfortranarray(cf)
+    dd = _with_subcolumns(oracle, d, 2)
+    free = (dd["cldfmcl"] < 1e-20).all(axis=(0, 1))                       # per layer, all sub-columns of all columns
+    assert free.any() and not free.all()
+    dj = dict(dd)
+    for k, v in (("ciwpmcl", 900.0), ("clwpmcl", 800.0), ("taucmcl", 4.0)):
+        a = np.array(dd[k]); a[:, :, free] = v; a[:, :200, 9] = v; dj[k] = np.asfortranarray(a)
+    for k, v in (("reicmcl", 1e4), ("relqmcl", 0.001)):
+        a = np.array(dd[k]); a[:, free] = v; a[:200, 9] = v; dj[k] = np.asfortranarray(a)
+    hip.set_batch(200)
+    try:
+        a = hip.rrtmg_lw_mcica_from_dict(dd, icld=2)
+        b = hip.rrtmg_lw_mcica_from_dict(dj, icld=2)
+    finally:
+        hip.set_batch(262144)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(a[k], b[k]), k
+    ref = oracle.rrtmg_lw(ncol, nlay, 2, d["idrv"], dj, mcica=True)
+    _compare(b, ref, d["idrv"], "junk in cloud-free layers of the sub-column arrays")
+
+
 @pytest.mark.parametrize("icld", [2, 5])
 def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld):
     """rtrnmc through the array entry and through the fused generator entry on cloud decks whose top differs from one 64-column

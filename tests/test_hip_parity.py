@@ -425,6 +425,50 @@ def test_host_entry_rows_that_do_not_travel(hip, oracle):
     _compare(plain, ref, d["idrv"], "rows that do not travel")
 
 
+def test_host_entry_ignores_cloud_arrays_where_no_column_has_cloud(hip, oracle):
+    """A layer whose cloud fraction is below cldmin in every column of a batch: cldprop reads nothing else of it
+    (src/rrtmg_lw_cldprop.f90:185-186), and the host-pointer entry does not read, sum, scan or copy the other cloud arrays there.
+    Junk in those layers - water paths, optical depths, particle sizes outside the parameterisations' bounds, which would `stop` the
+    reference in a cloudy layer - must change nothing; a layer that is cloud-free in some batches and cloudy in others; fractions of
+    1e-21 (below cldmin) and of exactly cldmin."""
+    ncol, nlay = 900, 40
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=5)
+    rng = np.random.default_rng(4)
+    cf = np.array(d["cldfr"])
+    cf[:300, 20] = 0.0; cf[300:, 20] = np.where(rng.random(600) < 0.3, 0.5, 0.0)       # layer 21: cloud-free in the first batch only
+    cf[:, 30] = 1e-21                                                                  # below cldmin everywhere
+    cf[:, 31] = 0.0; cf[17, 31] = 1e-20                                                # one column exactly at cldmin
+    free = (cf < 1e-20).all(axis=0)
+    clean = {k: np.array(d[k]) for k in ("cicewp", "cliqwp", "reice", "reliq")}
+    clean["cldfr"] = cf
+    for k in ("cicewp", "cliqwp"):
+        clean[k][:, 20] = np.where(cf[:, 20] > 0, 20.0, 0.0)
+        clean[k][17, 31] = 5.0
+    clean["reice"][:, 20] = 60.0; clean["reliq"][:, 20] = 10.0; clean["reice"][17, 31] = 60.0; clean["reliq"][17, 31] = 10.0
+    tc = np.zeros((16, ncol, nlay))
+    junk = {k: v.copy() for k, v in clean.items()}
+    junk["cicewp"][:, free] = 1e3; junk["cliqwp"][:, free] = 7e2; junk["reice"][:, free] = 500.0; junk["reliq"][:, free] = 0.01
+    junk["cicewp"][:300, 20] = 40.0; junk["reice"][:300, 20] = 1e4                       # (cloud-free for the first batch's columns only)
+    tcj = tc.copy(); tcj[:, :, free] = 5.0; tcj[:, :300, 20] = 3.0
+    hip.set_batch(300)
+    try:
+        for inflag in (2, 0):
+            d["inflglw"] = inflag
+            if inflag == 0:
+                d["iceflglw"], d["liqflglw"] = 0, 0
+                tc[:, :, 5:14] = 0.4 * (cf[None, :, 5:14] > 0); tcj[:, :, 5:14] = tc[:, :, 5:14]
+            da = dict(d); da.update({k: np.asfortranarray(v) for k, v in clean.items()}); da["taucld"] = np.asfortranarray(tc)
+            db = dict(d); db.update({k: np.asfortranarray(v) for k, v in junk.items()}); db["taucld"] = np.asfortranarray(tcj)
+            a = hip.rrtmg_lw_from_dict(da, icld=2)
+            b = hip.rrtmg_lw_from_dict(db, icld=2)
+            for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+                assert np.array_equal(a[k], b[k]), (k, inflag)
+            ref = oracle.rrtmg_lw(ncol, nlay, 2, d["idrv"], db)          # the oracle reads the junk the way the reference does: not at all
+            _compare(b, ref, d["idrv"], f"junk in cloud-free layers, inflag {inflag}")
+    finally:
+        hip.set_batch(262144)
+
+
 def test_several_devices_from_one_process(hip, oracle):
     """rrtmg_lw_hip_init_devices: the host-pointer entries split their columns over the devices, one host thread each.  One GPU is
     reachable here, so the three devices are virtual ones on GPU 0 (separate workspaces, streams, table copies): results must equal

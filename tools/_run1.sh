@@ -1,13 +1,10 @@
 #!/bin/bash
 # scratch: run through gpurun
 set -o pipefail
-for n in 4096 8192 16384 32768 65536 131072; do
-  for cfg in cloudy clear; do
-    timeout -k 10 200 python bench.py --ncol $n --config $cfg --steps 50 --warmup 5 --no-cpu-baseline --host-cols 0 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('$cfg', $n, 'ms/step', d['ms_per_step'], 'Mcol/s', round(d['value']/1e6,2), {k:round(v,2) for k,v in d['path']['families'].items()})
-" || exit 1
-  done
-done
+mkdir -p gpurun_out/stage
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/stage/pytest.log 2>&1; rc=$?
+tail -5 gpurun_out/stage/pytest.log
+[ $rc -ne 0 ] && exit $rc
+for n in 131072 524288; do timeout -k 10 200 python tools/e2e_timing.py cloudy $n 72 || exit 1; done
+timeout -k 10 200 python tools/e2e_timing.py aer_idrv 131072 72 || exit 1
+RRTMG_LW_STAGE_TIMING=1 timeout -k 10 200 python tools/e2e_timing.py cloudy 524288 72 2>&1 | tail -3
