@@ -249,8 +249,8 @@ int rrtmg_lw_hip_n1_prototype(void);
 /* Number of g-point chunks the sweep kernel distributes over threads (one partial flux slab each). */
 int rrtmg_lw_hip_num_chunks(void);
 /* g-points of this build: 140 (librrtmg_lw_hip.so, the reference's shipped model) or 256 (librrtmg_lw_hip_g256.so: every band keeps its 16
- * original g-points - the accuracy mode the reference keeps commented out in modules/parrrtm.f90:40-41,77-110; same symbols, non-McICA
- * entries only; select it by linking / loading that library instead). */
+ * original g-points - the accuracy mode the reference keeps commented out in modules/parrrtm.f90:40-41,77-110; same symbols; the McICA
+ * sub-column arrays and masks then hold 256 sub-columns; select it by linking / loading that library instead). */
 int rrtmg_lw_hip_gpoints(void);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py's roofline leg).

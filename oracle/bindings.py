@@ -33,15 +33,15 @@ GCM_FIELDS_2D = ("play", "plev", "tlay", "tlev")
 GAS_FIELDS = ("h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr")
 
 
-def _gcm_call(fn, ncol, nlay, icld, idrv, d, mcica):
+def _gcm_call(fn, ncol, nlay, icld, idrv, d, mcica, ngpt=NGPT):
     """Shared marshalling for the rrtmg_lw(ncol, nlay, ...) argument list (src/rrtmg_lw_rad*.f90:99-108)."""
     arrs = [_f(d["play"], (ncol, nlay)), _f(d["plev"], (ncol, nlay + 1)), _f(d["tlay"], (ncol, nlay)),
             _f(d["tlev"], (ncol, nlay + 1)), _f(d["tsfc"], (ncol,))]
     arrs += [_f(d[g], (ncol, nlay)) for g in GAS_FIELDS]
     arrs.append(_f(d["emis"], (ncol, NBND)))
     if mcica:
-        cld = [_f(d["cldfmcl"], (NGPT, ncol, nlay)), _f(d["taucmcl"], (NGPT, ncol, nlay)),
-               _f(d["ciwpmcl"], (NGPT, ncol, nlay)), _f(d["clwpmcl"], (NGPT, ncol, nlay)),
+        cld = [_f(d["cldfmcl"], (ngpt, ncol, nlay)), _f(d["taucmcl"], (ngpt, ncol, nlay)),
+               _f(d["ciwpmcl"], (ngpt, ncol, nlay)), _f(d["clwpmcl"], (ngpt, ncol, nlay)),
                _f(d["reicmcl"], (ncol, nlay)), _f(d["relqmcl"], (ncol, nlay))]
     else:
         cld = [_f(d["cldfr"], (ncol, nlay)), _f(d["taucld"], (NBND, ncol, nlay)), _f(d["cicewp"], (ncol, nlay)),
@@ -87,18 +87,18 @@ def _column_call(fn, col, istart, iend, iout, icld, idrv, byref_scalars, ngpt=NG
     return rc, res
 
 
-def _column_mc_call(fn, col, sub, istart, iend, iout, icld, idrv):
+def _column_mc_call(fn, col, sub, istart, iend, iout, icld, idrv, ngpt=NGPT):
     """Prepared column + one set of sub-columns (cldfmc, taucmc, ciwpmc, clwpmc (140,nlayers); reicmc, relqmc (nlayers))."""
     nl = int(col["nlayers"])
     z = lambda *s: np.zeros(s, order="F")
     outs = [z(nl + 1) for _ in range(10)]
-    taug, fracs = z(nl, NGPT), z(nl, NGPT)
+    taug, fracs = z(nl, ngpt), z(nl, ngpt)
     ncb = C.c_int(0)
     a = dict(pavel=_f(col["pavel"], (nl,)), tavel=_f(col["tavel"], (nl,)), pz=_f(col["pz"], (nl + 1,)),
              tz=_f(col["tz"], (nl + 1,)), semiss=_f(col["semiss"], (NBND,)), coldry=_f(col["coldry"], (nl,)),
              wkl=_f(col["wkl"], (7, nl)), wbrodl=_f(col["wbrodl"], (nl,)), wx=_f(col["wx"], (4, nl)),
-             cldfmc=_f(sub["cldfmc"], (NGPT, nl)), taucmc=_f(sub["taucmc"], (NGPT, nl)), ciwpmc=_f(sub["ciwpmc"], (NGPT, nl)),
-             clwpmc=_f(sub["clwpmc"], (NGPT, nl)), reicmc=_f(sub["reicmc"], (nl,)), relqmc=_f(sub["relqmc"], (nl,)),
+             cldfmc=_f(sub["cldfmc"], (ngpt, nl)), taucmc=_f(sub["taucmc"], (ngpt, nl)), ciwpmc=_f(sub["ciwpmc"], (ngpt, nl)),
+             clwpmc=_f(sub["clwpmc"], (ngpt, nl)), reicmc=_f(sub["reicmc"], (nl,)), relqmc=_f(sub["relqmc"], (nl,)),
              taua=_f(col["tauaer"], (nl, NBND)))
     args = [C.c_int(nl), C.c_int(istart), C.c_int(iend), C.c_int(iout), C.c_int(icld), C.c_int(idrv),
             _p(a["pavel"]), _p(a["tavel"]), _p(a["pz"]), _p(a["tz"]), C.c_double(float(col["tbound"])),
@@ -118,7 +118,7 @@ class Oracle:
     """The plain-C restatement (oracle/rrtmg_lw_oracle.c)."""
 
     def __init__(self, kdata=STANDIN_KDATA, cpdair=1004.0, static=STATIC_BLOB, gpoints=140):
-        """gpoints = 256: the build that keeps every band's 16 original g-points (liboracle_g256.so; non-McICA entries only)."""
+        """gpoints = 256: the build that keeps every band's 16 original g-points (liboracle_g256.so)."""
         assert gpoints in (140, 256)
         path = os.path.join(HERE, "liboracle.so" if gpoints == 140 else "liboracle_g256.so")
         if not os.path.exists(path):
@@ -137,7 +137,7 @@ class Oracle:
 
     def rrtmg_lw(self, ncol, nlay, icld, idrv, d, mcica=False):
         fn = self.lib.orc_rrtmg_lw_mcica if mcica else self.lib.orc_rrtmg_lw_nomcica
-        rc, out = _gcm_call(fn, ncol, nlay, icld, idrv, d, mcica)
+        rc, out = _gcm_call(fn, ncol, nlay, icld, idrv, d, mcica, self.ngpt)
         if rc != 0:
             raise RuntimeError(f"oracle: {self.errmsg()}")
         return out
@@ -154,7 +154,7 @@ class Oracle:
         """One McICA sample of the column driver: cldprmc -> setcoef -> taumol -> rtrnmc on the given sub-columns."""
         icld = int(col["icld"]) if icld is None else icld
         idrv = int(col["idrv"]) if idrv is None else idrv
-        rc, res = _column_mc_call(self.lib.orc_column_mc, col, sub, istart, iend, iout, icld, idrv)
+        rc, res = _column_mc_call(self.lib.orc_column_mc, col, sub, istart, iend, iout, icld, idrv, self.ngpt)
         if rc != 0:
             raise RuntimeError(f"oracle: {self.errmsg()}")
         return res
@@ -167,7 +167,7 @@ class Oracle:
 
     def mcica_subcol(self, ncol, nlay, icld, permuteseed, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha):
         """mcica_subcol_lw with the GCM argument list (src/mcica_subcol_gen_lw.f90:183-185)."""
-        o = _subcol_outputs(ncol, nlay)
+        o = _subcol_outputs(ncol, nlay, self.ngpt)
         irng_c = C.c_int(irng)
         ins = [_f(play, (ncol, nlay)), _f(cldfrac, (ncol, nlay)), _f(ciwp, (ncol, nlay)), _f(clwp, (ncol, nlay)),
                _f(rei, (ncol, nlay)), _f(rel, (ncol, nlay)), _f(tauc, (NBND, ncol, nlay)), _f(alpha, (ncol, nlay))]
@@ -193,8 +193,8 @@ class Oracle:
         return t, e, f
 
 
-def _subcol_outputs(ncol, nlay):
-    z3 = lambda: np.zeros((NGPT, ncol, nlay), order="F")
+def _subcol_outputs(ncol, nlay, ngpt=NGPT):
+    z3 = lambda: np.zeros((ngpt, ncol, nlay), order="F")
     z2 = lambda: np.zeros((ncol, nlay), order="F")
     return dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), reicmcl=z2(), relqmcl=z2(), taucmcl=z3())
 
@@ -219,7 +219,7 @@ class Reference:
         return os.path.exists(os.path.join(HERE, "_ref", f"libref_{flavour}.so"))
 
     def rrtmg_lw(self, ncol, nlay, icld, idrv, d):
-        _, out = _gcm_call(self.lib.ref_rrtmg_lw, ncol, nlay, icld, idrv, d, self.flavour == "mcica")
+        _, out = _gcm_call(self.lib.ref_rrtmg_lw, ncol, nlay, icld, idrv, d, self.flavour.startswith("mcica"), self.ngpt)
         return out
 
     def column(self, col, istart=1, iend=16, iout=0, icld=None, idrv=None):
@@ -231,7 +231,7 @@ class Reference:
     def column_mc(self, col, sub, istart=1, iend=16, iout=0, icld=None, idrv=None):
         icld = int(col["icld"]) if icld is None else icld
         idrv = int(col["idrv"]) if idrv is None else idrv
-        _, res = _column_mc_call(self.lib.ref_column_mc, col, sub, istart, iend, iout, icld, idrv)
+        _, res = _column_mc_call(self.lib.ref_column_mc, col, sub, istart, iend, iout, icld, idrv, self.ngpt)
         return res
 
     def get_alpha_1col(self, nlay, icld, idcor, decorr_con, dz, lat, juldat, cldfrac):
@@ -241,8 +241,8 @@ class Reference:
         return a
 
     def mcica_subcol_1col(self, nlay, icld, ims, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha):
-        """The reference's one-column generator (src/mcica_subcol_gen_lw.1col.f90:171); permuteseed = ims * 140."""
-        z2 = lambda: np.zeros((NGPT, nlay), order="F")
+        """The reference's one-column generator (src/mcica_subcol_gen_lw.1col.f90:171); permuteseed = ims * ngptlw."""
+        z2 = lambda: np.zeros((self.ngpt, nlay), order="F")
         o = dict(cldfmc=z2(), ciwpmc=z2(), clwpmc=z2(), reicmc=np.zeros(nlay), relqmc=np.zeros(nlay), taucmc=z2())
         irng_c = C.c_int(irng)
         ins = [_f(play, (nlay,)), _f(cldfrac, (nlay,)), _f(ciwp, (nlay,)), _f(clwp, (nlay,)), _f(rei, (nlay,)), _f(rel, (nlay,)),

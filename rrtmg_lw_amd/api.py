@@ -54,7 +54,7 @@ def lib():
 
 def select_gpoints(n):
     """Choose the g-point model of the calls that follow: 140 (the reference's shipped model) or 256 (every band keeps its 16 original
-    g-points: the accuracy mode of modules/parrrtm.f90:40-41,77-110; non-McICA entries only).  Each is its own library with its own
+    g-points: the accuracy mode of modules/parrrtm.f90:40-41,77-110; its McICA arrays hold 256 sub-columns).  Each is its own library with its own
     state: call rrtmg_lw_ini after switching."""
     global _lib, _gpoints
     if n not in (140, 256):
@@ -298,8 +298,9 @@ def rrtmg_lw_mcica(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr,
     """McICA rrtmg_lw (src/rrtmg_lw_rad.f90:99-108) with host arrays; sub-column arrays are (140, ncol, nlay)."""
     a = _gcm_arrays(ncol, nlay, play, plev, tlay, tlev, tsfc,
                     (h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr), emis)
-    cld = [_f(cldfmcl, (NGPT, ncol, nlay)), _f(taucmcl, (NGPT, ncol, nlay)), _f(ciwpmcl, (NGPT, ncol, nlay)),
-           _f(clwpmcl, (NGPT, ncol, nlay)), _f(reicmcl, (ncol, nlay)), _f(relqmcl, (ncol, nlay)), _f(tauaer, (ncol, nlay, NBND))]
+    ng = gpoints()
+    cld = [_f(cldfmcl, (ng, ncol, nlay)), _f(taucmcl, (ng, ncol, nlay)), _f(ciwpmcl, (ng, ncol, nlay)),
+           _f(clwpmcl, (ng, ncol, nlay)), _f(reicmcl, (ncol, nlay)), _f(relqmcl, (ncol, nlay)), _f(tauaer, (ncol, nlay, NBND))]
     out = _out_arrays(ncol, nlay, idrv)
     icld_c = C.c_int(int(icld))
     args = [C.c_int(ncol), C.c_int(nlay), C.byref(icld_c), C.c_int(int(idrv))] + [_p(x) for x in a]
@@ -331,7 +332,8 @@ def get_alpha(ncol, nlay, icld, idcor, decorr_con, dz, lat, juldat, cldfrac):
 def mcica_subcol_lw(ncol, nlay, icld, permuteseed, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha=None):
     """mcica_subcol_lw (src/mcica_subcol_gen_lw.f90:183-185; `iplon` dropped: every column is generated).
     Returns dict(cldfmcl, ciwpmcl, clwpmcl, taucmcl (140,ncol,nlay), reicmcl, relqmcl (ncol,nlay), irng)."""
-    z3 = lambda: np.zeros((NGPT, ncol, nlay), order="F")
+    ng = gpoints()
+    z3 = lambda: np.zeros((ng, ncol, nlay), order="F")
     z2 = lambda: np.zeros((ncol, nlay), order="F")
     o = dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), reicmcl=z2(), relqmcl=z2(), taucmcl=z3())
     irng_c = C.c_int(int(irng))
@@ -405,7 +407,7 @@ def run_columns_mcica(cols, subs, istart=1, iend=16, icld=None, idrv=None):
              pwvcm=_f(np.array([float(c["pwvcm"]) for c in cols]), (n,)), reicmc=st(subs, "reicmc", (n, nl)), relqmc=st(subs, "relqmc", (n, nl)),
              taua=st(cols, "tauaer", (n, nl, NBND)))
     for k in ("cldfmc", "taucmc", "ciwpmc", "clwpmc"):          # (140, n, nlayers)
-        a[k] = _f(np.stack([np.asarray(s_[k], dtype=np.float64) for s_ in subs], axis=1), (NGPT, n, nl))
+        a[k] = _f(np.stack([np.asarray(s_[k], dtype=np.float64) for s_ in subs], axis=1), (gpoints(), n, nl))
     names = ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc", "dtotuflux_dt", "dtotuclfl_dt")
     out = {k: np.zeros((n, nl + 1), order="F") for k in names}
     c0 = cols[0]
@@ -427,7 +429,7 @@ def column_mcica_samples(col, samples, irng=1, alpha=None):
     al = None if alpha is None else r2(alpha)
     subs = []
     for ims in samples:
-        g = mcica_subcol_lw(1, nl, int(col["icld"]), ims * NGPT, irng, r2(col["pavel"]), r2(col["cldfrac"]), r2(col["ciwp"]),
+        g = mcica_subcol_lw(1, nl, int(col["icld"]), ims * gpoints(), irng, r2(col["pavel"]), r2(col["cldfrac"]), r2(col["ciwp"]),
                             r2(col["clwp"]), r2(col["rei"]), r2(col["rel"]),
                             np.asfortranarray(np.asarray(col["tauc"], dtype=np.float64).reshape((NBND, 1, nl), order="F")), al)
         subs.append(dict(cldfmc=g["cldfmcl"][:, 0, :], taucmc=g["taucmcl"][:, 0, :], ciwpmc=g["ciwpmcl"][:, 0, :],

@@ -693,10 +693,9 @@ int ensure_stage(size_t bytes)
     return 0;
 }
 
-// the McICA entries exist for the 140-g-point model only (the sub-column masks are 140 bits; ngptlw sub-columns, src/rrtmg_lw_rad.f90:140)
+// the McICA entries exist in both builds: ngptlw sub-columns (src/rrtmg_lw_rad.f90:140, :267-288), masks of MASK_WORDS words
 int check_mcica_build()
 {
-    if (NGPT != 140) return fail(RRTMG_LW_HIP_EARG, "this library is the 256-g-point build: McICA entries are not available");
     return 0;
 }
 

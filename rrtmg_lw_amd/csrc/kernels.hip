@@ -110,7 +110,7 @@ struct Workspace {
     // McICA (rtrnmc): per-g-point cloud terms, written by k_cloudmc
     double *odg;        // [NQUAD][nlay][ncolb][4]     secdiff(band) * taucmc(g)
     float *cfef;        // [NQUAD][nlay][ncolb][8]     {cldfmc(g) x4, efclfrac(g) x4}
-    unsigned *mask;     // [5][nlay][mask_stride]      sub-column cloud mask of ALL columns of the call (indexed by the global
+    unsigned *mask;     // [MASK_WORDS][nlay][mask_stride]      sub-column cloud mask of ALL columns of the call (indexed by the global
     size_t mask_stride; //                             column mask_col0 + col0 + col), bit k of word w = sub-column 32 w + k
     size_t mask_col0;
 };
@@ -1486,7 +1486,7 @@ struct LayerWg { double2 *lds; int jp0, im0, tid, nth; bool lower, ok; };
 template <int B, int CLOUD, int BASE_LO, int BASE_UP>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
                                            __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol, int cloudy,
-                                           const unsigned (&mw)[5])
+                                           const unsigned (&mw)[MASK_WORDS])
 {
     STAMP(4);                                                                   // (cells of the previous band)
     unsigned delta[NROLE];
@@ -1557,7 +1557,7 @@ using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13>,
 template <class PL, int CLOUD, int... I>
 __device__ __forceinline__ void pass_run(std::integer_sequence<int, I...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
-                                         int cloudy, const unsigned (&mw)[5])
+                                         int cloudy, const unsigned (&mw)[MASK_WORDS])
 {
     // the pass's tables -> LDS; the barriers are reached by every thread of the workgroup
     STAMP(4);
@@ -1574,7 +1574,7 @@ __device__ __forceinline__ void pass_run(std::integer_sequence<int, I...>, const
 template <int CLOUD, class... PLs>
 __device__ __forceinline__ void passes_run(std::tuple<PLs...> *, const DevTables &T, const Workspace &W, const LayerArgs &a,
                                            const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
-                                           int cloudy, const unsigned (&mw)[5])
+                                           int cloudy, const unsigned (&mw)[MASK_WORDS])
 {
     (pass_run<PLs, CLOUD>(std::make_integer_sequence<int, PLs::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw), ...);
 }
@@ -1693,7 +1693,7 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
     if (CLOUD) cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
     // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
     const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
-    const unsigned mw[5] = {0u, 0u, 0u, 0u, 0u};
+    const unsigned mw[MASK_WORDS] = {};
 #ifdef RRLW_LAYER_STAMPS
     if ((threadIdx.x & 63) == 0) { for (int i = 0; i < NSTAMP; i++) s_stamp[(threadIdx.x >> 6) * (NSTAMP + 1) + i] = 0ull; }
     STAMP(-1);
@@ -1748,15 +1748,18 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
     const double radice = FROMMASK ? g.reice[cl] : m.reicmcl[cl];
     const double radliq = FROMMASK ? g.reliq[cl] : m.relqmcl[cl];
     double mciwp = 0.0, mclwp = 0.0;
-    unsigned mw[5] = {0u, 0u, 0u, 0u, 0u};
+    unsigned mw[MASK_WORDS] = {};
     if (FROMMASK) {
         mciwp = g.cicewp[cl];
         mclwp = g.cliqwp[cl];
 #pragma unroll
-        for (int w = 0; w < 5; w++) mw[w] = W.mask[((size_t)w * nlay + (lay - 1)) * W.mask_stride + W.mask_col0 + gc];
+        for (int w = 0; w < MASK_WORDS; w++) mw[w] = W.mask[((size_t)w * nlay + (lay - 1)) * W.mask_stride + W.mask_col0 + gc];
     }
     if constexpr (FROMMASK) {
-        if ((mw[0] | mw[1] | mw[2] | mw[3] | (mw[4] & 0xfffu)) == 0u) {       // no cloudy sub-column in this layer (140 = 4 x 32 + 12 bits)
+        unsigned anybit = 0u;
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; w++) anybit |= (w == MASK_WORDS - 1 && (NGPT & 31)) ? (mw[w] & ((1u << (NGPT & 31)) - 1u)) : mw[w];
+        if (anybit == 0u) {       // no cloudy sub-column in this layer (140 = 4 x 32 + 12 bits)
             W.cflag[(size_t)lay * ncb + col] = 0;      // (odcld / efcl of a layer are read only when its flag is set)
             if (lay == 1) W.cflag[(size_t)(nlay + 1) * ncb + col] = 0;
             return;
@@ -1808,7 +1811,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
         if constexpr (FROMMASK) {
             // every cloudy cell of this band and layer carries the same values (src/mcica_subcol_gen_lw.f90:664-680): one
             // optical depth / emissivity per band; k_layer<..,3,..> and k_sweepz<.,4> combine them with the mask bits
-            const unsigned long long lo = mw[g0 >> 5], hi = (g0 >> 5) < 4 ? mw[(g0 >> 5) + 1] : 0u;
+            const unsigned long long lo = mw[g0 >> 5], hi = (g0 >> 5) < MASK_WORDS - 1 ? mw[(g0 >> 5) + 1] : 0u;
             const unsigned bits = (unsigned)(((lo | (hi << 32)) >> (g0 & 31)) & ((1ull << ng) - 1ull));
             double t = tband, od = 0.0, ef = 0.0;
             if (bits) {
@@ -2036,7 +2039,7 @@ __device__ __forceinline__ double overlap_rule(int icld, int l, double x, double
 // order with cldfrac / alpha re-read for every sub-column - moved 161 GB per 1e6 columns through HBM: 73 KB per wave of re-read
 // working set, sixteen waves a CU, against 128 KB of L2 a CU.)
 constexpr int KJ_COLS = 16;
-constexpr int KJ_NWORD = (NGPT + 31) / 32;          // mask words of a column = waves of a work-group
+constexpr int KJ_NWORD = MASK_WORDS;                 // mask words of a column = waves of a work-group
 constexpr int KJ_BLOCK = 64 * KJ_NWORD;
 constexpr int KJ_NGROUP = 4 * KJ_NWORD;             // 8-sub-column groups, the last ones possibly short or empty
 

@@ -24,12 +24,13 @@ namespace rrlw {
 constexpr int NBND = 16;
 // -DRRLW_G256 builds the 256-g-point model the reference keeps as a commented-out alternative (modules/parrrtm.f90:40-41,77-110;
 // src/rrtmg_lw_init.f90:313-314: "the full 256 g-point set can be restored with ngptlw=256, ngc=16*16, ngn=256*1., etc."): every band
-// keeps its 16 original g-points and the combination step copies.  Non-McICA entries only (the sub-column masks are 140 bits).
+// keeps its 16 original g-points and the combination step copies (McICA: 256 sub-columns, masks of 8 words).
 #ifdef RRLW_G256
 constexpr int NGPT = 256;
 #else
 constexpr int NGPT = 140;
 #endif
+constexpr int MASK_WORDS = (NGPT + 31) / 32;        // 32-bit words of a (column, layer)'s sub-column cloud mask: 5 (140 bits) or 8
 constexpr int NTBL = 10000;
 
 struct BlobEntry {

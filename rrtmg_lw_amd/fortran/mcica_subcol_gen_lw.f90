@@ -7,7 +7,7 @@
 
       use iso_c_binding
       use parkind, only : im => kind_im, rb => kind_rb
-      use rrtmg_lw_init, only : rrtmg_lw_hip_abort
+      use rrtmg_lw_init, only : rrtmg_lw_hip_abort, rrtmg_lw_hip_gpoints
 
       implicit none
 
@@ -86,11 +86,12 @@
       real(kind=rb), intent(out) :: relqmcl(:,:), reicmcl(:,:)
 
       integer(c_int) :: rc, irng_c
-      integer, parameter :: ng = 140
+      integer :: ng                                   ! sub-columns = g-points of the linked library (ngptlw: 140, or 256)
       real(c_double), allocatable :: o3(:,:,:,:), o2(:,:,:)
 
       if (icld == 0) return                            ! src/mcica_subcol_gen_lw.f90:265
       irng_c = int(irng, c_int)
+      ng = int(rrtmg_lw_hip_gpoints())
       allocate(o3(ng, ncol, nlay, 4), o2(ncol, nlay, 2))
       rc = rrtmg_lw_hip_mcica_subcol(int(ncol, c_int), int(nlay, c_int), int(icld, c_int), int(permuteseed, c_int), irng_c, &
             play(1:ncol, 1:nlay), cldfrac(1:ncol, 1:nlay), ciwp(1:ncol, 1:nlay), clwp(1:ncol, 1:nlay), &

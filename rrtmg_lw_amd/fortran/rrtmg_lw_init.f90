@@ -39,6 +39,10 @@
             type(c_ptr), value :: ptr
             integer(c_int) :: rc
          end function rrtmg_lw_hip_host_unregister
+         function rrtmg_lw_hip_gpoints() bind(C, name='rrtmg_lw_hip_gpoints') result(n)
+            import :: c_int
+            integer(c_int) :: n        ! ngptlw of the linked library: 140, or 256 (librrtmg_lw_hip_g256.so)
+         end function rrtmg_lw_hip_gpoints
          function rrtmg_lw_hip_last_error() bind(C, name='rrtmg_lw_hip_last_error') result(p)
             import :: c_ptr
             type(c_ptr) :: p

@@ -10,7 +10,7 @@
 
       use iso_c_binding
       use parkind, only : im => kind_im, rb => kind_rb
-      use rrtmg_lw_init, only : rrtmg_lw_hip_abort
+      use rrtmg_lw_init, only : rrtmg_lw_hip_abort, rrtmg_lw_hip_gpoints
 
       implicit none
 
@@ -68,10 +68,12 @@
       real(kind=rb), intent(out), optional, target :: duflx_dt(:,:), duflxc_dt(:,:)
 
       integer(c_int) :: rc, icld_c
+      integer :: ng                                   ! ngptlw of the linked library (140, or 256)
       real(c_double), allocatable, target :: d1(:,:), d2(:,:)
       type(c_ptr) :: p1, p2
 
       icld_c = int(icld, c_int)
+      ng = int(rrtmg_lw_hip_gpoints())
       p1 = c_null_ptr
       p2 = c_null_ptr
       if (idrv == 1) then
@@ -89,6 +91,10 @@
       call check_extent('plev', size(plev,1), size(plev,2), ncol, nlay+1)
       call check_extent('tauaer', size(tauaer,1), size(tauaer,2), ncol, nlay)
       call check_extent('cldfmcl', size(cldfmcl,2), size(cldfmcl,3), ncol, nlay)
+      if (size(cldfmcl,1) < ng) then
+         write(*,'(a,i0,a,i0,a)') 'rrtmg_lw: cldfmcl holds ', size(cldfmcl,1), ' sub-columns, the linked library has ', ng, ' g-points'
+         error stop 1
+      endif
       call check_extent('uflx', size(uflx,1), size(uflx,2), ncol, nlay+1)
       call check_extent('hr', size(hr,1), size(hr,2), ncol, nlay)
       rc = rrtmg_lw_hip_run_mcica(int(ncol, c_int), int(nlay, c_int), icld_c, int(idrv, c_int), &
@@ -97,8 +103,8 @@
             n2ovmr(1:ncol,1:nlay), o2vmr(1:ncol,1:nlay), cfc11vmr(1:ncol,1:nlay), cfc12vmr(1:ncol,1:nlay), &
             cfc22vmr(1:ncol,1:nlay), ccl4vmr(1:ncol,1:nlay), emis(1:ncol,1:16), &
             int(inflglw, c_int), int(iceflglw, c_int), int(liqflglw, c_int), &
-            cldfmcl(1:140,1:ncol,1:nlay), taucmcl(1:140,1:ncol,1:nlay), ciwpmcl(1:140,1:ncol,1:nlay), &
-            clwpmcl(1:140,1:ncol,1:nlay), reicmcl(1:ncol,1:nlay), relqmcl(1:ncol,1:nlay), tauaer(1:ncol,1:nlay,1:16), &
+            cldfmcl(1:ng,1:ncol,1:nlay), taucmcl(1:ng,1:ncol,1:nlay), ciwpmcl(1:ng,1:ncol,1:nlay), &
+            clwpmcl(1:ng,1:ncol,1:nlay), reicmcl(1:ncol,1:nlay), relqmcl(1:ncol,1:nlay), tauaer(1:ncol,1:nlay,1:16), &
             uflx(1:ncol,1:nlay+1), dflx(1:ncol,1:nlay+1), hr(1:ncol,1:nlay), &
             uflxc(1:ncol,1:nlay+1), dflxc(1:ncol,1:nlay+1), hrc(1:ncol,1:nlay), p1, p2)
       if (rc /= 0) call rrtmg_lw_hip_abort('rrtmg_lw')

@@ -2,7 +2,8 @@
 keeps as a commented-out alternative (modules/parrrtm.f90:40-41,77-110; src/rrtmg_lw_init.f90:313-314).  Pinned three ways:
  * tests/golden/ref_g256_*.npz - outputs of the reference's own Fortran built in that configuration (oracle/patch_g256.py switches its
    commented-out parameters on; tools/gen_ref_fixtures.py --g256) - against the oracle (CPU) and against the HIP library (GPU);
- * live against oracle/_ref/libref_nomcica_g256.so where that build is present;
+ * live against oracle/_ref/libref_nomcica_g256.so / libref_mcica_g256.so where those builds are present;
+ * McICA with 256 sub-columns (generator bit-exact, cldprmc + rtrnmc) the same three ways;
  * HIP vs the oracle built the same way (oracle/liboracle_g256.so) on larger inputs.
 The reference's statement about the reduction ("within 0.5 W m-2", README.md:19 of the reference) needs real k-data - with the stand-in
 tables the two models merely have to be close."""
@@ -95,6 +96,65 @@ def test_oracle_g256_matches_live_reference_build():
         assert np.abs(a[k] - b[k]).max() <= ORACLE_TOL, k
 
 
+MC_FIX = sorted(glob.glob(os.path.join(G, "ref_g256_mcica_*.npz")))
+
+
+def _fixture_subcolumns(gen, f, d):
+    """256 sub-columns per column the way the fixture's generator call made them: one call for kissvec, one call per column for the
+    Mersenne Twister (the reference's one-column generator seeds a fresh stream per column)."""
+    ncol, nlay, icld, irng, seed = int(f["ncol"]), int(f["nlay"]), int(f["icld"]), int(f["irng"]), int(f["ims"]) * 256
+    args = lambda sl: (d["play"][sl], d["cldfr"][sl], d["cicewp"][sl], d["cliqwp"][sl], d["reice"][sl], d["reliq"][sl], d["taucld"][:, sl, :])
+    if irng == 0:
+        return gen(ncol, nlay, icld, seed, 0, *args(slice(None)))
+    parts = [gen(1, nlay, icld, seed, 1, *args(slice(c, c + 1))) for c in range(ncol)]
+    return {k: np.asfortranarray(np.concatenate([p[k] for p in parts], axis=1 if parts[0][k].ndim == 3 else 0))
+            for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl", "reicmcl", "relqmcl")}
+
+
+def _check_subcolumns(sub, f):
+    ncol, nlay = int(f["ncol"]), int(f["nlay"])
+    mask = np.unpackbits(f["mask"])[:256 * ncol * nlay].reshape((256, ncol, nlay), order="F")
+    assert np.array_equal(sub["cldfmcl"], mask.astype(float))
+    assert 0 < mask.mean() < 1
+    for k3, ks in (("ciwpmcl", "ciwpsum"), ("clwpmcl", "clwpsum"), ("taucmcl", "taucsum")):
+        assert np.array_equal(sub[k3].sum(axis=0), f[ks]), k3
+
+
+@pytest.mark.parametrize("path", MC_FIX, ids=os.path.basename)
+def test_oracle_g256_matches_reference_mcica_fixture(path):
+    """McICA in the 256-g-point configuration: the reference's own generator and McICA rrtmg_lw built with its 256-g-point parameters
+    (oracle/_ref/libref_mcica_g256.so, tools/gen_ref_fixtures.py --g256) - masks bit-exact, fluxes to rounding."""
+    from oracle.bindings import Oracle
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
+    o = Oracle(gpoints=256)
+    sub = _fixture_subcolumns(lambda *a: o.mcica_subcol(*a, np.zeros((a[0], a[1]))), f, d)
+    _check_subcolumns(sub, f)
+    dd = dict(d); dd.update(sub)
+    r = o.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    assert r["icld"] == int(f["icld_out"])
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if d["idrv"] else ()):
+        assert np.abs(r[k] - f[k]).max() <= ORACLE_TOL, k
+
+
+def test_oracle_g256_mcica_matches_live_reference_build():
+    from oracle import bindings
+    if not bindings.Reference.available("mcica_g256"):
+        pytest.skip("reference 256-g-point McICA build not present")
+    ref, orc = bindings.Reference("mcica_g256"), bindings.Oracle(gpoints=256)
+    d = make_gcm_inputs(7, 45, "cloudy", col0=99)
+    sc = orc.mcica_subcol(7, 45, 3, 512, 0, d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"], d["reliq"], d["taucld"], np.zeros((7, 45)))
+    dd = dict(d); dd.update({k: sc[k] for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl", "reicmcl", "relqmcl")})
+    a, b = orc.rrtmg_lw(7, 45, 3, d["idrv"], dd, mcica=True), ref.rrtmg_lw(7, 45, 3, d["idrv"], dd)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.abs(a[k] - b[k]).max() <= ORACLE_TOL, k
+    for c in range(7):
+        one = ref.mcica_subcol_1col(45, 3, 2, 0, d["play"][c], d["cldfr"][c], d["cicewp"][c], d["cliqwp"][c], d["reice"][c], d["reliq"][c],
+                                    d["taucld"][:, c, :], np.zeros(45))
+        assert np.array_equal(sc["cldfmcl"][:, c, :], one["cldfmc"]), c
+
+
 @pytest.fixture()
 def hip256(hip):
     """The session's 140-point library stays loaded; the 256-point one is selected for the test and deselected afterwards."""
@@ -125,7 +185,7 @@ def test_g256_gcm_entry_matches_oracle(hip256, config, nlay, icld, ncol):
 
 
 @pytest.mark.gpu
-def test_g256_columns_and_mcica_refusal(hip256):
+def test_g256_prepared_columns_match_oracle(hip256):
     from oracle.bindings import Oracle
     col = read_input_rrtm(os.path.join(G, "input_rrtm_MLS-cld-imca0-icld2"), os.path.join(G, "in_cld_rrtm-cld5"))
     o = Oracle(gpoints=256)
@@ -134,9 +194,55 @@ def test_g256_columns_and_mcica_refusal(hip256):
         ref = o.column(col, a, b, 99 if a == b else 0)
         for k in ("totuflux", "totdflux", "htr"):
             assert np.abs(got[k][0] - ref[k]).max() <= 5e-5, (a, k)
-    d = make_gcm_inputs(64, 40, "cloudy")
-    with pytest.raises(hip256.RrtmgLwError, match="256-g-point build"):
-        hip256.mcica_subcol_lw(64, 40, 2, 1, 0, d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"], d["reliq"], d["taucld"])
+
+
+SUB256 = ("cldfmcl", "ciwpmcl", "clwpmcl", "reicmcl", "relqmcl", "taucmcl")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("icld,irng", [(1, 0), (2, 0), (3, 0), (5, 0), (2, 1), (4, 1)])
+def test_g256_subcolumn_generator_is_bit_exact(hip256, icld, irng):
+    """mcica_subcol_lw with 256 sub-columns (the reference's McICA arrays are ngptlw-sized, src/rrtmg_lw_rad.f90:267-288): kissvec by
+    jump-ahead and the Mersenne-Twister stream in chunks, masks of 8 words - every array equals the oracle's bit for bit."""
+    from oracle.bindings import Oracle
+    from test_hip_mcica import _gen_args, _geometry
+    ncol, nlay = 150, 33
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=11)
+    o = Oracle(gpoints=256)
+    dz, lat = _geometry(ncol, nlay)
+    alpha = o.get_alpha(ncol, nlay, icld, 0, 2500.0, dz, lat, 100, d["cldfr"]) if icld >= 4 else np.zeros((ncol, nlay))
+    ref = o.mcica_subcol(ncol, nlay, icld, 77, irng, *_gen_args(d), alpha)
+    got = hip256.mcica_subcol_lw(ncol, nlay, icld, 77, irng, *_gen_args(d), alpha=alpha if icld >= 4 else None)
+    assert got["cldfmcl"].shape == (256, ncol, nlay)
+    for k in SUB256:
+        assert np.array_equal(got[k], ref[k]), k
+    assert 0.0 < got["cldfmcl"].mean() < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,nlay,icld,ncol", [("cloudy", 72, 2, 200), ("cloudy", 40, 1, 70), ("aer_idrv", 60, 3, 90)])
+def test_g256_mcica_entries_match_oracle(hip256, config, nlay, icld, ncol):
+    """The McICA rrtmg_lw of the 256-g-point build: sub-column arrays (256, ncol, nlay) through the array entry (cldprmc, rtrnmc), and
+    the fused generator + solver entry on the same inputs (kissvec): the two must agree bit for bit."""
+    from oracle.bindings import Oracle
+    from test_hip_mcica import _gen_args
+    o = Oracle(gpoints=256)
+    d = make_gcm_inputs(ncol, nlay, config, col0=21)
+    sc = o.mcica_subcol(ncol, nlay, icld, 140, 0, *_gen_args(d), np.zeros((ncol, nlay)))
+    dd = dict(d); dd.update({k: sc[k] for k in SUB256})
+    got = hip256.rrtmg_lw_mcica_from_dict(dd, icld=icld)
+    ref = o.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd, mcica=True)
+    dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
+    dhr = max(np.abs(got[k] - ref[k]).max() for k in ("hr", "hrc"))
+    print(f"g256 mcica {config} L{nlay} icld{icld}: max|dflux|={dflux:.3e} max|dhr|={dhr:.3e}")
+    assert dflux <= 0.01 and dhr <= 0.001
+    assert dflux <= 5e-5 and dhr <= 5e-5
+    if d["idrv"]:
+        assert max(np.abs(got[k] - ref[k]).max() for k in ("duflx_dt", "duflxc_dt")) <= 5e-5
+    assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
+    fused = hip256.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0, icld=icld)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(got[k], fused[k]), k
 
 
 @pytest.mark.gpu
@@ -170,3 +276,23 @@ def test_g256_prepared_columns_match_reference_fixture(hip256, path):
         gb = hip256.run_columns([col], b, b)
         for k, fk in (("totuflux", "up"), ("totdflux", "dn"), ("htr", "htr")):
             assert np.abs(gb[k][0] - f[f"b{b}_{fk}"]).max() <= 5e-5, (b, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", MC_FIX, ids=os.path.basename)
+def test_g256_mcica_matches_reference_fixture(hip256, path):
+    """HIP (256-g library): generator masks bit-exact and McICA fluxes against numbers the reference's own 256-g-point McICA build produced."""
+    f = np.load(path)
+    ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
+    d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
+    sub = _fixture_subcolumns(lambda *a: hip256.mcica_subcol_lw(*a), f, d)
+    _check_subcolumns(sub, f)
+    dd = dict(d); dd.update({k: sub[k] for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl", "reicmcl", "relqmcl")})
+    got = hip256.rrtmg_lw_mcica_from_dict(dd, icld=icld)
+    dflux = max(np.abs(got[k] - f[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
+    dhr = max(np.abs(got[k] - f[k]).max() for k in ("hr", "hrc"))
+    print(f"{os.path.basename(path)}: HIP-256 McICA vs reference-256 fixture max|dflux|={dflux:.3e} max|dhr|={dhr:.3e}")
+    assert dflux <= 0.01 and dhr <= 0.001
+    assert dflux <= 5e-5 and dhr <= 5e-5
+    if d["idrv"]:
+        assert max(np.abs(got[k] - f[k]).max() for k in ("duflx_dt", "duflxc_dt")) <= 5e-5

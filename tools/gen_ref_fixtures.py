@@ -41,6 +41,7 @@ COL_CASES = [  # name, input, cloud file, aerosol file
 
 
 G256_GCM_CASES = [("clear72", "clear", 4, 72, 0), ("cloudy72_mr", "cloudy", 16, 72, 2), ("aer60_rnd", "aer_idrv", 8, 60, 1)]
+G256_MCICA_CASES = [("cloudy40_mr_kiss", "cloudy", 10, 40, 2, 0, 2), ("aer33_rnd_mt", "aer_idrv", 6, 33, 1, 1, 1)]     # name, config, ncol, nlay, icld, irng, ims
 G256_COL_CASES = [c for c in COL_CASES if c[0] in ("MLS-clr", "MLS-cld5-icld2", "SAW-clr")]
 COL_KEYS = ("totuflux", "totdflux", "fnet", "htr", "totuclfl", "totdclfl", "fnetc", "htrc", "dtotuflux_dt", "dtotuclfl_dt")
 
@@ -62,6 +63,28 @@ def g256():
             bands.update({f"b{b}_up": ob["totuflux"], f"b{b}_dn": ob["totdflux"], f"b{b}_htr": ob["htr"]})
         np.savez_compressed(os.path.join(G, f"ref_g256_col_{name}.npz"), inp=inp, cld=cld or "", aer=aer or "",
                             taug=o["taug"].astype(np.float32), fracs=o["fracs"].astype(np.float32), **{k: o[k] for k in COL_KEYS}, **bands)
+    # McICA in the same configuration: 256 sub-columns from the reference's one-column generator, then its McICA rrtmg_lw
+    refm = Reference("mcica_g256")
+    for name, cfg, ncol, nlay, icld, irng, ims in G256_MCICA_CASES:
+        d = make_gcm_inputs(ncol, nlay, cfg, col0=777)
+        z3 = lambda: np.zeros((256, ncol, nlay), order="F")
+        sub = dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), taucmcl=z3(), reicmcl=np.zeros((ncol, nlay), order="F"),
+                   relqmcl=np.zeros((ncol, nlay), order="F"))
+        for c in range(ncol):
+            r = refm.mcica_subcol_1col(nlay, icld, ims, irng, d["play"][c], d["cldfr"][c], d["cicewp"][c], d["cliqwp"][c],
+                                       d["reice"][c], d["reliq"][c], d["taucld"][:, c, :], np.zeros(nlay))
+            for k3, k2 in (("cldfmcl", "cldfmc"), ("ciwpmcl", "ciwpmc"), ("clwpmcl", "clwpmc"), ("taucmcl", "taucmc")):
+                sub[k3][:, c, :] = r[k2]
+            sub["reicmcl"][c] = r["reicmc"]
+            sub["relqmcl"][c] = r["relqmc"]
+        dd = dict(d)
+        dd.update(sub)
+        o = refm.rrtmg_lw(ncol, nlay, icld, d["idrv"], dd)
+        assert set(np.unique(sub["cldfmcl"])) <= {0.0, 1.0}
+        np.savez_compressed(os.path.join(G, f"ref_g256_mcica_{name}.npz"), config=cfg, ncol=ncol, nlay=nlay, icld=icld, irng=irng, ims=ims,
+                            col0=777, icld_out=o["icld"], mask=np.packbits(sub["cldfmcl"].astype(np.uint8).ravel(order="F")),
+                            ciwpsum=sub["ciwpmcl"].sum(axis=0), clwpsum=sub["clwpmcl"].sum(axis=0), taucsum=sub["taucmcl"].sum(axis=0),
+                            **{k: o[k] for k in OUT_KEYS})
     print("wrote 256-g-point fixtures to", G)
 
 
