@@ -329,13 +329,16 @@ def get_alpha(ncol, nlay, icld, idcor, decorr_con, dz, lat, juldat, cldfrac):
     return alpha
 
 
-def mcica_subcol_lw(ncol, nlay, icld, permuteseed, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha=None):
+def mcica_subcol_lw(ncol, nlay, icld, permuteseed, irng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha=None, out=None):
     """mcica_subcol_lw (src/mcica_subcol_gen_lw.f90:183-185; `iplon` dropped: every column is generated).
-    Returns dict(cldfmcl, ciwpmcl, clwpmcl, taucmcl (140,ncol,nlay), reicmcl, relqmcl (ncol,nlay), irng)."""
+    Returns dict(cldfmcl, ciwpmcl, clwpmcl, taucmcl (ngpt,ncol,nlay), reicmcl, relqmcl (ncol,nlay), irng); `out`: such a dict of
+    preallocated Fortran-ordered arrays to fill (a host model's sub-column arrays persist)."""
     ng = gpoints()
     z3 = lambda: np.zeros((ng, ncol, nlay), order="F")
     z2 = lambda: np.zeros((ncol, nlay), order="F")
-    o = dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), reicmcl=z2(), relqmcl=z2(), taucmcl=z3())
+    o = out if out is not None else dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), reicmcl=z2(), relqmcl=z2(), taucmcl=z3())
+    for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl"):
+        _f(o[k], (ng, ncol, nlay))
     irng_c = C.c_int(int(irng))
     ins = [_f(play, (ncol, nlay)), _f(cldfrac, (ncol, nlay)), _f(ciwp, (ncol, nlay)), _f(clwp, (ncol, nlay)),
            _f(rei, (ncol, nlay)), _f(rel, (ncol, nlay)), _f(tauc, (NBND, ncol, nlay))]

@@ -2224,28 +2224,33 @@ int rrtmg_lw_hip_mcica_subcol(
     hipStream_t s = G.stream;
     if (int rc = stage_in(ins, n, 0, n, s)) return rc;
     if (int rc = generate_mask(s, ncol, nlay, icld, permuteseed, *irng, ins[0].d, ins[1].d, ins[5].d)) return rc;
-    // expand layer slabs through a bounded device buffer: 4 arrays x 140 x ncol doubles per layer
-    const size_t slab = (size_t)NGPT * n;
-    double *d_out = nullptr;
-    const int lchunk = (int)std::max<size_t>(1, std::min<size_t>(L, ((size_t)1 << 30) / (slab * 4 * 8 + 1)));
-    HIP_TRY(hipMalloc((void **)&d_out, slab * 4 * 8 * lchunk));
-    int rc = 0;
-    for (int l0 = 0; l0 < nlay && rc == 0; l0 += lchunk) {
-        const int nl = std::min(lchunk, nlay - l0);
-        double *o[4];
-        for (int k = 0; k < 4; k++) o[k] = d_out + (size_t)k * slab * lchunk;
-        const dim3 grid((unsigned)((slab + BLOCK - 1) / BLOCK), nl), block(BLOCK);
-        hipLaunchKernelGGL(k_subcol_expand, grid, block, 0, s, G.W, (const double *)ins[2].d, (const double *)ins[3].d,
-                           (const double *)ins[4].d, ncol, nlay, l0, o[0], o[1], o[2], o[3]);
-        double *ho[4] = {cldfmcl, ciwpmcl, clwpmcl, taucmcl};
-        for (int k = 0; k < 4 && rc == 0; k++) {
-            hipError_t e = hipMemcpyAsync(ho[k] + slab * l0, d_out + (size_t)k * slab * lchunk, slab * nl * 8, hipMemcpyDeviceToHost, s);
-            if (e != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "sub-column copy: %s", hipGetErrorString(e));
+    // The sub-column arrays are implied by the mask (MASK_WORDS x 4 B per (column, layer)) and the grid-mean inputs, which the host holds:
+    // the mask comes back over PCIe and the host threads write the four (ngpt, ncol, nlay) arrays - 4 x ngpt x 8 B per (column, layer), 224
+    // times the mask - at memory speed (src/mcica_subcol_gen_lw.f90:664-680: where cloudy the layer's water paths and the band's optical
+    // depth, elsewhere zero).  (Expanding on the device and copying 322 KB per 72-layer column back ran at 0.03 M columns/s.)
+    std::vector<unsigned> hmask((size_t)MASK_WORDS * L * n);
+    HIP_TRY(hipMemcpyAsync(hmask.data(), G.mask, hmask.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int gband[NGPT];
+    for (int ig = 0; ig < NGPT; ig++) { int b = 1; for (int B = 2; B <= NBND; B++) b += (ig >= band_g0(B)) ? 1 : 0; gband[ig] = b - 1; }
+    host_parallel((size_t)NGPT * n * L * 8 * 4, [&](int t, int nt) {
+        const size_t cells = n * L;
+        for (size_t cl = cells * (size_t)t / (size_t)nt; cl < cells * (size_t)(t + 1) / (size_t)nt; cl++) {
+            const size_t l = cl / n, gc = cl % n;                      // cl = gc + n * l: the arrays' (column, layer) order
+            unsigned w[MASK_WORDS];
+            for (int k = 0; k < MASK_WORDS; k++) w[k] = hmask[((size_t)k * L + l) * n + gc];
+            const double iw = ciwp[cl], lw = clwp[cl];
+            const double *tc = tauc + (size_t)NBND * cl;
+            double *o0 = cldfmcl + (size_t)NGPT * cl, *o1 = ciwpmcl + (size_t)NGPT * cl, *o2 = clwpmcl + (size_t)NGPT * cl, *o3 = taucmcl + (size_t)NGPT * cl;
+            for (int ig = 0; ig < NGPT; ig++) {
+                const bool on = (w[ig >> 5] >> (ig & 31)) & 1u;
+                o0[ig] = on ? 1.0 : 0.0;
+                o1[ig] = on ? iw : 0.0;
+                o2[ig] = on ? lw : 0.0;
+                o3[ig] = on ? tc[gband[ig]] : 0.0;
+            }
         }
-        if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "sub-column expand failed");
-    }
-    (void)hipFree(d_out);
-    if (rc) return rc;
+    });
     memcpy(reicmcl, rei, n * L * 8);                            // :283-284
     memcpy(relqmcl, rel, n * L * 8);
     return read_physics_error(s);
