@@ -87,24 +87,23 @@
 
       integer(c_int) :: rc, irng_c
       integer :: ng                                   ! sub-columns = g-points of the linked library (ngptlw: 140, or 256)
-      real(c_double), allocatable :: o3(:,:,:,:), o2(:,:,:)
 
       if (icld == 0) return                            ! src/mcica_subcol_gen_lw.f90:265
       irng_c = int(irng, c_int)
       ng = int(rrtmg_lw_hip_gpoints())
-      allocate(o3(ng, ncol, nlay, 4), o2(ncol, nlay, 2))
+      if (size(cldfmcl,1) < ng .or. size(cldfmcl,2) < ncol .or. size(cldfmcl,3) < nlay) then
+         write(*,'(a,i0,a,i0,a,i0,a)') 'mcica_subcol_lw: the sub-column arrays are smaller than (', ng, ',', ncol, ',', nlay, ')'
+         error stop 1
+      endif
+      ! sections (1:ngptlw, 1:ncol, 1:nlay): exactly-sized arrays (322 KB per 72-layer column) are filled in place, oversized or
+      ! strided ones through the compiler's packed temporaries
       rc = rrtmg_lw_hip_mcica_subcol(int(ncol, c_int), int(nlay, c_int), int(icld, c_int), int(permuteseed, c_int), irng_c, &
             play(1:ncol, 1:nlay), cldfrac(1:ncol, 1:nlay), ciwp(1:ncol, 1:nlay), clwp(1:ncol, 1:nlay), &
             rei(1:ncol, 1:nlay), rel(1:ncol, 1:nlay), tauc(1:16, 1:ncol, 1:nlay), alpha(1:ncol, 1:nlay), &
-            o3(:,:,:,1), o3(:,:,:,2), o3(:,:,:,3), o2(:,:,1), o2(:,:,2), o3(:,:,:,4))
+            cldfmcl(1:ng, 1:ncol, 1:nlay), ciwpmcl(1:ng, 1:ncol, 1:nlay), clwpmcl(1:ng, 1:ncol, 1:nlay), &
+            reicmcl(1:ncol, 1:nlay), relqmcl(1:ncol, 1:nlay), taucmcl(1:ng, 1:ncol, 1:nlay))
       if (rc /= 0) call rrtmg_lw_hip_abort('mcica_subcol_lw')
       irng = int(irng_c, im)
-      cldfmcl(1:ng, 1:ncol, 1:nlay) = o3(:,:,:,1)
-      ciwpmcl(1:ng, 1:ncol, 1:nlay) = o3(:,:,:,2)
-      clwpmcl(1:ng, 1:ncol, 1:nlay) = o3(:,:,:,3)
-      taucmcl(1:ng, 1:ncol, 1:nlay) = o3(:,:,:,4)
-      reicmcl(1:ncol, 1:nlay) = o2(:,:,1)
-      relqmcl(1:ncol, 1:nlay) = o2(:,:,2)
 
       end subroutine mcica_subcol_lw
 
