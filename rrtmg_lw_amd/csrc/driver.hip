@@ -28,6 +28,12 @@ constexpr int BLOCK = 256;
 // columns per batch of the host-pointer entries (H2D | kernels | D2H pipeline); RRTMG_LW_HOST_BATCH overrides (measurements)
 const int HOST_BATCH = []() { const char *e = getenv("RRTMG_LW_HOST_BATCH"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 16384; }();     // 16 384: the entries are bound by the host threads, short batches fill and drain the pipeline sooner (524 288 columns pinned: 93.8 ms against 119.6 with 32 768)
 
+// staging sets of the host-pointer pipeline (device staging, pinned host staging, events): the calling thread may be this many batches
+// ahead of the batch whose outputs it unpacks.  With two, the thread's waits at the head of every iteration (the H2D of batch i - 2 out of
+// the pinned set, the D2H of batch i - 2 into it) left the copy engines and the kernels taking turns: a trace of a 524 288-column call
+// showed 11 ms of overlap between 44 ms of kernels and 52 ms of copies.
+constexpr int HOST_SETS = 4;
+
 struct State {
     bool init = false;
     int device = -1;
@@ -69,13 +75,13 @@ struct State {
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
     hipStream_t cp_in = nullptr, cp_out = nullptr;      // host-pointer entries: H2D and D2H copy streams
-    double *h_tot = nullptr;                            // pinned host scratch of the non-McICA host entry: tauctot of two column batches
+    double *h_tot = nullptr;                            // pinned host scratch of the non-McICA host entry: tauctot of HOST_SETS column batches
     size_t h_tot_doubles = 0;
     // pinned host staging of the host-pointer entries, two sets like the device staging: `in` = the rows of the caller's PAGEABLE input
     // arrays that travel (packed by the host threads, then one DMA per run of rows), `out` = the pageable output arrays' rows (DMA, then
     // unpacked by the host threads), `fill` = the table of k_fill_rows (rows that do not travel)
-    struct HostSet { char *in = nullptr; size_t in_cap = 0; char *out = nullptr; size_t out_cap = 0; char *fill = nullptr; size_t fill_cap = 0; } hset[2];
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    struct HostSet { char *in = nullptr; size_t in_cap = 0; char *out = nullptr; size_t out_cap = 0; char *fill = nullptr; size_t fill_cap = 0; } hset[HOST_SETS];
+    hipEvent_t ev_h2d[HOST_SETS] = {}, ev_cmp[HOST_SETS] = {}, ev_d2h[HOST_SETS] = {};
     std::string err;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profile = false;
@@ -892,7 +898,7 @@ int ensure_copy_streams()
     if (G.cp_in) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&G.cp_in, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&G.cp_out, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < HOST_SETS; k++) {
         HIP_TRY(hipEventCreateWithFlags(&G.ev_h2d[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&G.ev_cmp[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&G.ev_d2h[k], hipEventDisableTiming));
@@ -979,7 +985,7 @@ int stage_rows(std::vector<HostIn> &ins, size_t nb, int k, hipStream_t s)
 }
 
 // Host-pointer entries as a three-stage pipeline over the column batches: H2D of batch i+1 (copy stream) | kernels of
-// batch i (G.stream) | D2H of batch i-1 (second copy stream), two staging sets on the device and two pinned sets on the host.
+// batch i (G.stream) | D2H of batch i-1 (second copy stream), HOST_SETS staging sets on the device and as many pinned sets on the host.
 // The calling thread (with the host threads) scans and packs batch i+1 and unpacks the outputs of batch i-1 while the DMAs and
 // kernels of the batches between are in flight; nothing it calls blocks on a copy.  body(stream, nb, col0, in, out) enqueues the
 // kernels of one batch whose staged arrays start at column 0; prep(k, col0, nb, stream) is the entry's own host work for the batch.
@@ -1008,7 +1014,7 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
         if (a.active && a.h && !a.pinned) out_pageable += a.rows * (size_t)nbmax * 8;
     }
     set = align_up(set * 8, 256);
-    if (int rc = ensure_stage(2 * set + 4096)) return rc;
+    if (int rc = ensure_stage(HOST_SETS * set + 4096)) return rc;
     for (auto &hs : G.hset) {
         if (int rc = ensure_hostbuf(&hs.fill, &hs.fill_cap, nrows * sizeof(RowFill))) return rc;
         if (int rc = ensure_hostbuf(&hs.out, &hs.out_cap, out_pageable)) return rc;
@@ -1018,7 +1024,7 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
         for (auto &a : ins) { a.d = a.h ? p : nullptr; p += a.h ? a.inner * a.rows * (size_t)nbmax : 0; }
         for (auto &a : outs) { a.d = p; p += a.rows * (size_t)nbmax; }
     };
-    struct Pending { bool on = false; int col0 = 0, nb = 0; } pend[2];
+    struct Pending { bool on = false; int col0 = 0, nb = 0; } pend[HOST_SETS];
     auto copy_out = [&](int k, int col0, int nb) -> int {
         bind(k);
         HIP_TRY(hipStreamWaitEvent(G.cp_out, G.ev_cmp[k], 0));
@@ -1036,8 +1042,14 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
         pend[k] = Pending{any, col0, nb};
         return 0;
     };
-    auto unpack = [&](int k) -> int {        // the pageable output arrays' rows of the batch that used set k last: pinned set -> the caller's arrays
+    // the pageable output arrays' rows of the batch that used set k last: pinned set -> the caller's arrays.  must = false: only if its D2H has landed
+    auto unpack = [&](int k, bool must) -> int {
         if (!pend[k].on) return 0;
+        if (!must) {
+            const hipError_t q = hipEventQuery(G.ev_d2h[k]);
+            if (q == hipErrorNotReady) return 0;
+            if (q != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
         pend[k].on = false;
         HIP_TRY(hipEventSynchronize(G.ev_d2h[k]));
         const size_t nb = (size_t)pend[k].nb, col0 = (size_t)pend[k].col0;
@@ -1068,14 +1080,14 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
     const auto t_call = std::chrono::steady_clock::now();
     int i = 0, prev_col0 = 0, prev_nb = 0;
     for (int col0 = c0; col0 < c1; col0 += nbmax, i++) {
-        const int nb = std::min(nbmax, c1 - col0), k = i & 1;
+        const int nb = std::min(nbmax, c1 - col0), k = i % HOST_SETS, kprev = (i + HOST_SETS - 1) % HOST_SETS;
         bind(k);
         clk.start();
-        if (i >= 2) {
-            HIP_TRY(hipStreamWaitEvent(G.cp_in, G.ev_cmp[k], 0));          // kernels of batch i-2 have read staging set k
+        if (i >= HOST_SETS) {
+            HIP_TRY(hipStreamWaitEvent(G.cp_in, G.ev_cmp[k], 0));          // kernels of batch i - HOST_SETS have read staging set k
             HIP_TRY(hipEventSynchronize(G.ev_h2d[k]));                     // its DMAs have left the pinned set k (this thread runs ahead of the device)
             clk.lap(0);
-            if (int rc = unpack(k)) return rc;
+            if (int rc = unpack(k, true)) return rc;
             clk.lap(1);
         }
         for (auto &a : ins) { a.src = a.h; a.src_ncol = (size_t)ncol; a.src_col0 = (size_t)col0; a.src_pinned = a.pinned; a.skip = nullptr; }
@@ -1088,21 +1100,25 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
         HIP_TRY(hipEventRecord(G.ev_h2d[k], G.cp_in));
         clk.lap(3);
         HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_h2d[k], 0));
-        if (i >= 2) HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_d2h[k], 0));         // outputs of batch i-2 have left staging set k
+        if (i >= HOST_SETS) HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_d2h[k], 0));         // outputs of batch i - HOST_SETS have left staging set k
         tmark(G.stream);
         if (int rc = body(G.stream, nb, col0, ins, outs)) return rc;
         tmark(G.stream);
         HIP_TRY(hipEventRecord(G.ev_cmp[k], G.stream));
         clk.lap(4);
         if (i >= 1)
-            if (int rc = copy_out(k ^ 1, prev_col0, prev_nb)) return rc;
+            if (int rc = copy_out(kprev, prev_col0, prev_nb)) return rc;
         clk.lap(5);
+        // outputs that have landed in the meantime (oldest first): unpacked now, while the device works on the batches just enqueued
+        for (int j = 1; j < HOST_SETS; j++)
+            if (int rc = unpack((k + j) % HOST_SETS, false)) return rc;
+        clk.lap(1);
         prev_col0 = col0; prev_nb = nb;
     }
     clk.start();
-    if (int rc = copy_out((i - 1) & 1, prev_col0, prev_nb)) return rc;
-    if (int rc = unpack(i & 1)) return rc;               // (the batch before the last, if any)
-    if (int rc = unpack((i - 1) & 1)) return rc;
+    if (int rc = copy_out((i + HOST_SETS - 1) % HOST_SETS, prev_col0, prev_nb)) return rc;
+    for (int j = 0; j < HOST_SETS; j++)                  // (oldest first)
+        if (int rc = unpack((i + j) % HOST_SETS, true)) return rc;
     HIP_TRY(hipStreamSynchronize(G.cp_out));
     HIP_TRY(hipStreamSynchronize(G.stream));
     clk.lap(6);
@@ -1478,7 +1494,7 @@ static void finalize_state()
     if (G.cp_in) {
         (void)hipStreamDestroy(G.cp_in);
         (void)hipStreamDestroy(G.cp_out);
-        for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_h2d[k]); (void)hipEventDestroy(G.ev_cmp[k]); (void)hipEventDestroy(G.ev_d2h[k]); }
+        for (int k = 0; k < HOST_SETS; k++) { (void)hipEventDestroy(G.ev_h2d[k]); (void)hipEventDestroy(G.ev_cmp[k]); (void)hipEventDestroy(G.ev_d2h[k]); }
     }
     if (G.aux) {
         (void)hipStreamDestroy(G.aux);
@@ -1671,10 +1687,10 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
         {cloud ? cliqwp : nullptr, 1, L, 0}, {cloud ? reice : nullptr, 1, L, 0}, {cloud ? reliq : nullptr, 1, L, 0}};
     for (size_t k = 0; k < 17; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array (argument %d)", (int)k);
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
-    if (use_tot && G.h_tot_doubles < 2 * L * (size_t)nbmax) {
+    if (use_tot && G.h_tot_doubles < HOST_SETS * L * (size_t)nbmax) {
         if (G.h_tot) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipHostFree(G.h_tot)); G.h_tot = nullptr; G.h_tot_doubles = 0; }
-        HIP_TRY(hipHostMalloc((void **)&G.h_tot, 2 * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
-        G.h_tot_doubles = 2 * L * (size_t)nbmax;
+        HIP_TRY(hipHostMalloc((void **)&G.h_tot, HOST_SETS * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
+        G.h_tot_doubles = HOST_SETS * L * (size_t)nbmax;
     }
     std::vector<unsigned char> cloudfree(L, 0);
     auto prep = [&](int k, int col0, int nb, hipStream_t) -> int {
@@ -2128,7 +2144,7 @@ int rrtmg_lw_hip_run_mcica(
     if (int rc = check_common(ncol, nlay)) return rc;
     HIP_TRY(hipDeviceSynchronize());        // asynchronous device-entry work of earlier calls shares the workspace
     // the sub-column arrays are 4 x 140 x nlay doubles per column: bound the batch so that staging stays below ~4 GB
-    const int mcmax = (int)std::max<size_t>(64, ((size_t)2 << 30) / ((size_t)4 * NGPT * nlay * 8));        // (two staging sets)
+    const int mcmax = (int)std::max<size_t>(64, ((size_t)1 << 30) / ((size_t)4 * NGPT * nlay * 8));        // (HOST_SETS staging sets of 1 GiB)
     const int nbmax = balanced_batch(c1 - c0, std::min(std::min(G.batch, HOST_BATCH), cloud ? mcmax : HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud)) return rc;
     const size_t L = (size_t)nlay;
