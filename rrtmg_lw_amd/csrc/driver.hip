@@ -723,6 +723,8 @@ struct HostIn {
     bool pinned = false;                                  // h is page-locked (rrtmg_lw_hip_host_register, or pinned by the caller's own means)
     const double *src = nullptr; size_t src_ncol = 0, src_col0 = 0; bool src_pinned = false;
     const unsigned char *skip = nullptr;                  // per batch, set by the entry's prep step: rows nothing reads (a cloud array's layers without cloud) - not scanned, zero-filled
+    const unsigned char *known = nullptr;                 // ... rows the prep step has already read in full and found to hold one pattern (known_bits): not scanned again
+    const uint64_t *known_bits = nullptr;
 };
 struct HostOut { double *h; size_t rows; double *d; bool active; bool pinned = false; };
 
@@ -770,7 +772,7 @@ int host_threads()
         cpu_set_t set;
         if (!e && sched_getaffinity(0, sizeof set, &set) == 0) v = std::min(v, CPU_COUNT(&set));
 #endif
-        return std::max(1, std::min(v, 16));
+        return std::max(1, std::min(v, e ? 64 : 16));     // (sixteen unless the variable asks for more: the scan is bound by the memory of the NUMA node the arrays live on)
     }();
     return nt;
 }
@@ -847,21 +849,27 @@ void host_parallel(size_t work_bytes, F f)
 // flags[r] = 1 when every value of row r of the column batch [col0, col0 + nb) of a (rows, ncol, inner) array is below `thr` (a NaN is not).
 // With thr = cldmin: a layer of the cloud fraction without cloud in any column of the batch - cldprop / cldprmc then read nothing else of that
 // layer (src/rrtmg_lw_cldprop.f90:185-186, src/rrtmg_lw_cldprmc.f90:182-183), so the other cloud arrays' rows of that layer need not be read here.
-void rows_below(const double *h, size_t inner, size_t rows, size_t ncol, size_t col0, size_t nb, double thr, unsigned char *flags)
+// uni / bits (optional): rows that were read to their end (the ones below the threshold) and hold ONE 8-byte pattern - stage_rows need not read them again.
+void rows_below(const double *h, size_t inner, size_t rows, size_t ncol, size_t col0, size_t nb, double thr, unsigned char *flags,
+                unsigned char *uni = nullptr, uint64_t *bits = nullptr)
 {
     host_parallel(inner * rows * nb * 8, [&](int t, int nt) {
         for (size_t r = (size_t)t; r < rows; r += (size_t)nt) {
             const double *p = h + inner * (col0 + ncol * r);
+            const uint64_t *u = reinterpret_cast<const uint64_t *>(p);
             const size_t n = inner * nb;
+            const uint64_t v = u[0];
+            uint64_t acc = 0;
             bool below = true;
             size_t i = 0;
             for (; i + 64 <= n && below; i += 64) {
                 int ok = 1;
-                for (size_t e = 0; e < 64; e++) ok &= (int)(p[i + e] < thr);
+                for (size_t e = 0; e < 64; e++) { ok &= (int)(p[i + e] < thr); acc |= u[i + e] ^ v; }
                 below = ok != 0;
             }
-            for (; i < n && below; i++) below = p[i] < thr;
+            for (; i < n && below; i++) { below = p[i] < thr; acc |= u[i] ^ v; }
             flags[r] = below ? 1 : 0;
+            if (uni) { uni[r] = (below && acc == 0) ? 1 : 0; bits[r] = v; }
         }
     });
 }
@@ -935,6 +943,7 @@ int stage_rows(std::vector<HostIn> &ins, size_t nb, int k, hipStream_t s)
         for (size_t j = (size_t)t; j < rows.size(); j += (size_t)nt) {
             StagedRow &q = rows[j];
             if (ins[q.arr].skip && ins[q.arr].skip[q.row]) { q.uniform = true; q.bits = 0; continue; }
+            if (ins[q.arr].known && ins[q.arr].known[q.row]) { q.uniform = true; q.bits = ins[q.arr].known_bits[q.row]; continue; }
             const uint64_t *p = reinterpret_cast<const uint64_t *>(row_src(q));
             const size_t n = ins[q.arr].inner * nb;
             const uint64_t v = p[0];
@@ -1090,7 +1099,7 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
             if (int rc = unpack(k, true)) return rc;
             clk.lap(1);
         }
-        for (auto &a : ins) { a.src = a.h; a.src_ncol = (size_t)ncol; a.src_col0 = (size_t)col0; a.src_pinned = a.pinned; a.skip = nullptr; }
+        for (auto &a : ins) { a.src = a.h; a.src_ncol = (size_t)ncol; a.src_col0 = (size_t)col0; a.src_pinned = a.pinned; a.skip = nullptr; a.known = nullptr; a.known_bits = nullptr; }
         // the entry's own host work for this batch (reductions into its pinned scratch set k, which it then names as an array's source)
         if (int rc = prep(k, col0, nb, G.cp_in)) return rc;
         clk.lap(2);
@@ -2167,10 +2176,12 @@ int rrtmg_lw_hip_run_mcica(
         return run_batch<true>(s, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, &m);
     };
     // layers whose sub-column cloud fractions are all below cldmin for the batch: cldprmc reads nothing else of them (src/rrtmg_lw_cldprmc.f90:182-183)
-    std::vector<unsigned char> cloudfree(L, 0);
+    std::vector<unsigned char> cloudfree(L, 0), cf_uni(L, 0);
+    std::vector<uint64_t> cf_bits(L, 0);
     auto prep = [&](int, int col0, int nb, hipStream_t) -> int {
         if (!cloud) return 0;
-        rows_below(cldfmcl, NGPT, L, (size_t)ncol, (size_t)col0, (size_t)nb, 1.e-20, cloudfree.data());
+        rows_below(cldfmcl, NGPT, L, (size_t)ncol, (size_t)col0, (size_t)nb, 1.e-20, cloudfree.data(), cf_uni.data(), cf_bits.data());
+        ins[17].known = cf_uni.data(); ins[17].known_bits = cf_bits.data();        // (the cloud-free layers of cldfmcl have just been read to their end)
         for (size_t a = 18; a < ins.size(); a++) ins[a].skip = cloudfree.data();
         return 0;
     };
