@@ -77,7 +77,7 @@ struct State {
     hipStream_t cp_in = nullptr, cp_out = nullptr;      // host-pointer entries: H2D and D2H copy streams
     double *h_tot = nullptr;                            // pinned host scratch of the non-McICA host entry: tauctot of HOST_SETS column batches
     size_t h_tot_doubles = 0;
-    // pinned host staging of the host-pointer entries, two sets like the device staging: `in` = the rows of the caller's PAGEABLE input
+    // pinned host staging of the host-pointer entries, HOST_SETS sets like the device staging: `in` = the rows of the caller's PAGEABLE input
     // arrays that travel (packed by the host threads, then one DMA per run of rows), `out` = the pageable output arrays' rows (DMA, then
     // unpacked by the host threads), `fill` = the table of k_fill_rows (rows that do not travel)
     struct HostSet { char *in = nullptr; size_t in_cap = 0; char *out = nullptr; size_t out_cap = 0; char *fill = nullptr; size_t fill_cap = 0; } hset[HOST_SETS];

@@ -2497,6 +2497,12 @@ __device__ __forceinline__ void bstore_f64x2(void *base, unsigned voff, double v
 }
 
 // table index of a cell's code (0 for the series branch: entry 0 is {1 - exp = 0, tfn = 0})
+// From here to the end of k_sweepz nothing is contracted behind the source's back: every fused multiply-add of the sweeps is written as
+// one (fma).  The two sweep kernels, and the copies of a level's body inside each (one per prefetch slot), must round a level alike -
+// which of them sweeps a level follows from the clouds of the 64-column block a column shares - and with contraction left to the
+// compiler they did not: tp + f * (tq1 - tq0) of planck_at fused in one inlined copy and not in another moved a flux partial by an ulp
+// (tools/soak_host_entry.py, tests/test_hip_parity.py::test_a_column_does_not_depend_on_its_neighbours).
+#pragma clang fp contract(off)
 __device__ __forceinline__ unsigned code_index(scr_t c) { return (unsigned)max((int)(-c), 0); }
 // the optical depth of a series cell, 0 for a table cell: max(c, 0) on the bit pattern (a negative float is a negative integer)
 __device__ __forceinline__ float code_od(scr_t c) { return __int_as_float(max(__float_as_int(c), 0)); }
@@ -2506,14 +2512,14 @@ __device__ __forceinline__ void decode(scr_t c, const float2 &e, double &atr, do
 {
 #ifdef RRLW_DECODE_F64
     const double od = (double)code_od(c);
-    atr = (double)e.x + (od - 0.5 * od * od);
-    tfn = (double)e.y + 0.166667 * od;
+    atr = (double)e.x + fma(-0.5 * od, od, od);
+    tfn = fma(0.166667, od, (double)e.y);
 #else
     // float arithmetic up to the two conversions: the table values are floats already, and of the two summands one is an exact
     // zero; the series terms carry ~1e-7 relative error (od <= 0.06), the same class as the float table entries
     const float od = code_od(c);
     atr = (double)(e.x + __builtin_fmaf(-0.5f * od, od, od));
-    tfn = (double)(e.y + 0.166667f * od);
+    tfn = (double)__builtin_fmaf(0.166667f, od, e.y);
 #endif
 }
 // RRLW_SWEEP_EXPF (measurement variant, north_star "__builtin_amdgcn_expf for transmittance"): the table entry of index i evaluated
@@ -2544,7 +2550,7 @@ __device__ __forceinline__ double planck_at(const double *tp, const double *tq, 
     const double x = t - 159.;
     const int ind = clampi((int)x, 1, 180);
     const double f = x - (double)ind;
-    return tp[ind - 1] + f * (tq[ind] - tq[ind - 1]);
+    return fma(f, tq[ind] - tq[ind - 1], tp[ind - 1]);
 }
 
 // LDS tables of a sweep workgroup (one band): the transmittance table as float pairs {1 - exp, tfn}, the band's row of totplnk (and band
@@ -2681,6 +2687,26 @@ __host__ __device__ constexpr int sweepc_nsb(int NQ, int PHASE, bool IDRV, int n
 // in order, so a wait for everything would stall the wave on the codes it has just requested for the next level.
 template <int G> struct SweepcLev { double tl, tz; unsigned w; };
 
+// 1 - x as a value of its own.  With contraction allowed across statements the compiler folds (1 - x) * y into fma(-x, y, y) where the
+// difference has a single use and keeps the product where it has several: the same source line then rounds differently in two copies of
+// the level body (the two prefetch slots, the two kernels) and a level's d(flux)/dT depended, in its last bit, on the hand-off level of
+// its block - found by tools/soak_host_entry.py.  The empty asm hides the subtraction from that fold.
+__device__ __forceinline__ double one_minus(double x)
+{
+    double t = 1.0 - x;
+    asm("" : "+v"(t));
+    return t;
+}
+// ... and a product as a value of its own: d(radiance)/dT of a level is the product radiance' x (1 - a), which is both the state carried
+// upward and a term of the level's sum over the g-points - fused into that sum (fma(radiance', 1 - a, next term)) in one copy of the body
+// and not in another, the sum rounded differently.  (The radiances themselves are results of an fma; nothing is left to fuse.)
+__device__ __forceinline__ double times(double x, double y)
+{
+    double t = x * y;
+    asm("" : "+v"(t));
+    return t;
+}
+
 // NT threads (waves) per band, each with G = NQ / NT of its quads: the band's partial is the sum of their raw quad sums, formed - with the
 // band's weight - by the wave that adds the group (so a band split over two waves still rounds like one swept by a single thread).  Used
 // where all 16 g-points of a band with two streams would leave one wave per SIMD (sweepc_nt).
@@ -2773,6 +2799,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     unsigned bufoff = 0u;                                                                       // 0 / NVAL * vstride
     auto red_put = [&](int c, int val, double v) { red[bufoff + val * vstride + rband + (unsigned)(c * ncw) + rlane] = v; };
     auto round_end = [&](auto dn_tag, int lev0, int nvalid) {
+#pragma clang fp contract(off)      // (a band's weight, the flux factor and the sum over the bands round as written: in k_sweepz too - a level's partial must not depend on the kernel that swept it)
         constexpr bool DN = decltype(dn_tag)::value;
         constexpr int NV = DN ? 1 : NVAL;
         __syncthreads();
@@ -2847,13 +2874,14 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
                 double atr, tfn;
                 decode(ck.v[jj], e[jj], atr, tfn);
                 double fr = row[j];
-                if constexpr (BIN) fr = fr + fpl * (row[16 + j] - fr);
-                const double bb = fr * (blay + tfn * dpl);
-                rad[j] = rad[j] + (bb - rad[j]) * atr;
-                if constexpr (TWO && !DN) radc[j] = radc[j] + (bb - radc[j]) * atr;
+                if constexpr (BIN) fr = fma(fpl, row[16 + j] - fr, fr);
+                const double bb = fr * fma(tfn, dpl, blay);
+                rad[j] = fma(bb - rad[j], atr, rad[j]);
+                if constexpr (TWO && !DN) radc[j] = fma(bb - radc[j], atr, radc[j]);
                 if constexpr (IDRV && !DN) {
-                    drad[j] = drad[j] * (1.0 - atr);
-                    if constexpr (TWO) dradc[j] = dradc[j] * (1.0 - atr);
+                    const double tr = one_minus(atr);
+                    drad[j] = times(drad[j], tr);
+                    if constexpr (TWO) dradc[j] = times(dradc[j], tr);
                 }
             }
             qs[k] = (rad[4 * k] + rad[4 * k + 1]) + (rad[4 * k + 2] + rad[4 * k + 3]);
@@ -2931,10 +2959,10 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
         double usum = 0.0, dusum = 0.0;
 #pragma unroll
         for (int j = 0; j < NG; j++) {
-            const double fr = any_bin ? row[j] + fpl * (row[16 + j] - row[j]) : row[j];
-            rad[j] = fr * pb + reflect * rad[j];
+            const double fr = any_bin ? fma(fpl, row[16 + j] - row[j], row[j]) : row[j];
+            rad[j] = fma(reflect, rad[j], fr * pb);
             usum = usum + rad[j];
-            if constexpr (IDRV) { drad[j] = fr * dpb; dusum = dusum + drad[j]; }
+            if constexpr (IDRV) { drad[j] = times(fr, dpb); dusum = dusum + drad[j]; }
         }
         red_put(0, 0, usum);
         if constexpr (IDRV) red_put(0, 1, dusum);
@@ -3104,6 +3132,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     unsigned bufoff = 0u;
     auto red_put = [&](int c, int val, double v) { red[bufoff + val * vstride + rband + (unsigned)(c * ncw) + rlane] = v; };
     auto round_end = [&](auto dn_tag, int lev0, int nvalid) __attribute__((always_inline)) {
+#pragma clang fp contract(off)      // (as in k_sweepc)
         constexpr bool DN = decltype(dn_tag)::value;
         __syncthreads();
         constexpr int NV = DN ? 2 : NVAL;
@@ -3224,37 +3253,38 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                 double atr, tfn;
                 decode(ck.v[jj], e[jj], atr, tfn);
                 double fr = row[j];
-                if constexpr (BIN) fr = fr + fpl * (row[16 + j] - fr);
-                const double bb = fr * (blay + tfn * dpl);
+                if constexpr (BIN) fr = fma(fpl, row[16 + j] - fr, fr);
+                const double bb = fr * fma(tfn, dpl, blay);
                 // clear level: rtrnmr :617-627 / :705-716
-                const double rad_s = rad[j] + (bb - rad[j]) * atr;
-                const double updc = radc[j] + (bb - radc[j]) * atr;
+                const double rad_s = fma(bb - rad[j], atr, rad[j]);
+                const double updc = fma(bb - radc[j], atr, radc[j]);
                 if (!anycld) {
                     rad[j] = rad_s;
                     radc[j] = seen ? updc : rad_s;
                     if constexpr (IDRV && !DN) {
-                        drad[j] = drad[j] * (1.0 - atr);
-                        dradc[j] = seen ? dradc[j] * (1.0 - atr) : drad[j];
+                        const double tr = one_minus(atr);
+                        drad[j] = times(drad[j], tr);
+                        dradc[j] = seen ? times(dradc[j], tr) : drad[j];
                     }
                 } else {
                     // cloudy level: rtrnmr :591-615 / :680-703, formed for every lane of the wave and selected
                     double atot, tftot;
                     decode(ckt.v[jj], et[jj], atot, tftot);
-                    const double bbtot = fr * (blay + tftot * dpl);
+                    const double bbtot = fr * fma(tftot, dpl, blay);
                     const double gassrc = bb * atr;
                     double rad_c;
                     if constexpr (MODE == 2) {
                         double cr = cldrad[j], lr = clrrad[j], mr = radmr[j];
                         if (first) { cr = cf * rad[j]; lr = rad[j] - cr; mr = 0.0; }
-                        const double ttot = 1. - atot;
+                        const double ttot = one_minus(atot), tgas = one_minus(atr), clr = one_minus(cf);
                         const double cldsrc = bbtot * atot;
-                        cr = cr * ttot + cf * cldsrc;
-                        lr = lr * (1. - atr) + (1. - cf) * gassrc;
+                        cr = fma(cr, ttot, cf * cldsrc);
+                        lr = fma(lr, tgas, clr * gassrc);
                         rad_c = cr + lr;
-                        const double radmod = mr * (f0.x * (1. - atr) + f0.y * ttot) - f1.x * gassrc + f1.y * cldsrc;
+                        const double radmod = fma(f1.y, cldsrc, fma(-f1.x, gassrc, mr * fma(f0.x, tgas, f0.y * ttot)));
                         const double oldcld = cr - radmod;
                         const double oldclr = lr + radmod;
-                        mr = -radmod + f2.x * oldclr - f2.y * oldcld;
+                        mr = fma(-f2.y, oldcld, fma(f2.x, oldclr, -radmod));
                         // (the cloudy / clear parts and the carried correction of a lane that is clear at this level need not be kept:
                         // the next cloudy level of that column is the first of a block, istcld = 1, and sets them anew)
                         cldrad[j] = cr + mr;
@@ -3275,11 +3305,12 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                         double cfd = cf;
                         if constexpr (MODE == 4) cfd = ((gbits >> j) & 1u) ? 1.0 : 0.0;
                         if constexpr (MODE == 3) cfd = reinterpret_cast<const float *>(&cf4[k])[jj];
-                        const double d_s = drad[j] * (1.0 - atr);
-                        const double d_c = drad[j] * cfd * (1.0 - atot) + drad[j] * (1.0 - cfd) * (1.0 - atr);
-                        const double dc_s = seen ? dradc[j] * (1.0 - atr) : d_s;
+                        const double tr = one_minus(atr);
+                        const double d_s = times(drad[j], tr);
+                        const double d_c = times(drad[j] * cfd, one_minus(atot)) + times(drad[j] * one_minus(cfd), tr);     // (rtrnmr :697-699: two products and their sum, rounded as written)
+                        const double dc_s = seen ? times(dradc[j], tr) : d_s;
                         drad[j] = cloudy ? d_c : d_s;
-                        dradc[j] = cloudy ? dradc[j] * (1.0 - atr) : dc_s;
+                        dradc[j] = cloudy ? times(dradc[j], tr) : dc_s;
                     }
                 }
             }
@@ -3332,15 +3363,16 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                 double atr, tfn;
                 decode(ck.v[jj], e[jj], atr, tfn);
                 double fr = row[j];
-                if constexpr (BIN) fr = fr + fpl * (row[16 + j] - fr);
-                const double bb = fr * (blay + tfn * dpl);
-                const double rad_s = rad[j] + (bb - rad[j]) * atr;
-                const double updc = radc[j] + (bb - radc[j]) * atr;
+                if constexpr (BIN) fr = fma(fpl, row[16 + j] - fr, fr);
+                const double bb = fr * fma(tfn, dpl, blay);
+                const double rad_s = fma(bb - rad[j], atr, rad[j]);
+                const double updc = fma(bb - radc[j], atr, radc[j]);
                 rad[j] = rad_s;
                 radc[j] = seen ? updc : rad_s;
                 if constexpr (IDRV && !DN) {
-                    drad[j] = drad[j] * (1.0 - atr);
-                    dradc[j] = seen ? dradc[j] * (1.0 - atr) : drad[j];
+                    const double tr = one_minus(atr);
+                    drad[j] = times(drad[j], tr);
+                    dradc[j] = seen ? times(dradc[j], tr) : drad[j];
                 }
             }
             qs[k] = (rad[4 * k] + rad[4 * k + 1]) + (rad[4 * k + 2] + rad[4 * k + 3]);
@@ -3407,14 +3439,14 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         double usum = 0.0, usumc = 0.0, dusum = 0.0;
 #pragma unroll
         for (int j = 0; j < NG; j++) {
-            const double fr = any_bin ? row[j] + fpl * (row[16 + j] - row[j]) : row[j];
+            const double fr = any_bin ? fma(fpl, row[16 + j] - row[j], row[j]) : row[j];
             const double rad0 = fr * pb;
-            rad[j] = rad0 + reflect * rad[j];
-            radc[j] = rad0 + reflect * radc[j];
+            rad[j] = fma(reflect, rad[j], rad0);
+            radc[j] = fma(reflect, radc[j], rad0);
             usum = usum + rad[j];
             usumc = usumc + radc[j];
             if constexpr (MODE == 2) { cldrad[j] = 0.0; clrrad[j] = 0.0; radmr[j] = 0.0; }
-            if constexpr (IDRV) { drad[j] = fr * dpb; dradc[j] = drad[j]; dusum = dusum + drad[j]; }
+            if constexpr (IDRV) { drad[j] = times(fr, dpb); dradc[j] = drad[j]; dusum = dusum + drad[j]; }
         }
         red_put(0, 0, usum);
         red_put(0, 1, usumc);
@@ -3444,6 +3476,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     }
 }
 
+#pragma clang fp contract(fast)
 // ------------------------------------------------------------------------------------------------
 // k_n1 : PROTOTYPE of the mapping BASELINE.json's north_star names, for cloud-free calls (icld = 0), kept to put a number beside the
 //        production mapping ("north-star mapping"): ONE COLUMN PER WAVEFRONT, G-POINTS ACROSS LANES (three passes over the

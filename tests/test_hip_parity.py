@@ -63,6 +63,33 @@ def test_batching_is_transparent(hip, oracle):
         assert np.array_equal(one[k], many[k]), k
 
 
+def test_a_column_does_not_depend_on_its_neighbours(hip):
+    """A column's results - d(flux)/dT included - are the same, bit for bit, whether it is solved alone, in a block of other columns or in
+    the whole call: the hand-off level between the clear-sky and the cloud-zone sweeps follows from the clouds of the 64-column block a
+    column happens to share, and no level's sum may round differently for it (found by tools/soak_host_entry.py: a product fused into the
+    sum over the g-points in one copy of the level body and not in another)."""
+    ncol, nlay = 1500, 60
+    d = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=7)
+    assert d["idrv"] == 1
+    full = hip.rrtmg_lw_from_dict(d, icld=2)
+    names = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")
+
+    def part(c0, n):
+        p = dict(d); p["ncol"] = n
+        for k, v in d.items():
+            if isinstance(v, np.ndarray):
+                p[k] = np.asfortranarray(v[:, c0:c0 + n, :] if (v.ndim == 3 and v.shape[0] == 16) else v[c0:c0 + n])
+        return hip.rrtmg_lw_from_dict(p, icld=2)
+
+    cf = np.asarray(d["cldfr"])
+    tops = np.array([(np.nonzero(cf[i] > 0)[0] + 1).max() if (cf[i] > 0).any() else 0 for i in range(ncol)])
+    assert len(set(tops[:640])) >= 3            # the blocks mix cloud tops (and cloud-free columns)
+    for c0, n in [(c, 1) for c in range(0, 640, 37)] + [(5, 3), (100, 64), (131, 65), (700, 257)]:
+        got = part(c0, n)
+        for k in names:
+            assert np.array_equal(got[k], full[k][c0:c0 + n]), (k, c0, n)
+
+
 def test_cloud_inputs_ignored_when_icld0(hip, oracle):
     """inatm copies cloud arrays only when icld >= 1 (src/rrtmg_lw_rad.nomcica.f90:893-910)."""
     d = make_gcm_inputs(100, 72, "cloudy")
