@@ -2607,18 +2607,24 @@ __device__ __forceinline__ void sweep_stage_band(const DevTables &T, double (*s_
 // waves per SIMD each instantiation is compiled for = what its registers allow without spilling (a spilled register is reloaded with a
 // scratch load, which counts as a vector-memory operation: its wait drains every prefetch in flight), at most 4 (one workgroup of
 // <= 1024 threads per CU: the transmittance table takes half of the LDS).  Register needs, unconstrained, by quads per thread 4 / 3 / 2 / 1:
-//   phase 1                       154 148 102  84
-//   phase 0                       247 171 147 106
-//   phase 2                       256+ 222 172 102
-//   phase 0 with d/dT             250 199 148 105
-//   phase 2 with d/dT             256+ 256+ 241 132
+//   phase 1                       154 148 102  84          (as compiled since the fused multiply-adds are written out: 136 114  91  75)
+//   phase 0                       247 171 147 106          (two waves per band at 4 quads: 112; 140 111  85)
+//   phase 2                       256+ 222 172 102         (145 with two waves per band; 188 143  95)
+//   phase 0 with d/dT             250 199 148 105          (146; 189 144  95)
+//   phase 2 with d/dT             256+ 256+ 241 132        (212; 256 + 44 accumulation registers; 210 126)
+#ifndef RRLW_SWEEPC_P0
+#define RRLW_SWEEPC_P0 6, 4, 3, 2      // (6, 3, 2, 2 until the sweeps' fused multiply-adds were written out: 111 / 140 registers at 2 / 3 quads since; 1e4 clear columns 0.78 -> 0.69 ms)
+#endif
+#ifndef RRLW_SWEEPC_P2D
+#define RRLW_SWEEPC_P2D 3, 2, 1, 1
+#endif
 #ifndef RRLW_SWEEPC_WAVES_CAP
 #define RRLW_SWEEPC_WAVES_CAP 4
 #endif
 __host__ __device__ constexpr int sweepc_waves(int NQ, int PHASE, bool IDRV)
 {
     const int row = PHASE == 1 ? 0 : (PHASE == 0 && !IDRV) ? 1 : (PHASE == 2 && IDRV) ? 3 : 2;
-    const int tab[4][4] = {{7, 5, 4, 3}, {6, 3, 2, 2}, {5, 3, 2, 1}, {3, 2, 1, 1}};      // [row][NQ - 1]
+    const int tab[4][4] = {{7, 5, 4, 3}, {RRLW_SWEEPC_P0}, {5, 3, 2, 1}, {RRLW_SWEEPC_P2D}};      // [row][NQ - 1]
     const int w = tab[row][NQ - 1];
     return w < RRLW_SWEEPC_WAVES_CAP ? w : RRLW_SWEEPC_WAVES_CAP;
 }
