@@ -727,6 +727,8 @@ struct HostIn {
     const uint64_t *known_bits = nullptr;
 };
 struct HostOut { double *h; size_t rows; double *d; bool active; bool pinned = false; };
+int bounce_h2d(void *dst, const void *src, size_t bytes);
+int bounce_d2h(void *dst, const void *src, size_t bytes);
 
 int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
 {
@@ -740,25 +742,30 @@ int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
     return 0;
 }
 
-// the plain form (small one-batch entries: get_alpha, the stand-alone generator)
+// the plain form (small one-batch entries: get_alpha, the stand-alone generator): blocking copies through the library's pinned buffer (bounce_h2d)
 int stage_in(std::vector<HostIn> &ins, size_t ncol, size_t col0, size_t nb, hipStream_t s)
 {
+    HIP_TRY(hipStreamSynchronize(s));                    // (the staging buffer's last readers)
     for (auto &a : ins) {
         if (!a.h) continue;
-        const size_t w = a.inner * nb * 8, sp = a.inner * ncol * 8;
-        HIP_TRY(hipMemcpy2DAsync(a.d, w, a.h + a.inner * col0, sp, w, a.rows, hipMemcpyHostToDevice, s));
+        const size_t w = a.inner * nb * 8;
+        if (nb == ncol) { if (int rc = bounce_h2d(a.d, a.h, w * a.rows)) return rc; continue; }
+        for (size_t r = 0; r < a.rows; r++)
+            if (int rc = bounce_h2d(a.d + a.inner * nb * r, a.h + a.inner * (col0 + ncol * r), w)) return rc;
     }
     return 0;
 }
 
 int stage_out(std::vector<HostOut> &outs, size_t ncol, size_t col0, size_t nb, hipStream_t s)
 {
+    HIP_TRY(hipStreamSynchronize(s));
     for (auto &a : outs) {
         if (!a.active || !a.h) continue;
-        const size_t w = nb * 8, sp = ncol * 8;
-        HIP_TRY(hipMemcpy2DAsync(a.h + col0, sp, a.d, w, w, a.rows, hipMemcpyDeviceToHost, s));
+        const size_t w = nb * 8;
+        if (nb == ncol) { if (int rc = bounce_d2h(a.h, a.d, w * a.rows)) return rc; continue; }
+        for (size_t r = 0; r < a.rows; r++)
+            if (int rc = bounce_d2h(a.h + col0 + ncol * r, a.d + nb * r, w)) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -874,21 +881,24 @@ void rows_below(const double *h, size_t inner, size_t rows, size_t ncol, size_t 
     });
 }
 
-// ranges the caller pinned through rrtmg_lw_hip_host_register; arrays pinned by other means (hipHostMalloc, a framework's pinned
-// allocator) are recognised by the runtime's pointer attributes
+// Ranges pinned through rrtmg_lw_hip_host_register (and the chunk queue's own pinned set): an array lies in one of them with all its bytes,
+// or it is treated as pageable and goes through the pinned staging.  (The runtime's pointer attributes were asked as well, at an array's
+// first and last byte, until tools/soak_host_entry.py found the hole: registrations are page-granular, so an UNREGISTERED array whose two
+// ends share pages with registered neighbours - small arrays side by side on the heap - looked pinned, its middle pages were not mapped for
+// the device, and the direct copy faulted.  An array pinned by other means than this library's call is copied like a pageable one.)
 std::vector<std::pair<const char *, size_t>> g_pinned;
+void forget_pinned(const void *ptr)
+{
+    for (size_t i = 0; i < g_pinned.size(); i++)
+        if (g_pinned[i].first == (const char *)ptr) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
+}
 bool host_range_pinned(const void *p, size_t bytes)
 {
     const char *a = (const char *)p;
     if (!a || bytes == 0) return false;
     for (auto &r : g_pinned)
         if (a >= r.first && a + bytes <= r.first + r.second) return true;
-    for (const char *q : {a, a + bytes - 1}) {
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (at.type != hipMemoryTypeHost) return false;
-    }
-    return true;
+    return false;
 }
 
 int ensure_hostbuf(char **p, size_t *cap, size_t bytes)
@@ -898,6 +908,40 @@ int ensure_hostbuf(char **p, size_t *cap, size_t bytes)
     const size_t want = bytes + bytes / 4 + 4096;
     HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocDefault));
     *cap = want;
+    return 0;
+}
+
+// Blocking copies between the caller's (possibly pageable) memory and the device through this library's own pinned buffer: the runtime is
+// never handed a pageable user pointer.  It would pin the range in place, page-granular, and unpin it afterwards - and the unpinning takes a
+// page shared with a neighbouring array out of the device's page table as well, whether that neighbour is the source of another copy in
+// flight or an array the caller registered (tools/soak_host_entry.py: "Memory access fault" at heap addresses).
+constexpr size_t BOUNCE_BYTES = (size_t)32 << 20;
+int bounce_h2d(void *dst, const void *src, size_t bytes)
+{
+    auto &hs = G.hset[0];
+    if (int rc = ensure_hostbuf(&hs.in, &hs.in_cap, std::min(bytes, BOUNCE_BYTES))) return rc;
+    for (size_t o = 0; o < bytes; o += BOUNCE_BYTES) {
+        const size_t n = std::min(BOUNCE_BYTES, bytes - o);
+        host_parallel(2 * n, [&](int t, int nt) {
+            const size_t a = n * (size_t)t / (size_t)nt, b = n * (size_t)(t + 1) / (size_t)nt;
+            memcpy(hs.in + a, (const char *)src + o + a, b - a);
+        });
+        HIP_TRY(hipMemcpy((char *)dst + o, hs.in, n, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+int bounce_d2h(void *dst, const void *src, size_t bytes)
+{
+    auto &hs = G.hset[0];
+    if (int rc = ensure_hostbuf(&hs.out, &hs.out_cap, std::min(bytes, BOUNCE_BYTES))) return rc;
+    for (size_t o = 0; o < bytes; o += BOUNCE_BYTES) {
+        const size_t n = std::min(BOUNCE_BYTES, bytes - o);
+        HIP_TRY(hipMemcpy(hs.out, (const char *)src + o, n, hipMemcpyDeviceToHost));
+        host_parallel(2 * n, [&](int t, int nt) {
+            const size_t a = n * (size_t)t / (size_t)nt, b = n * (size_t)(t + 1) / (size_t)nt;
+            memcpy((char *)dst + o + a, hs.out + a, b - a);
+        });
+    }
     return 0;
 }
 
@@ -1408,8 +1452,8 @@ static int init_state(const char *static_tables_path, const char *kdata_path, do
     if (G.d_stat) { (void)hipFree(G.d_stat); G.d_stat = nullptr; }
     HIP_TRY(hipMalloc((void **)&G.d_ktab, G.H.ktab.size() * 8));
     HIP_TRY(hipMalloc((void **)&G.d_stat, G.H.stat.size() * 8));
-    HIP_TRY(hipMemcpy(G.d_ktab, G.H.ktab.data(), G.H.ktab.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(G.d_stat, G.H.stat.data(), G.H.stat.size() * 8, hipMemcpyHostToDevice));
+    if (int rc = bounce_h2d(G.d_ktab, G.H.ktab.data(), G.H.ktab.size() * 8)) return rc;          // (never a pageable pointer to the runtime: bounce_h2d)
+    if (int rc = bounce_h2d(G.d_stat, G.H.stat.data(), G.H.stat.size() * 8)) return rc;
     if (!G.d_err) {
         HIP_TRY(hipMalloc((void **)&G.d_err, sizeof(int)));
     }
@@ -1485,7 +1529,7 @@ static void finalize_state()
     if (G.ws_base) (void)hipFree(G.ws_base);
     if (G.stage_base) (void)hipFree(G.stage_base);
     if (first) {            // the queue and the generator's caches live on the first device
-        if (Q.pinned) { (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
+        if (Q.pinned) { forget_pinned(Q.pinned); (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
         Q.chunks.clear(); Q.ncol = 0; Q.open = false;
         if (g_kiss_table.dev) { (void)hipFree(g_kiss_table.dev); g_kiss_table = KissTable{}; }
         for (MtStates &S : g_mt) {
@@ -1844,7 +1888,7 @@ int rrtmg_lw_hip_run_columns(
     hipStream_t s = G.stream;
     for (auto &i : ins) {
         i.d = p; p += i.cnt;
-        HIP_TRY(hipMemcpyAsync(i.d, i.h, i.cnt * 8, hipMemcpyHostToDevice, s));
+        if (int rc = bounce_h2d(i.d, i.h, i.cnt * 8)) return rc;
     }
     double *o[10];
     for (auto &q : o) { q = p; p += n * (L + 1); }
@@ -1859,7 +1903,8 @@ int rrtmg_lw_hip_run_columns(
     FluxOut out{o[0], o[1], o[3], o[4], o[5], o[7], o[8], o[9], o[2], o[6]};
     if (int rc = run_batch<false>(s, ncol, 0, ncol, nlayers, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out)) return rc;
     double *ho[10] = {totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, dtotuflux_dt, dtotuclfl_dt};
-    for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(ho[k], o[k], n * (L + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 10; k++) if (int rc = bounce_d2h(ho[k], o[k], n * (L + 1) * 8)) return rc;
     return read_physics_error(s);
 }
 
@@ -1896,7 +1941,7 @@ int rrtmg_lw_hip_run_columns_mcica(
     hipStream_t s = G.stream;
     for (auto &i : ins) {
         i.d = p; p += i.cnt;
-        HIP_TRY(hipMemcpyAsync(i.d, i.h, i.cnt * 8, hipMemcpyHostToDevice, s));
+        if (int rc = bounce_h2d(i.d, i.h, i.cnt * 8)) return rc;
     }
     double *o[10];
     for (auto &q : o) { q = p; p += n * (L + 1); }
@@ -1911,7 +1956,8 @@ int rrtmg_lw_hip_run_columns_mcica(
     FluxOut out{o[0], o[1], o[3], o[4], o[5], o[7], o[8], o[9], o[2], o[6]};
     if (int rc = run_batch<false>(s, ncol, 0, ncol, nlayers, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, out, &m)) return rc;
     double *ho[10] = {totuflux, totdflux, fnet, htr, totuclfl, totdclfl, fnetc, htrc, dtotuflux_dt, dtotuclfl_dt};
-    for (int k = 0; k < 10; k++) HIP_TRY(hipMemcpyAsync(ho[k], o[k], n * (L + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 10; k++) if (int rc = bounce_d2h(ho[k], o[k], n * (L + 1) * 8)) return rc;
     return read_physics_error(s);
 }
 
@@ -1932,8 +1978,7 @@ int rrtmg_lw_hip_host_unregister(void *ptr)
     ENTRY_LOCK;
     if (!ptr) return fail(RRTMG_LW_HIP_EARG, "null pointer");
     HIP_TRY(hipHostUnregister(ptr));
-    for (size_t i = 0; i < g_pinned.size(); i++)
-        if (g_pinned[i].first == (const char *)ptr) { g_pinned.erase(g_pinned.begin() + (long)i); break; }
+    forget_pinned(ptr);
     return 0;
 }
 
@@ -2054,9 +2099,10 @@ extern "C" int rrtmg_lw_hip_queue_flush(void)
         for (int k = 0; k < 23; k++) tot += in_inner[k] * in_rows[k] * (size_t)N;
         for (int k = 0; k < 8; k++) tot += out_rows[k] * (size_t)N;
         if (Q.pinned_doubles < tot) {
-            if (Q.pinned) { (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
+            if (Q.pinned) { forget_pinned(Q.pinned); (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
             HIP_TRY(hipHostMalloc((void **)&Q.pinned, tot * sizeof(double), hipHostMallocDefault));
             Q.pinned_doubles = tot;
+            g_pinned.emplace_back((const char *)Q.pinned, tot * sizeof(double));
         }
         double *p = Q.pinned;
         for (int k = 0; k < 23; k++) { in_p[k] = p; p += in_inner[k] * in_rows[k] * (size_t)N; }
@@ -2256,8 +2302,8 @@ int rrtmg_lw_hip_mcica_subcol(
     // times the mask - at memory speed (src/mcica_subcol_gen_lw.f90:664-680: where cloudy the layer's water paths and the band's optical
     // depth, elsewhere zero).  (Expanding on the device and copying 322 KB per 72-layer column back ran at 0.03 M columns/s.)
     std::vector<unsigned> hmask((size_t)MASK_WORDS * L * n);
-    HIP_TRY(hipMemcpyAsync(hmask.data(), G.mask, hmask.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (int rc = bounce_d2h(hmask.data(), G.mask, hmask.size() * sizeof(unsigned))) return rc;
     int gband[NGPT];
     for (int ig = 0; ig < NGPT; ig++) { int b = 1; for (int B = 2; B <= NBND; B++) b += (ig >= band_g0(B)) ? 1 : 0; gband[ig] = b - 1; }
     host_parallel((size_t)NGPT * n * L * 8 * 4, [&](int t, int nt) {
@@ -2338,10 +2384,10 @@ int rrtmg_lw_hip_run_mcica_subcol(
     if (cloud) {
         if (!play || !cldfr || (two && !alpha)) return fail(RRTMG_LW_HIP_EARG, "null generator input");
         HIP_TRY(hipMalloc((void **)&d_gen, n * L * 8 * 3));
-        hipError_t e = hipMemcpyAsync(d_gen, play, n * L * 8, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_gen + n * L, cldfr, n * L * 8, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess && two) e = hipMemcpyAsync(d_gen + 2 * n * L, alpha, n * L * 8, hipMemcpyHostToDevice, s);
-        int rc = e == hipSuccess ? 0 : fail(RRTMG_LW_HIP_EHIP, "generator input copy: %s", hipGetErrorString(e));
+        // (through the library's own pinned buffer: see bounce_h2d)
+        int rc = bounce_h2d(d_gen, play, n * L * 8);
+        if (rc == 0) rc = bounce_h2d(d_gen + n * L, cldfr, n * L * 8);
+        if (rc == 0 && two) rc = bounce_h2d(d_gen + 2 * n * L, alpha, n * L * 8);
         if (rc == 0) rc = generate_mask(s, ncol, nlay, icld_gen, permuteseed, *irng, d_gen, d_gen + n * L, two ? d_gen + 2 * n * L : nullptr);
         if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "generator failed");
         (void)hipFree(d_gen);

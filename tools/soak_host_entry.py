@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the host-pointer entry: random column counts, random subsets of the arrays page-locked, back-to-back calls - every result must
 equal, bit for bit, the same columns of one reference call (columns are independent and results do not depend on the batching).
-usage: python tools/soak_host_entry.py [seconds] [max columns]"""
+usage: python tools/soak_host_entry.py [seconds] [max columns] [mcica]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -10,13 +10,15 @@ from rrtmg_lw_amd.synth import make_gcm_inputs
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 nmax = int(sys.argv[2]) if len(sys.argv) > 2 else 70000
+mcica = len(sys.argv) > 3 and sys.argv[3] == "mcica"       # the fused generator + solver entry (kissvec: a column's sub-columns are its own)
 nlay = 60
 api.rrtmg_lw_ini(1004.0, kdata=api.STANDIN_KDATA, device=0)
 rng = np.random.default_rng(1)
 full = make_gcm_inputs(nmax, nlay, "aer_idrv", col0=7)
 for k in ("co2vmr", "o2vmr"):                       # some rows uniform, some not
     full[k] = np.asfortranarray(np.full((nmax, nlay), float(np.asarray(full[k])[0, 0])))
-ref = api.rrtmg_lw_from_dict(full, icld=2)
+solve = (lambda d, out=None: api.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0, icld=2)) if mcica else (lambda d, out=None: api.rrtmg_lw_from_dict(d, icld=2, out=out))
+ref = solve(full)
 names = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")
 t0, calls, cols = time.time(), 0, 0
 while time.time() - t0 < secs:
@@ -33,8 +35,10 @@ while time.time() - t0 < secs:
     for v in pinned:
         api.host_register(v)
     reps = int(rng.integers(1, 4))
+    if os.environ.get("SOAK_VERBOSE"):
+        print(f"call n={n} c0={c0} reps={reps} pinned={[k for k, v in d.items() if any(v is w for w in pinned)]}", flush=True)
     for _ in range(reps):
-        got = api.rrtmg_lw_from_dict(d, icld=2, out=out)
+        got = solve(d, out)
         for k in names:
             if not np.array_equal(got[k], ref[k][c0:c0 + n]):
                 bad = np.argwhere(got[k] != ref[k][c0:c0 + n])
