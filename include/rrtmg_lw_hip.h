@@ -262,6 +262,9 @@ int rrtmg_lw_hip_profile_end(char *buf, int len);
  * copies then run as asynchronous DMA overlapped with the kernels of the neighbouring column batches. */
 int rrtmg_lw_hip_host_register(void *ptr, long long bytes);
 int rrtmg_lw_hip_host_unregister(void *ptr);
+/* 1 when [ptr, ptr + bytes) lies inside a range registered above - the only arrays the entries copy from where they lie; everything else
+ * goes through the library's own pinned staging (an array is NOT pinned because its ends share pages with registered neighbours). */
+int rrtmg_lw_hip_host_is_registered(const void *ptr, long long bytes);
 
 /* PMC calibration: one kernel that reads `bytes` and writes `bytes` with 16 B per lane (known HBM traffic), so that a
  * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can fix the counters' unit and scale in the same session. */

@@ -110,6 +110,11 @@ def host_register(a):
     _check(lib().rrtmg_lw_hip_host_register(C.c_void_p(a.ctypes.data), C.c_longlong(a.nbytes)))
 
 
+def host_is_registered(a):
+    """whether the host-pointer entries would copy the numpy array `a` from where it lies (it is inside a range pinned by host_register)"""
+    return bool(lib().rrtmg_lw_hip_host_is_registered(C.c_void_p(a.ctypes.data), C.c_longlong(a.nbytes)))
+
+
 def host_unregister(a):
     _check(lib().rrtmg_lw_hip_host_unregister(C.c_void_p(a.ctypes.data)))
 

@@ -1973,6 +1973,12 @@ int rrtmg_lw_hip_host_register(void *ptr, long long bytes)
     return 0;
 }
 
+int rrtmg_lw_hip_host_is_registered(const void *ptr, long long bytes)
+{
+    ENTRY_LOCK;
+    return (ptr && bytes > 0 && host_range_pinned(ptr, (size_t)bytes)) ? 1 : 0;
+}
+
 int rrtmg_lw_hip_host_unregister(void *ptr)
 {
     ENTRY_LOCK;

@@ -63,6 +63,39 @@ def test_batching_is_transparent(hip, oracle):
         assert np.array_equal(one[k], many[k]), k
 
 
+def test_arrays_side_by_side_in_memory_some_of_them_pinned(hip, oracle):
+    """Input arrays carved one behind the other from a single allocation, so that neighbours share memory pages, every other one pinned:
+    an array between two pinned neighbours is NOT pinned (the runtime's pointer attributes would say so at both of its ends - registrations
+    are page-granular - and a direct copy from it faulted on its middle pages); results equal the call with separate arrays."""
+    ncol, nlay = 3000, 40
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=13)
+    keys = [k for k, v in d.items() if isinstance(v, np.ndarray) and v.dtype == np.float64]
+    total = sum(d[k].size for k in keys) + len(keys)
+    pool = np.zeros(total + 8)
+    packed, pos = dict(d), 3                                  # (3 doubles in: nothing page-aligned)
+    for k in keys:
+        n = d[k].size
+        view = pool[pos:pos + n].reshape(d[k].shape, order="F")
+        view[...] = d[k]
+        assert view.flags.f_contiguous
+        packed[k] = view
+        pos += n + 1
+    want = hip.rrtmg_lw_from_dict(d)
+    pinned = keys[::2]
+    for k in pinned:
+        hip.host_register(packed[k])
+    try:
+        for k in keys:
+            assert hip.host_is_registered(packed[k]) == (k in pinned), k
+        got = hip.rrtmg_lw_from_dict(packed)
+    finally:
+        for k in pinned:
+            hip.host_unregister(packed[k])
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+        assert np.array_equal(got[k], want[k]), k
+    assert not hip.host_is_registered(packed[pinned[0]])
+
+
 def test_a_column_does_not_depend_on_its_neighbours(hip):
     """A column's results - d(flux)/dT included - are the same, bit for bit, whether it is solved alone, in a block of other columns or in
     the whole call: the hand-off level between the clear-sky and the cloud-zone sweeps follows from the clouds of the 64-column block a
