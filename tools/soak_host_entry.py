@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the host-pointer entry: random column counts, random subsets of the arrays page-locked, back-to-back calls - every result must
 equal, bit for bit, the same columns of one reference call (columns are independent and results do not depend on the batching).
-usage: python tools/soak_host_entry.py [seconds] [max columns] [mcica]"""
+usage: python tools/soak_host_entry.py [seconds] [max columns] [mcica|arrays]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -11,13 +11,21 @@ from rrtmg_lw_amd.synth import make_gcm_inputs
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 nmax = int(sys.argv[2]) if len(sys.argv) > 2 else 70000
 mcica = len(sys.argv) > 3 and sys.argv[3] == "mcica"       # the fused generator + solver entry (kissvec: a column's sub-columns are its own)
+arrays = len(sys.argv) > 3 and sys.argv[3] == "arrays"     # mcica_subcol_lw into host arrays, then rrtmg_lw with the (140, ncol, nlay) sub-column arrays
 nlay = 60
 api.rrtmg_lw_ini(1004.0, kdata=api.STANDIN_KDATA, device=0)
 rng = np.random.default_rng(1)
 full = make_gcm_inputs(nmax, nlay, "aer_idrv", col0=7)
 for k in ("co2vmr", "o2vmr"):                       # some rows uniform, some not
     full[k] = np.asfortranarray(np.full((nmax, nlay), float(np.asarray(full[k])[0, 0])))
-solve = (lambda d, out=None: api.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0, icld=2)) if mcica else (lambda d, out=None: api.rrtmg_lw_from_dict(d, icld=2, out=out))
+def solve_arrays(d, out=None):
+    sub = api.mcica_subcol_lw(d["ncol"], d["nlay"], 2, 140, 0, d["play"], d["cldfr"], d["cicewp"], d["cliqwp"], d["reice"], d["reliq"], d["taucld"])
+    dd = dict(d)
+    dd.update({k: sub[k] for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl", "reicmcl", "relqmcl")})
+    return api.rrtmg_lw_mcica_from_dict(dd, icld=2)
+
+
+solve = (lambda d, out=None: api.rrtmg_lw_mcica_subcol_from_dict(d, 140, 0, icld=2)) if mcica else solve_arrays if arrays else (lambda d, out=None: api.rrtmg_lw_from_dict(d, icld=2, out=out))
 ref = solve(full)
 names = ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")
 t0, calls, cols = time.time(), 0, 0
