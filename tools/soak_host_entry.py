@@ -14,6 +14,8 @@ mcica = len(sys.argv) > 3 and sys.argv[3] == "mcica"       # the fused generator
 arrays = len(sys.argv) > 3 and sys.argv[3] == "arrays"     # mcica_subcol_lw into host arrays, then rrtmg_lw with the (140, ncol, nlay) sub-column arrays
 nlay = 60
 api.rrtmg_lw_ini(1004.0, kdata=api.STANDIN_KDATA, device=0)
+if int(os.environ.get("SOAK_NDEV", "1")) > 1:          # several (virtual) devices on GPU 0: the host entries split their columns over them
+    api.init_devices([0] * int(os.environ["SOAK_NDEV"]), kdata=api.STANDIN_KDATA)
 rng = np.random.default_rng(1)
 full = make_gcm_inputs(nmax, nlay, "aer_idrv", col0=7)
 for k in ("co2vmr", "o2vmr"):                       # some rows uniform, some not
