@@ -1745,11 +1745,13 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
         HIP_TRY(hipHostMalloc((void **)&G.h_tot, HOST_SETS * L * (size_t)nbmax * sizeof(double), hipHostMallocDefault));
         G.h_tot_doubles = HOST_SETS * L * (size_t)nbmax;
     }
-    std::vector<unsigned char> cloudfree(L, 0);
+    std::vector<unsigned char> cloudfree(L, 0), cf_uni(L, 0);
+    std::vector<uint64_t> cf_bits(L, 0);
     auto prep = [&](int k, int col0, int nb, hipStream_t) -> int {
         if (!cloud) return 0;
         // layers without cloud in any column of the batch: the other five cloud arrays are not read there (nor summed, nor scanned, nor copied)
-        rows_below(cldfr, 1, L, (size_t)ncol, (size_t)col0, (size_t)nb, 1.e-20, cloudfree.data());
+        rows_below(cldfr, 1, L, (size_t)ncol, (size_t)col0, (size_t)nb, 1.e-20, cloudfree.data(), cf_uni.data(), cf_bits.data());
+        ins[17].known = cf_uni.data(); ins[17].known_bits = cf_bits.data();        // (those layers of cldfr have just been read to their end)
         for (size_t a = 18; a < ins.size(); a++) ins[a].skip = cloudfree.data();
         if (!use_tot) return 0;
         double *tot = G.h_tot + (size_t)k * L * (size_t)nbmax;        // (the pipeline has waited for the copies that read scratch set k last)
