@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="columns per internal batch (0 = library default)")
     ap.add_argument("--no-overlap", action="store_true", help="serialise k_layer and the sweeps of consecutive batches (the library default)")
     ap.add_argument("--overlap", action="store_true", help="run the sweeps of batch i beside k_layer of batch i+1 (tuning; second scratch set)")
+    ap.add_argument("--cu-partition", type=int, default=-1, metavar="CUS",
+                    help="k_layer of batch i+1 on CUS compute units beside the sweeps of batch i on the others (implies --overlap); 0 = off; -1 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols-per-core", type=int, default=6000)
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the outputs (N > 1)")
@@ -109,6 +111,8 @@ def main():
         api.set_overlap(False)
     if args.overlap:
         api.set_overlap(True)
+    if args.cu_partition >= 0:
+        api.set_cu_partition(args.cu_partition)
 
     # contiguous column block of this rank.  Every rank works on exactly `per` = ceil(ncol / world) columns (the synthetic generator is
     # keyed by the global column index, so the last rank simply continues past --ncol when it does not divide): equal blocks for the

@@ -238,6 +238,12 @@ int rrtmg_lw_hip_set_batch(int ncol_batch);
  * LDS, all vector registers), so the two do not share one (measured: 1-2 % faster on 1e6 cloudy columns).  on = 0 frees the second set at the next workspace
  * allocation. */
 int rrtmg_lw_hip_set_overlap(int on);
+/* CU partition of that overlap: k_layer of batch i+1 runs on `layer_cus` of the device's compute units (rounded to a multiple of 8, the
+ * same number from every XCD: hipExtStreamCreateWithCUMask), the sweeps and k_flux of batch i on the others; the first batch's k_layer and
+ * the last batch's sweeps, which have nothing beside them, take the whole chip.  layer_cus > 0 switches the overlap on; 0 removes the
+ * partition.  Results do not depend on it.  rrtmg_lw_hip_cu_partition() returns the CUs of k_layer's share (0: none). */
+int rrtmg_lw_hip_set_cu_partition(int layer_cus);
+int rrtmg_lw_hip_cu_partition(void);
 /* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (about 0.2 MB per column of the batch
  * at 72 layers, 0.37 MB at 137: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer
  * (<= 512 MB, or one slab) and the cached chunk states (<= 2 x 180 MB) of the Mersenne-Twister stream. */

@@ -142,6 +142,15 @@ def set_overlap(on):
     _check(lib().rrtmg_lw_hip_set_overlap(C.c_int(1 if on else 0)))
 
 
+def set_cu_partition(layer_cus):
+    """k_layer of batch i+1 on `layer_cus` CUs beside the sweeps of batch i on the others (rrtmg_lw_hip_set_cu_partition); 0 = off"""
+    _check(lib().rrtmg_lw_hip_set_cu_partition(C.c_int(int(layer_cus))))
+
+
+def cu_partition():
+    return int(lib().rrtmg_lw_hip_cu_partition())
+
+
 def _f(a, shape):
     a = np.asfortranarray(a, dtype=np.float64)
     if tuple(a.shape) != tuple(shape):

@@ -52,9 +52,15 @@ struct State {
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
-    hipStream_t aux = nullptr, sw = nullptr;
-    hipStream_t swq[3] = {nullptr, nullptr, nullptr};     // the sweep launches of the 3-, 2- and 1-quad bands run beside the 4-quad launch
-    hipEvent_t ev_swq_go = nullptr, ev_swq_done[3] = {nullptr, nullptr, nullptr};
+    hipStream_t aux = nullptr;
+    // streams of the sweep launches: `main` (the split pipeline's sweep stream) and q[0..2], on which the launches of the 3-, 2- and 1-quad
+    // bands run beside the 4-quad launch.  Set 0 may use the whole chip; set 1 exists with a CU partition (rrtmg_lw_hip_set_cu_partition)
+    // and is confined to the sweeps' share of the CUs.
+    struct SweepSet { hipStream_t main = nullptr, q[3] = {nullptr, nullptr, nullptr}; hipEvent_t go = nullptr, done[3] = {nullptr, nullptr, nullptr}; } swset[2];
+    // k_layer's streams of the partitioned pipeline: lay_u the whole chip (first batch of a call: nothing runs beside it), lay_m its share
+    hipStream_t lay_u = nullptr, lay_m = nullptr;
+    int cu_layer = 0;            // CUs of k_layer's share (0: no partition), set by rrtmg_lw_hip_set_cu_partition
+    int cu_total = 0;
     bool sweep_fanout = true;
     hipEvent_t ev_last = nullptr;           // end of the previous device-entry call (calls on different streams share the workspace)
     bool ev_last_valid = false;
@@ -370,6 +376,40 @@ Workspace ws_for(int k)
     return w;
 }
 
+// A stream confined to the CUs [lo, hi) of the device's CU-mask order (hipExtStreamCreateWithCUMask; on a multi-XCD device consecutive
+// mask bits go round the XCDs, so a run of bits that is a multiple of 8 long takes the same number of CUs from every XCD), or - lo = hi -
+// an ordinary non-blocking stream.
+int make_stream(hipStream_t *st, int lo, int hi)
+{
+    if (hi <= lo) { HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return 0; }
+    uint32_t mask[32] = {};
+    const int nw = (G.cu_total + 31) / 32;
+    for (int b = lo; b < hi && b < 1024; b++) mask[b >> 5] |= 1u << (b & 31);
+    HIP_TRY(hipExtStreamCreateWithCUMask(st, (uint32_t)nw, mask));
+    return 0;
+}
+int ensure_sweep_set(int k)
+{
+    State::SweepSet &SS = G.swset[k];
+    if (SS.q[0]) return 0;
+    const int lo = k == 1 ? G.cu_layer : 0, hi = k == 1 ? G.cu_total : 0;
+    if (!SS.main) { if (int rc = make_stream(&SS.main, lo, hi)) return rc; }
+    for (int j = 0; j < 3; j++) {
+        if (int rc = make_stream(&SS.q[j], lo, hi)) return rc;
+        HIP_TRY(hipEventCreateWithFlags(&SS.done[j], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&SS.go, hipEventDisableTiming));
+    return 0;
+}
+void drop_sweep_set(int k)
+{
+    State::SweepSet &SS = G.swset[k];
+    if (SS.main) (void)hipStreamDestroy(SS.main);
+    for (int j = 0; j < 3; j++) { if (SS.q[j]) (void)hipStreamDestroy(SS.q[j]); if (SS.done[j]) (void)hipEventDestroy(SS.done[j]); }
+    if (SS.go) (void)hipEventDestroy(SS.go);
+    SS = State::SweepSet{};
+}
+
 // per-column part of one batch: k_colprep (+ k_cloudscan / k_cloudlay for rtrn / rtrnmr): it runs on the
 // auxiliary stream one batch ahead of the heavy kernels (run_pipelined).
 template <bool GCM>
@@ -433,7 +473,7 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 // vertical part of one batch: the sweep launches and k_flux
 template <bool GCM>
 int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
-              const GcmIn &g, const ColIn &c, const FluxOut &out, const McIn *mc = nullptr)
+              const GcmIn &g, const ColIn &c, const FluxOut &out, const McIn *mc = nullptr, int sset = 0)
 {
     const dim3 block(BLOCK);
     if (int rc = ensure_sweep_attrs()) return rc;
@@ -444,16 +484,11 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #define RRLW_FANOUT_MAX 0x7fffffff     // (round 3: for every batch size - 61.4 -> 60.2 ms per 1e6 cloudy columns, three runs each; deep clouds 87.7 -> 85.7.
 #endif                                 // The HIP-event times of the sweep kernels then overlap: their sum exceeds the wall time they take together)
     const bool fan = G.sweep_fanout && nb < RRLW_FANOUT_MAX;
-    if (fan && !G.swq[0]) {
-        for (int k = 0; k < 3; k++) {
-            HIP_TRY(hipStreamCreateWithFlags(&G.swq[k], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&G.ev_swq_done[k], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&G.ev_swq_go, hipEventDisableTiming));
-    }
+    State::SweepSet &SS = G.swset[sset];
     if (fan) {
-        HIP_TRY(hipEventRecord(G.ev_swq_go, s));
-        for (int k = 0; k < 3; k++) HIP_TRY(hipStreamWaitEvent(G.swq[k], G.ev_swq_go, 0));
+        if (int rc = ensure_sweep_set(sset)) return rc;
+        HIP_TRY(hipEventRecord(SS.go, s));
+        for (int k = 0; k < 3; k++) HIP_TRY(hipStreamWaitEvent(SS.q[k], SS.go, 0));
     }
     const hipStream_t s_main = s;
 #ifndef RRLW_TUNE
@@ -524,7 +559,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
                 sa.bands = fg.bands[g];
                 sa.nbands = fg.nb[g];
                 sa.group = g;
-                const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;
+                const hipStream_t s = (fan && nq < 4) ? SS.q[3 - nq] : s_main;
 #define SWEEPZ_I(Q, M, I)                                                                                            \
     do {                                                                                                             \
         constexpr int nt = sweepz_nt(Q);                                                                             \
@@ -553,7 +588,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             sa.bands = fg.bands[g];
             sa.nbands = fg.nb[g];
             sa.group = g;
-            const hipStream_t s = (fan && nq < 4) ? G.swq[3 - nq] : s_main;
+            const hipStream_t s = (fan && nq < 4) ? SS.q[3 - nq] : s_main;
 #ifdef RRLW_TUNE
             if (mode == 0) return fail(RRTMG_LW_HIP_EARG, "tuning build: cloudy calls only");
 #else
@@ -568,8 +603,8 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #undef SWEEPC_I
     if (fan) {
         for (int k = 0; k < 3; k++) {
-            HIP_TRY(hipEventRecord(G.ev_swq_done[k], G.swq[k]));
-            HIP_TRY(hipStreamWaitEvent(s_main, G.ev_swq_done[k], 0));
+            HIP_TRY(hipEventRecord(SS.done[k], SS.q[k]));
+            HIP_TRY(hipStreamWaitEvent(s_main, SS.done[k], 0));
         }
     }
     {
@@ -597,7 +632,6 @@ int ensure_pipeline()
 {
     if (G.aux) return 0;
     HIP_TRY(hipStreamCreateWithFlags(&G.aux, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&G.sw, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&G.ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&G.ev_last, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
@@ -631,6 +665,11 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
     ColIn c{};
     // sub-column arrays mode keeps per-g-point cloud arrays (odg/cfef) in one set only: no layer/sweep overlap there
     const bool split = G.split_sweep && G.ws_two_scr && !(mode == 3 && mc);
+    const bool part = split && G.cu_layer > 0;
+    if (part && !G.lay_m) {
+        if (int rc = make_stream(&G.lay_u, 0, 0)) return rc;
+        if (int rc = make_stream(&G.lay_m, 0, G.cu_layer)) return rc;
+    }
     if (G.ev_last_valid) HIP_TRY(hipStreamWaitEvent(s, G.ev_last, 0));      // an earlier call, possibly on another stream, still owns the workspace
     HIP_TRY(hipEventRecord(G.ev_in, s));                 // inputs are ready when the caller's stream gets here
     HIP_TRY(hipStreamWaitEvent(aux, G.ev_in, 0));
@@ -650,16 +689,33 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
             if (int rc = launch_kiss(aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha})) return rc;
         }
         HIP_TRY(hipEventRecord(G.ev_ready[k], aux));
-        HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
+        // (with a CU partition nothing is enqueued on the caller's stream inside the loop: streams with a CU mask are blocking streams, and
+        // where the caller's stream is the null stream every operation on it would be a barrier between them)
+        if (!part) HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
         if (split) {
-            // k_layer of this batch on the caller's stream, its sweep on `sw`: the HBM-bound sweep of batch i overlaps the
-            // latency-bound k_layer of batch i+1 (scratch set k is free once the sweep of batch i-2 is done)
-            if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, G.ev_done[k], 0));
-            if (int rc = run_layer<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc)) return rc;
-            HIP_TRY(hipEventRecord(G.ev_layer[k], s));
-            HIP_TRY(hipStreamWaitEvent(G.sw, G.ev_layer[k], 0));
-            if (int rc = run_sweep<true>(G.sw, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc)) return rc;
-            HIP_TRY(hipEventRecord(G.ev_done[k], G.sw));
+            // k_layer of this batch on the caller's stream, its sweep on the sweep set's main stream: the HBM-bound sweep of batch i
+            // overlaps the issue-bound k_layer of batch i+1 (scratch set k is free once the sweep of batch i-2 is done).
+            // With a CU partition (rrtmg_lw_hip_set_cu_partition) the two run on their own CUs: k_layer's workgroups otherwise take every
+            // register and LDS slot of whichever CU they reach first and the sweep workgroups (one per CU: the transmittance table) trickle
+            // in behind them.  The first batch's k_layer and the last batch's sweeps have nothing beside them and take the whole chip.
+            const bool last = col0 + nbmax >= ncol;
+            hipStream_t sl = s;
+            int sset = 0;
+            if (part) { sl = i == 0 ? G.lay_u : G.lay_m; sset = last ? 0 : 1; }
+            if (int rc = ensure_sweep_set(sset)) return rc;
+            const hipStream_t ssm = G.swset[sset].main;
+            if (part) {
+                if (i == 0) HIP_TRY(hipStreamWaitEvent(sl, G.ev_in, 0));
+                HIP_TRY(hipStreamWaitEvent(sl, G.ev_ready[k], 0));
+                if (i >= 1) HIP_TRY(hipStreamWaitEvent(sl, G.ev_layer[(i - 1) & 1], 0));     // (k_layer launches stay in batch order across the two streams)
+            }
+            if (i >= 2) HIP_TRY(hipStreamWaitEvent(sl, G.ev_done[k], 0));
+            if (int rc = run_layer<true>(sl, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc)) return rc;
+            HIP_TRY(hipEventRecord(G.ev_layer[k], sl));
+            HIP_TRY(hipStreamWaitEvent(ssm, G.ev_layer[k], 0));
+            if (part && i >= 1) HIP_TRY(hipStreamWaitEvent(ssm, G.ev_done[(i - 1) & 1], 0));   // (the partial slabs and the hand-off array exist once: sweeps stay in batch order across the two sets)
+            if (int rc = run_sweep<true>(ssm, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc, sset)) return rc;
+            HIP_TRY(hipEventRecord(G.ev_done[k], ssm));
         } else {
             if (int rc = run_layer<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc)) return rc;
 #if RRLW_GEN_BESIDE_SWEEP
@@ -1459,6 +1515,7 @@ static int init_state(const char *static_tables_path, const char *kdata_path, do
     }
     HIP_TRY(hipMemset(G.d_err, 0, sizeof(int)));
     if (!G.stream) HIP_TRY(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+    HIP_TRY(hipDeviceGetAttribute(&G.cu_total, hipDeviceAttributeMultiprocessorCount, device));
     DevTables &D = G.D;
     D.ktab = G.d_ktab;
     D.stat = G.d_stat;
@@ -1551,15 +1608,14 @@ static void finalize_state()
     }
     if (G.aux) {
         (void)hipStreamDestroy(G.aux);
-        (void)hipStreamDestroy(G.sw);
         (void)hipEventDestroy(G.ev_in);
         (void)hipEventDestroy(G.ev_last);
         for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_ready[k]); (void)hipEventDestroy(G.ev_layer[k]); (void)hipEventDestroy(G.ev_done[k]); }
     }
-    if (G.swq[0]) {
-        for (int k = 0; k < 3; k++) { (void)hipStreamDestroy(G.swq[k]); (void)hipEventDestroy(G.ev_swq_done[k]); }
-        (void)hipEventDestroy(G.ev_swq_go);
-    }
+    drop_sweep_set(0);
+    drop_sweep_set(1);
+    if (G.lay_u) (void)hipStreamDestroy(G.lay_u);
+    if (G.lay_m) (void)hipStreamDestroy(G.lay_m);
     if (G.h_tot) (void)hipHostFree(G.h_tot);
     for (auto &hs : G.hset) {
         if (hs.in) (void)hipHostFree(hs.in);
@@ -1598,6 +1654,37 @@ int rrtmg_lw_hip_set_overlap(int on)
     for (int d = 0; d < MAXDEV; d++) g_states[d].split_sweep = on != 0;       // the second scratch set is allocated by the next call that needs it
     return 0;
 }
+
+// CU partition of the overlapped pipeline (device-pointer entries): k_layer of batch i + 1 on `layer_cus` CUs (rounded to a multiple of 8:
+// the same number from every XCD), the sweeps and k_flux of batch i on the others; 0 = no partition.  A value > 0 switches the overlap on.
+int rrtmg_lw_hip_set_cu_partition(int layer_cus)
+{
+    ENTRY_LOCK;
+    if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
+    State *const keep = g_cur;
+    int rc = 0;
+    for (int d = 0; d < g_ndev && rc == 0; d++) {
+        g_cur = &g_states[d];
+        (void)hipSetDevice(G.device);
+        (void)hipDeviceSynchronize();
+        int n = layer_cus <= 0 ? 0 : std::max(8, std::min(G.cu_total - 8, (layer_cus + 4) / 8 * 8));
+        if (G.cu_total < 16) n = 0;
+        drop_sweep_set(1);
+        if (G.lay_u) { (void)hipStreamDestroy(G.lay_u); G.lay_u = nullptr; }
+        if (G.lay_m) { (void)hipStreamDestroy(G.lay_m); G.lay_m = nullptr; }
+        G.cu_layer = n;
+        if (n > 0) {
+            G.split_sweep = true;
+            // (created here so that a refusal of CU masks by the runtime is reported by this call)
+            if ((rc = make_stream(&G.lay_u, 0, 0)) == 0 && (rc = make_stream(&G.lay_m, 0, n)) == 0) rc = ensure_sweep_set(1);
+            if (rc != 0 && d > 0) g_states[0].err = G.err;
+        }
+    }
+    g_cur = keep;
+    (void)hipSetDevice(G.device);
+    return rc;
+}
+int rrtmg_lw_hip_cu_partition(void) { return g_states[0].cu_layer; }
 
 // measurement only (tools/n1_expf_measure.sh, the prototype's GPU test): cloud-free GCM calls take k_n1 instead of the production sweeps.
 // An explicit call, not an environment variable: a stray variable in a job's environment must not change the numerical path.
