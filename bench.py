@@ -333,8 +333,9 @@ def main():
                 try:
                     ent = json.load(open(pc)).get(key)
                     if ent:
-                        valu = ent["valu_wave_instr_per_column"] * 64.0 * ncol * args.steps / (ktot * 1e-3)
-                        ldsb = ent["lds_bytes_per_column"] * ncol * args.steps / (ktot * 1e-3)
+                        # (over the path's time, as `roofline`: the summed HIP-event times overlap since the sweeps run on four streams)
+                        valu = ent["valu_wave_instr_per_column"] * 64.0 * ncol * args.steps / (tpath * 1e-3)
+                        ldsb = ent["lds_bytes_per_column"] * ncol * args.steps / (tpath * 1e-3)
                         compute = dict(valu_lane_instr_per_s=round(valu, 1), valu_peak=VALU_PEAK_LANE_INSTR, valu_frac=round(valu / VALU_PEAK_LANE_INSTR, 4),
                                        valu_frac_of_f64_rate=round(valu / (VALU_PEAK_LANE_INSTR / 2), 4),
                                        lds_bytes_per_s=round(ldsb, 1), lds_peak=LDS_PEAK_BYTES, lds_frac=round(ldsb / LDS_PEAK_BYTES, 4),

@@ -162,6 +162,13 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
+def _out_ok(a, shape, name):
+    """an array the library writes into in place: float64, Fortran-contiguous, writeable, exactly the interface's shape"""
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.f_contiguous and a.flags.writeable and tuple(a.shape) == tuple(shape)):
+        raise ValueError(f"output array {name!r} must be a writeable float64 Fortran-ordered array of shape {tuple(shape)}")
+    return a
+
+
 def rrtmg_lw(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr,
              cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp,
              cliqwp, reice, reliq, tauaer, out=None):
@@ -175,6 +182,11 @@ def rrtmg_lw(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr
            _f(reice, (ncol, nlay)), _f(reliq, (ncol, nlay)), _f(tauaer, (ncol, nlay, NBND))]
     if out is None:
         out = _out_arrays(ncol, nlay, idrv)
+    else:
+        for k in ("uflx", "dflx", "uflxc", "dflxc") + (("duflx_dt", "duflxc_dt") if idrv == 1 else ()):
+            _out_ok(out[k], (ncol, nlay + 1), k)
+        for k in ("hr", "hrc"):
+            _out_ok(out[k], (ncol, nlay), k)
     icld_c = C.c_int(int(icld))
     null = C.cast(None, _dp)
     args = [C.c_int(ncol), C.c_int(nlay), C.byref(icld_c), C.c_int(int(idrv))]
@@ -351,8 +363,11 @@ def mcica_subcol_lw(ncol, nlay, icld, permuteseed, irng, play, cldfrac, ciwp, cl
     z3 = lambda: np.zeros((ng, ncol, nlay), order="F")
     z2 = lambda: np.zeros((ncol, nlay), order="F")
     o = out if out is not None else dict(cldfmcl=z3(), ciwpmcl=z3(), clwpmcl=z3(), reicmcl=z2(), relqmcl=z2(), taucmcl=z3())
-    for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl"):
-        _f(o[k], (ng, ncol, nlay))
+    # the C entry writes through these pointers: every output must BE a float64 Fortran-ordered array of the declared shape (_f would
+    # silently hand a converted copy to nobody)
+    for k, shape in (("cldfmcl", (ng, ncol, nlay)), ("ciwpmcl", (ng, ncol, nlay)), ("clwpmcl", (ng, ncol, nlay)), ("taucmcl", (ng, ncol, nlay)),
+                     ("reicmcl", (ncol, nlay)), ("relqmcl", (ncol, nlay))):
+        _out_ok(o[k], shape, k)
     irng_c = C.c_int(int(irng))
     ins = [_f(play, (ncol, nlay)), _f(cldfrac, (ncol, nlay)), _f(ciwp, (ncol, nlay)), _f(clwp, (ncol, nlay)),
            _f(rei, (ncol, nlay)), _f(rel, (ncol, nlay)), _f(tauc, (NBND, ncol, nlay))]

@@ -1051,7 +1051,7 @@ int stage_rows(std::vector<HostIn> &ins, size_t nb, int k, hipStream_t s)
             size_t i = 0;
             for (; i + 64 <= n && acc == 0; i += 64)
                 for (size_t e = 0; e < 64; e++) acc |= p[i + e] ^ v;
-            for (; i < n; i++) acc |= p[i] ^ v;
+            for (; i < n && acc == 0; i++) acc |= p[i] ^ v;
             q.uniform = acc == 0;
             q.bits = v;
         }
@@ -1107,8 +1107,25 @@ struct StageClock {
     void lap(int k) { auto n = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double, std::milli>(n - last).count(); last = n; }
 };
 struct NoPrep { int operator()(int, int, int, hipStream_t) const { return 0; } };
+template <class Body, class Prep>
+int host_pipeline_run(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body, Prep prep, std::vector<hipEvent_t> &tev);
 template <class Body, class Prep = NoPrep>
 int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body, Prep prep = Prep())
+{
+    std::vector<hipEvent_t> tev;             // (timing) per batch: H2D begin / end, kernels begin / end
+    const int rc = host_pipeline_run(ncol, c0, c1, nbmax, ins, outs, body, prep, tev);
+    if (rc != 0) {
+        // An error part-way leaves up to HOST_SETS batches of DMAs and kernels in flight, some of them to and from the caller's registered
+        // arrays: nothing of this call may still be running when the caller gets its error (and frees or unregisters them).
+        if (G.cp_in) (void)hipStreamSynchronize(G.cp_in);
+        if (G.stream) (void)hipStreamSynchronize(G.stream);
+        if (G.cp_out) (void)hipStreamSynchronize(G.cp_out);
+    }
+    for (auto e : tev) (void)hipEventDestroy(e);
+    return rc;
+}
+template <class Body, class Prep>
+int host_pipeline_run(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins, std::vector<HostOut> &outs, Body body, Prep prep, std::vector<hipEvent_t> &tev)
 {   // columns [c0, c1) of arrays that are ncol columns wide
     if (int rc = ensure_copy_streams()) return rc;
     size_t set = 0, nrows = 0, out_pageable = 0;
@@ -1184,7 +1201,6 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
         return 0;
     };
     StageClock clk;
-    std::vector<hipEvent_t> tev;             // (timing) per batch: H2D begin / end, kernels begin / end
     auto tmark = [&](hipStream_t st) { if (!g_stage_timing) return; hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st); tev.push_back(e); };
     const auto t_call = std::chrono::steady_clock::now();
     int i = 0, prev_col0 = 0, prev_nb = 0;
@@ -1239,7 +1255,6 @@ int host_pipeline(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &ins,
             (void)hipEventElapsedTime(&b, tev[e + 2], tev[e + 3]);
             h2d += a; ker += b;
         }
-        for (auto e : tev) (void)hipEventDestroy(e);
         const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
         fprintf(stderr, "[rrtmg_lw_hip stage] %d columns in %d batches of <= %d: wall %.2f ms | host: wait-h2d %.2f unpack(+wait d2h) %.2f prep %.2f scan+pack+enqueue %.2f "
                         "body-enqueue %.2f copy_out-enqueue %.2f drain %.2f | device: H2D stream busy %.2f kernels %.2f\n",
@@ -1503,6 +1518,7 @@ static int init_state(const char *static_tables_path, const char *kdata_path, do
     std::string err;
     if (!build_tables(static_tables_path, kdata_path, cpdair, G.H, err)) return fail(RRTMG_LW_HIP_EDATA, "%s", err.c_str());
     HIP_TRY(hipSetDevice(device));
+    G.device = device;                  // (from here on the state owns resources on this device: finalize_state releases them there)
     G.sweep_attrs = false;
     if (G.d_ktab) { (void)hipFree(G.d_ktab); G.d_ktab = nullptr; }
     if (G.d_stat) { (void)hipFree(G.d_stat); G.d_stat = nullptr; }
@@ -1551,16 +1567,24 @@ int rrtmg_lw_hip_init_devices(const char *static_tables_path, const char *kdata_
     std::lock_guard<std::mutex> lk(g_mu);
     g_cur = &g_states[0];
     if (ndev < 1 || ndev > MAXDEV || !devices) return fail(RRTMG_LW_HIP_EARG, "ndev must be 1..%d", MAXDEV);
-    for (int d = ndev; d < g_ndev; d++) { g_cur = &g_states[d]; finalize_state(); }      // states of an earlier, larger set
-    g_cur = &g_states[0];
-    int rc = 0;
+    int rc = 0, done = 0;
+    std::string err;
     for (int d = 0; d < ndev && rc == 0; d++) {
         g_cur = &g_states[d];
         rc = init_state(static_tables_path, kdata_path, cpdair, devices[d]);
-        if (rc != 0 && d > 0) g_states[0].err = G.err;
+        if (rc != 0) err = G.err; else done = d + 1;
+    }
+    if (rc == 0) {
+        for (int d = ndev; d < g_ndev; d++) { g_cur = &g_states[d]; finalize_state(); }      // the surplus states of an earlier, larger set: dropped once the new set stands
+        g_ndev = ndev;
+    } else {
+        // nothing half-initialised stays behind: every state this call touched is released (the failed one may hold tables), as are the
+        // states of the earlier set - a failed init leaves the library uninitialised, and says so
+        for (int d = std::max(g_ndev, done + 1) - 1; d >= 0; d--) { g_cur = &g_states[d]; G.init = G.init || G.d_ktab || G.d_stat || G.d_err || G.stream; finalize_state(); }
+        g_ndev = 1;
+        g_states[0].err = err;
     }
     g_cur = &g_states[0];
-    if (rc == 0) g_ndev = ndev;
     (void)hipSetDevice(g_states[0].device >= 0 ? g_states[0].device : 0);
     return rc;
 }

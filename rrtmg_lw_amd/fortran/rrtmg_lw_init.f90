@@ -100,16 +100,32 @@
 !  Optional, for a host model whose profile / flux arrays live for the whole run: page-lock an array once (after rrtmg_lw_ini), and
 !  rrtmg_lw's copies of it are direct DMA - no packing through the library's pinned staging by host threads.
 !      call rrtmg_lw_pin(play, size(play))   ...   call rrtmg_lw_unpin(play)      (before the array is deallocated)
-!  `a` is any contiguous real(rb) array (sequence association), `n` its number of elements.
+!  `a` is a whole, contiguous real(rb) array of any rank (assumed rank: the dummy is the caller's array itself, never a compiler-made
+!  copy - a section or an expression would be registered at the address of a temporary that is gone on return), `n` its number of
+!  elements (optional check).  A non-contiguous actual stops the run with a message instead of pinning the wrong memory.
       subroutine rrtmg_lw_pin(a, n)
-      real(kind=rb), intent(in), target :: a(*)
-      integer, intent(in) :: n
-      if (n < 1) return
-      if (rrtmg_lw_hip_host_register(c_loc(a), int(n, c_long_long) * 8_c_long_long) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_pin')
+      real(kind=rb), intent(in), target :: a(..)
+      integer, intent(in), optional :: n
+      if (size(a) < 1) return
+      if (.not. is_contiguous(a)) then
+         write(*,*) 'rrtmg_lw_pin: the array is not contiguous (pass the whole array, not a section)'
+         error stop 1
+      endif
+      if (present(n)) then
+         if (n /= size(a)) then
+            write(*,*) 'rrtmg_lw_pin: n differs from the size of the array'
+            error stop 1
+         endif
+      endif
+      if (rrtmg_lw_hip_host_register(c_loc(a), int(size(a), c_long_long) * 8_c_long_long) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_pin')
       end subroutine rrtmg_lw_pin
 
       subroutine rrtmg_lw_unpin(a)
-      real(kind=rb), intent(in), target :: a(*)
+      real(kind=rb), intent(in), target :: a(..)
+      if (.not. is_contiguous(a)) then
+         write(*,*) 'rrtmg_lw_unpin: the array is not contiguous (pass the whole array that was pinned)'
+         error stop 1
+      endif
       if (rrtmg_lw_hip_host_unregister(c_loc(a)) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_unpin')
       end subroutine rrtmg_lw_unpin
 

@@ -69,18 +69,33 @@
       integer(c_int) :: rc, icld_c
       real(c_double), allocatable, target :: d1(:,:), d2(:,:)
       type(c_ptr) :: p1, p2
+      logical :: inplace
 
       icld_c = int(icld, c_int)
       p1 = c_null_ptr
       p2 = c_null_ptr
+      inplace = .false.
       if (idrv == 1) then
          if (.not. (present(duflx_dt) .and. present(duflxc_dt))) then
             write(*,*) 'rrtmg_lw: idrv = 1 requires duflx_dt and duflxc_dt'
             error stop 1
          endif
-         allocate(d1(ncol, nlay+1), d2(ncol, nlay+1))
-         p1 = c_loc(d1)
-         p2 = c_loc(d2)
+         ! exactly sized, contiguous actuals go across in place like every other array (and stay page-locked if the host pinned them:
+         ! rrtmg_lw_pin); an optional dummy cannot be passed as a section, so anything else goes through a temporary
+         inplace = size(duflx_dt,1) == ncol .and. size(duflx_dt,2) == nlay+1 .and. is_contiguous(duflx_dt) .and. &
+                   size(duflxc_dt,1) == ncol .and. size(duflxc_dt,2) == nlay+1 .and. is_contiguous(duflxc_dt)
+         if (inplace) then
+            p1 = c_loc(duflx_dt)
+            p2 = c_loc(duflxc_dt)
+         else
+            if (size(duflx_dt,1) < ncol .or. size(duflx_dt,2) < nlay+1 .or. size(duflxc_dt,1) < ncol .or. size(duflxc_dt,2) < nlay+1) then
+               write(*,*) 'rrtmg_lw: duflx_dt / duflxc_dt smaller than (ncol, nlay+1)'
+               error stop 1
+            endif
+            allocate(d1(ncol, nlay+1), d2(ncol, nlay+1))
+            p1 = c_loc(d1)
+            p2 = c_loc(d2)
+         endif
       endif
       ! The reference indexes play(iplon,lay) etc. (src/rrtmg_lw_rad.nomcica.f90:785-910), so a host may pass arrays that are
       ! larger than (ncol,nlay) - e.g. dimensioned (pcols,pver) with ncol < pcols - or strided sections.  The C side strides by
@@ -104,7 +119,7 @@
             uflxc(1:ncol,1:nlay+1), dflxc(1:ncol,1:nlay+1), hrc(1:ncol,1:nlay), p1, p2)
       if (rc /= 0) call rrtmg_lw_hip_abort('rrtmg_lw')
       icld = int(icld_c, im)
-      if (idrv == 1) then
+      if (idrv == 1 .and. .not. inplace) then
          duflx_dt(1:ncol, 1:nlay+1) = d1
          duflxc_dt(1:ncol, 1:nlay+1) = d2
       endif

@@ -56,3 +56,28 @@ def test_product_does_not_import_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".f90", ".h")):
                 assert not bad.search(open(os.path.join(dp, f), errors="ignore").read()), (dp, f)
+
+
+def test_output_arrays_are_checked_not_converted():
+    """An array the C entries write through must be float64, Fortran-ordered and exactly shaped: a float32 / C-ordered / sliced array is
+    refused before any pointer leaves Python (np.asfortranarray on an OUTPUT hands a converted copy to nobody)."""
+    import numpy as np
+    from rrtmg_lw_amd import api
+    ncol, nlay, ng = 6, 5, api.gpoints()
+    ok = np.zeros((ng, ncol, nlay), order="F")
+    assert api._out_ok(ok, (ng, ncol, nlay), "x") is ok
+    for bad in (np.zeros((ng, ncol, nlay), order="C"), np.zeros((ng, ncol, nlay), dtype=np.float32, order="F"),
+                np.zeros((ng, ncol + 1, nlay), order="F"), np.zeros((ng, 2 * ncol, nlay), order="F")[:, ::2, :], [[0.0]]):
+        with pytest.raises(ValueError, match="output array"):
+            api._out_ok(bad, (ng, ncol, nlay), "x")
+    z2 = lambda: np.zeros((ncol, nlay), order="F")
+    out = dict(cldfmcl=ok, ciwpmcl=ok.copy(order="F"), clwpmcl=ok.copy(order="F"), taucmcl=ok.copy(order="F"), reicmcl=z2(),
+               relqmcl=np.zeros((ncol, nlay), dtype=np.float32, order="F"))
+    with pytest.raises(ValueError, match="relqmcl"):
+        api.mcica_subcol_lw(ncol, nlay, 2, 1, 0, z2(), z2(), z2(), z2(), z2(), z2(), np.zeros((16, ncol, nlay), order="F"), out=out)
+    o = {k: np.zeros((ncol, nlay + 1), order="F") for k in ("uflx", "dflx", "uflxc", "dflxc")}
+    o["hr"] = np.zeros((ncol, nlay), order="C")
+    o["hrc"] = z2()
+    from rrtmg_lw_amd.synth import make_gcm_inputs
+    with pytest.raises(ValueError, match="'hr'"):
+        api.rrtmg_lw_from_dict(make_gcm_inputs(ncol, nlay, "clear"), out=o)

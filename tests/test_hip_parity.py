@@ -306,34 +306,40 @@ def test_special_cloud_configurations(hip, oracle, kind, icld):
     d = _special_cloud_inputs(ncol, nlay, kind)
     got = hip.rrtmg_lw_from_dict(d, icld=icld)
     ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
-    if kind == "toplayer":
-        # An (unphysical) water cloud in the 0.03 hPa thick top layer: the heating rate of that layer is the flux divergence times
-        # 8.4 / dp[hPa] = 280 K d-1 per W m-2, so the float32 transmittance of the cloud (7e-6 W m-2 in the fluxes, inside the bar like
-        # everywhere else) shows as 2e-3 K d-1 there - 1e-5 of the layer's own heating rate.  Fluxes at the usual bar, rates relative.
-        dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
-        rel = max((np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1.0)).max() for k in ("hr", "hrc"))
-        print(f"{kind} icld={icld}: max|dflux|={dflux:.3e} W/m2  max relative dhr={rel:.3e}")
-        assert dflux <= TIGHT_FLUX and rel <= 1e-4
-        assert np.abs(got["hr"][:, :-1] - ref["hr"][:, :-1]).max() <= TIGHT_HR          # every layer below the top one: the usual bar
+    if kind == "toplayer":        # an (unphysical) water cloud in the 0.011 hPa thick top layer: own rate 5e4 K d-1
+        _compare_thin_layers(got, ref, d, d["idrv"], f"{kind} icld={icld}")
     else:
         _compare(got, ref, d["idrv"], f"{kind} icld={icld}")
     if kind not in ("thin", "nocloud"):
         assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
 
 
+DIV_TOL = 2.5e-5     # W m-2: flux divergence of a layer (half of what two fluxes at TIGHT_FLUX each could differ by)
+HEATFAC = 8.4391     # K d-1 per (W m-2 / hPa): g x 86400 / (cpdair x 100), src/rrtmg_lw_init.f90:298 with cpdair = 1004
+
+
 def _compare_thin_layers(got, ref, d, idrv, tag):
-    """For cloud decks that reach layers thinner than 1 hPa (an unphysical stress of the sweeps' hand-off logic): a heating rate there is
-    the flux divergence x 8.4 / dp[hPa] K d-1 per W m-2 - 40 to 400 - so the float32 transmittance of a thick cloud (7e-6 W m-2 in the
-    fluxes, inside the bar like everywhere else) shows as 1e-3 K d-1, ~1e-5 of the layer's own rate.  Fluxes at the usual tight bar
-    everywhere; rates 5x inside the north-star bar where a layer is at least 1 hPa thick, relative (1e-3 of max(|rate|, 1)) above."""
+    """Cloud decks that reach layers thinner than 1 hPa - down to 0.002 hPa: an unphysical stress of the sweeps' hand-off logic.  A heating
+    rate IS the layer's flux divergence x 8.44 / dp[hPa] (src/rrtmg_lw_rtrn.f90:598), and an optically thick cloud in such a layer absorbs
+    part of whatever error the upward flux carries INTO the layer from the column below (<= 1.4e-5 W m-2 = 3e-8 of the flux: the float32
+    cell codes and table entries of every cell underneath; measured, profiles/round4_thin_layers.md: a float64 decode of the layer's own
+    cells changes nothing) - x 460 at 0.018 hPa that is 5e-3 K d-1.  So the bars are: fluxes and d(flux)/dT as everywhere (5e-5); every
+    layer's flux divergence within 2.5e-5 W m-2, i.e. every heating rate within max(5e-5 K d-1, 2.1e-4 / dp[hPa]) - the first term, the
+    bar of every other test, decides for layers at least 4.2 hPa thick; and the north-star 1e-3 K d-1 in every layer at least 0.25 hPa thick."""
     dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
     ddt = max(np.abs(got[k] - ref[k]).max() for k in ("duflx_dt", "duflxc_dt")) if idrv == 1 else 0.0
-    thick = (np.array(d["plev"])[:, :-1] - np.array(d["plev"])[:, 1:]) >= 1.0
-    rel = max((np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1.0)).max() for k in ("hr", "hrc"))
-    dlow = max(np.abs(got[k] - ref[k])[thick].max() for k in ("hr", "hrc"))
-    print(f"{tag}: max|dflux|={dflux:.3e} W/m2  max|d(dF/dT)|={ddt:.3e}  max relative dhr={rel:.3e}  max|dhr| in layers >= 1 hPa thick={dlow:.3e}")
+    dp = np.array(d["plev"])[:, :-1] - np.array(d["plev"])[:, 1:]
+    err = np.stack([np.abs(got[k] - ref[k]) for k in ("hr", "hrc")])
+    bound = np.maximum(TIGHT_HR, DIV_TOL * HEATFAC / dp)[None]
+    worst = float((err / bound).max())
+    i = np.unravel_index(err.argmax(), err.shape)
+    thick = np.broadcast_to(dp[None] >= 0.25, err.shape)
+    print(f"{tag}: max|dflux|={dflux:.3e} W/m2  max|d(dF/dT)|={ddt:.3e}  max|dhr|={err.max():.3e} K/d (layer {dp[i[1], i[2]]:.4f} hPa thick: "
+          f"divergence error {err.max() * dp[i[1], i[2]] / HEATFAC:.2e} W/m2)  worst error / bound = {worst:.3f}  "
+          f"max|dhr| in layers >= 0.25 hPa thick = {err[thick].max():.3e}")
     assert np.isfinite(got["uflx"]).all() and np.isfinite(got["hr"]).all()
-    assert dflux <= TIGHT_FLUX and ddt <= TIGHT_FLUX and rel <= 1e-3 and dlow <= HR_TOL / 5
+    assert dflux <= TIGHT_FLUX and ddt <= TIGHT_FLUX
+    assert worst <= 1.0 and err[thick].max() <= HR_TOL
     assert got["icld"] == ref["icld"]
 
 
@@ -571,7 +577,7 @@ def test_several_devices_from_one_process(hip, oracle):
 @pytest.mark.parametrize("icld,idrv,ncol", [(2, 1, 70), (0, 0, 65), (1, 0, 64)])
 def test_tallest_column_the_interface_accepts(hip, oracle, icld, idrv, ncol):
     """nlay = 603 = mxlay of modules/parrrtm.f90:31, the largest value the entries accept: level tiles of k_flux, the sweeps' level loops,
-    k_blocksort's histogram, 603 k_layer rows.  (Layers 0.002 hPa thick: heating rates relative, see _compare_thin_layers.)"""
+    k_blocksort's histogram, 603 k_layer rows.  (Layers down to 0.002 hPa thick.)"""
     nlay = 603
     d = make_gcm_inputs(ncol, nlay, "aer_idrv" if idrv else "cloudy", col0=12)
     got = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
