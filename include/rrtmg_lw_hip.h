@@ -244,6 +244,10 @@ int rrtmg_lw_hip_set_overlap(int on);
  * partition.  Results do not depend on it.  rrtmg_lw_hip_cu_partition() returns the CUs of k_layer's share (0: none). */
 int rrtmg_lw_hip_set_cu_partition(int layer_cus);
 int rrtmg_lw_hip_cu_partition(void);
+/* A cloudy batch too small to fill the chip is a latency chain of kernels, three of them sweeps (down above the clouds, the cloud zone, up
+ * above the clouds).  Batches of up to `ncol` columns (default 4096; RRTMG_LW_ONE_SWEEP_MAX) take ONE sweep launch per band group instead:
+ * the cloud-zone kernel walks all levels.  0 = never.  Results do not depend on it (bit for bit).  Returns the previous value. */
+int rrtmg_lw_hip_set_one_sweep_max(int ncol);
 /* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (about 0.2 MB per column of the batch
  * at 72 layers, 0.37 MB at 137: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer
  * (<= 512 MB, or one slab) and the cached chunk states (<= 2 x 180 MB) of the Mersenne-Twister stream. */
@@ -271,6 +275,22 @@ int rrtmg_lw_hip_host_unregister(void *ptr);
 /* 1 when [ptr, ptr + bytes) lies inside a range registered above - the only arrays the entries copy from where they lie; everything else
  * goes through the library's own pinned staging (an array is NOT pinned because its ends share pages with registered neighbours). */
 int rrtmg_lw_hip_host_is_registered(const void *ptr, long long bytes);
+/* Optional: declare [ptr, ptr + bytes) STATIC - its contents stay as they are until rrtmg_lw_hip_host_changed(ptr, .).  The host-pointer
+ * entries look at every input row of every call for "one value for all columns of the batch" (such rows are filled on the device instead
+ * of copied: well-mixed gases handed over as full arrays, zero aerosol and cloud rows); that scan reads ~14 KB per 72-layer column and bounds
+ * the entries once the arrays are pinned.  For a static array the answer is kept per (array, column batch) and its rows are not read again.
+ * An array that is not declared is scanned on every call (the reference's semantics: inputs may change between calls).
+ * rrtmg_lw_hip_host_changed: the contents have changed - the cached scans are dropped; keep = 0 also withdraws the declaration (call it
+ * before the array is freed).  Fortran: rrtmg_lw_static / rrtmg_lw_changed (module rrtmg_lw_init). */
+int rrtmg_lw_hip_host_static(const void *ptr, long long bytes);
+int rrtmg_lw_hip_host_changed(const void *ptr, int keep);
+/* Concurrent callers of rrtmg_lw_hip_run_nomcica (an OpenMP host model calling per chunk of columns from several threads, the reference's
+ * calling model: serial inside a call, src/rrtmg_lw_rad.nomcica.f90:472): a call of at most RRTMG_LW_COMBINE_MAX (default 8192) columns
+ * that finds another call in flight is left in a list; whoever holds the turn solves everything that has gathered with the same
+ * (nlay, icld, idrv, inflglw, iceflglw, liqflglw) as ONE device pass and wakes the owners.  Results do not depend on it; a physics error
+ * is reported to the call whose columns caused it.  RRTMG_LW_COMBINE=0 restores the plain lock.  This returns the calls that came through
+ * the combining entry and the device passes that served them, since the library was loaded. */
+void rrtmg_lw_hip_combine_stats(long long *calls, long long *passes);
 
 /* PMC calibration: one kernel that reads `bytes` and writes `bytes` with 16 B per lane (known HBM traffic), so that a
  * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass can fix the counters' unit and scale in the same session. */

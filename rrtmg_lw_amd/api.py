@@ -119,6 +119,25 @@ def host_unregister(a):
     _check(lib().rrtmg_lw_hip_host_unregister(C.c_void_p(a.ctypes.data)))
 
 
+def host_static(a):
+    """Declare the numpy array `a` static: the host-pointer entries scan its rows once instead of on every call (rrtmg_lw_hip_host_static);
+    call host_changed(a) after modifying it."""
+    _check(lib().rrtmg_lw_hip_host_static(C.c_void_p(a.ctypes.data), C.c_longlong(a.nbytes)))
+
+
+def host_changed(a, keep=True):
+    """the static array `a` has new contents (keep=False: the declaration is withdrawn as well)"""
+    _check(lib().rrtmg_lw_hip_host_changed(C.c_void_p(a.ctypes.data), C.c_int(1 if keep else 0)))
+
+
+def combine_stats():
+    """(calls, device passes) of the combining entry for concurrent small calls since the library was loaded"""
+    c, p = C.c_longlong(0), C.c_longlong(0)
+    lib().rrtmg_lw_hip_combine_stats.restype = None
+    lib().rrtmg_lw_hip_combine_stats(C.byref(c), C.byref(p))
+    return int(c.value), int(p.value)
+
+
 def set_n1_prototype(on):
     """Measurement only: cloud-free calls through the prototype of the one-column-per-wavefront mapping (k_n1)."""
     _check(lib().rrtmg_lw_hip_set_n1_prototype(C.c_int(1 if on else 0)))
@@ -145,6 +164,11 @@ def set_overlap(on):
 def set_cu_partition(layer_cus):
     """k_layer of batch i+1 on `layer_cus` CUs beside the sweeps of batch i on the others (rrtmg_lw_hip_set_cu_partition); 0 = off"""
     _check(lib().rrtmg_lw_hip_set_cu_partition(C.c_int(int(layer_cus))))
+
+
+def set_one_sweep_max(ncol):
+    """cloudy batches of up to `ncol` columns take one sweep launch per band group instead of three (0 = never); returns the previous value"""
+    return int(lib().rrtmg_lw_hip_set_one_sweep_max(C.c_int(int(ncol))))
 
 
 def cu_partition():

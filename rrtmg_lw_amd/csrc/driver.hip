@@ -6,6 +6,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdarg>
 #include <mutex>
@@ -13,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -33,6 +35,8 @@ const int HOST_BATCH = []() { const char *e = getenv("RRTMG_LW_HOST_BATCH"); con
 // the pinned set, the D2H of batch i - 2 into it) left the copy engines and the kernels taking turns: a trace of a 524 288-column call
 // showed 11 ms of overlap between 44 ms of kernels and 52 ms of copies.
 constexpr int HOST_SETS = 4;
+
+struct KissTable { unsigned long long stride = 0; long long seed = -1; KissJump host[KJ_NGROUP + 1]; KissJump *dev = nullptr; };
 
 struct State {
     bool init = false;
@@ -88,6 +92,7 @@ struct State {
     // unpacked by the host threads), `fill` = the table of k_fill_rows (rows that do not travel)
     struct HostSet { char *in = nullptr; size_t in_cap = 0; char *out = nullptr; size_t out_cap = 0; char *fill = nullptr; size_t fill_cap = 0; } hset[HOST_SETS];
     hipEvent_t ev_h2d[HOST_SETS] = {}, ev_cmp[HOST_SETS] = {}, ev_d2h[HOST_SETS] = {};
+    KissTable kiss;             // the kissvec generator's jump table of the last (draws per sub-column, permuteseed) pair, on this device
     std::string err;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profile = false;
@@ -410,6 +415,13 @@ void drop_sweep_set(int k)
     SS = State::SweepSet{};
 }
 
+// A cloudy batch too small to fill the chip is a latency chain of six kernels; three of them are the sweeps (down above the clouds, the
+// cloud zone, up above the clouds).  Up to ONE_SWEEP_MAX columns the cloud-zone kernel walks all levels instead (k_blocksort, force_top)
+// and the two clear-sky launches are not made: 1 024 cloudy columns 0.58 -> MEASURED ms.  Larger batches keep the three launches - above the
+// clouds k_sweepc costs a third of k_sweepz's clear-sky body per level.
+int g_one_sweep_max = []() { const char *e = getenv("RRTMG_LW_ONE_SWEEP_MAX"); return e ? atoi(e) : 4096; }();       // rrtmg_lw_hip_set_one_sweep_max
+bool one_sweep(int nb, int mode) { return mode != 0 && nb <= g_one_sweep_max; }
+
 // per-column part of one batch: k_colprep (+ k_cloudscan / k_cloudlay for rtrn / rtrnmr): it runs on the
 // auxiliary stream one batch ahead of the heavy kernels (run_pipelined).
 template <bool GCM>
@@ -423,7 +435,7 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
         LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag, mode);
         const dim3 lgrid((nb + BLOCK - 1) / BLOCK, Wk.nlay), lblock(BLOCK);
         LAUNCH("k_cloudlay", (k_cloudlay<GCM>), lgrid, lblock, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
-        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(256), s, Wk, (nb + 63) / 64);      // the blocks by cloud top, hand-off levels
+        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(256), s, Wk, (nb + 63) / 64, one_sweep(nb, mode) ? 1 : 0);      // the blocks by cloud top, hand-off levels
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -441,7 +453,7 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         const dim3 cgrid((nb + BLOCK - 1) / BLOCK, nlay);
         if (mc) LAUNCH("k_cloudmc<arrays>", (k_cloudmc<false>), cgrid, block, s, G.D, Wk, *mc, g, nb, col0, nct, inflag, iceflag, liqflag);
         else LAUNCH("k_cloudmc<mask>", (k_cloudmc<true>), cgrid, block, s, G.D, Wk, McIn{}, g, nb, col0, nct, inflag, iceflag, liqflag);
-        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(256), s, Wk, (nb + 63) / 64);
+        LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(256), s, Wk, (nb + 63) / 64, one_sweep(nb, mode) ? 1 : 0);
     }
     LayerArgs la;
     la.ncol = nb; la.col0 = col0; la.nct = nct; la.idrv = idrv; la.istart = istart; la.iend = iend;
@@ -583,6 +595,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             continue;
         }
         if (mode == 0 && phase == 2) continue;
+        if (one_sweep(nb, mode)) continue;          // (the cloud-zone kernel walks all levels of a small batch)
         for (int g = 0; g < fg.n; g++) {            // above the clouds (or a cloud-free call): one launch per group
             const int nq = gq[g];
             sa.bands = fg.bands[g];
@@ -781,10 +794,12 @@ struct HostIn {
     const unsigned char *skip = nullptr;                  // per batch, set by the entry's prep step: rows nothing reads (a cloud array's layers without cloud) - not scanned, zero-filled
     const unsigned char *known = nullptr;                 // ... rows the prep step has already read in full and found to hold one pattern (known_bits): not scanned again
     const uint64_t *known_bits = nullptr;
+    unsigned long long static_gen = 0;                    // != 0: the caller declared the array static (rrtmg_lw_hip_host_static): row scans are cached per batch
 };
 struct HostOut { double *h; size_t rows; double *d; bool active; bool pinned = false; };
 int bounce_h2d(void *dst, const void *src, size_t bytes);
 int bounce_d2h(void *dst, const void *src, size_t bytes);
+int bounce_h2d_rows(void *dst, const void *src, size_t row_bytes, size_t stride_bytes, size_t rows);
 
 int stage_alloc(std::vector<HostIn> &ins, std::vector<HostOut> &outs, size_t nb)
 {
@@ -806,8 +821,7 @@ int stage_in(std::vector<HostIn> &ins, size_t ncol, size_t col0, size_t nb, hipS
         if (!a.h) continue;
         const size_t w = a.inner * nb * 8;
         if (nb == ncol) { if (int rc = bounce_h2d(a.d, a.h, w * a.rows)) return rc; continue; }
-        for (size_t r = 0; r < a.rows; r++)
-            if (int rc = bounce_h2d(a.d + a.inner * nb * r, a.h + a.inner * (col0 + ncol * r), w)) return rc;
+        if (int rc = bounce_h2d_rows(a.d, a.h + a.inner * col0, w, a.inner * ncol * 8, a.rows)) return rc;
     }
     return 0;
 }
@@ -893,16 +907,19 @@ public:
         return true;
     }
 };
-HostPool g_pool;
+// One pool per device of the fan-out: the worker thread that feeds device d (fan_out) runs its parallel regions on pool d with its share
+// of the host threads (host_threads() / devices: the scans are bound by the host's memory, more threads than cores only take turns).
+HostPool g_pools[MAXDEV];
+thread_local int tl_pool = 0, tl_share = 1;
 
 template <class F>
 void host_parallel(size_t work_bytes, F f)
 {
     // (a thread per MB of host data at least: a call of a few columns does not wake sixteen threads)
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), work_bytes >> 20));
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, host_threads() / tl_share), work_bytes >> 20));
     if (nt == 1) { f(0, 1); return; }
     const std::function<void(int, int)> fn = [&f](int t, int n) { f(t, n); };
-    if (g_pool.run(nt, fn)) return;
+    if (g_pools[tl_pool].run(nt, fn)) return;
     std::vector<std::thread> th;
     for (int t = 1; t < nt; t++) th.emplace_back([=, &f]() { f(t, nt); });
     f(0, nt);
@@ -957,6 +974,38 @@ bool host_range_pinned(const void *p, size_t bytes)
     return false;
 }
 
+// Arrays the caller has declared static (rrtmg_lw_hip_host_static): their contents stay as they are until rrtmg_lw_hip_host_changed.
+// The host-pointer entries scan every input row of every call for "one value for all columns of the batch" (stage_rows) - 14 KB per
+// 72-layer column of reads that bound the entry once the arrays are pinned; for a static array (well-mixed gases handed over as full
+// arrays, zero aerosol, emissivities) the answer of the first call is kept per (array, column batch) and the rows are not read again:
+// uniform rows are filled on the device as before, the others go straight to their DMA.
+struct StaticRange { const char *p; size_t bytes; unsigned long long gen; };
+std::vector<StaticRange> g_static;
+unsigned long long g_static_gen = 1;
+struct ScanKey {
+    const void *base; size_t ncol, inner, rows, col0, nb;
+    bool operator<(const ScanKey &o) const
+    {
+        if (base != o.base) return base < o.base;
+        if (ncol != o.ncol) return ncol < o.ncol;
+        if (inner != o.inner) return inner < o.inner;
+        if (rows != o.rows) return rows < o.rows;
+        if (col0 != o.col0) return col0 < o.col0;
+        return nb < o.nb;
+    }
+};
+struct ScanVal { unsigned long long gen = 0; std::vector<unsigned char> state; std::vector<uint64_t> bits; };     // state: 0 not scanned, 1 uniform, 2 not uniform
+std::map<ScanKey, ScanVal> g_scan;
+std::mutex g_scan_mu;          // (the fan-out's worker threads stage their batches side by side)
+// generation of the static range that holds the whole array, 0 if none
+unsigned long long static_gen_of(const void *p, size_t bytes)
+{
+    const char *a = (const char *)p;
+    for (auto &r : g_static)
+        if (a >= r.p && a + bytes <= r.p + r.bytes) return r.gen;
+    return 0;
+}
+
 int ensure_hostbuf(char **p, size_t *cap, size_t bytes)
 {
     if (*cap >= bytes) return 0;
@@ -1001,6 +1050,25 @@ int bounce_d2h(void *dst, const void *src, size_t bytes)
     return 0;
 }
 
+// `rows` rows of `row_bytes` each, `stride_bytes` apart in the caller's memory, to a contiguous device buffer (a column block of a
+// (ncol, nlay) array), packed into the pinned buffer by the host threads first
+int bounce_h2d_rows(void *dst, const void *src, size_t row_bytes, size_t stride_bytes, size_t rows)
+{
+    if (row_bytes == stride_bytes) return bounce_h2d(dst, src, row_bytes * rows);
+    auto &hs = G.hset[0];
+    const size_t per = std::max<size_t>(1, BOUNCE_BYTES / row_bytes);
+    if (int rc = ensure_hostbuf(&hs.in, &hs.in_cap, std::min(rows, per) * row_bytes)) return rc;
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+        const size_t nr = std::min(per, rows - r0);
+        host_parallel(2 * nr * row_bytes, [&](int t, int nt) {
+            for (size_t r = nr * (size_t)t / (size_t)nt; r < nr * (size_t)(t + 1) / (size_t)nt; r++)
+                memcpy(hs.in + r * row_bytes, (const char *)src + (r0 + r) * stride_bytes, row_bytes);
+        });
+        HIP_TRY(hipMemcpy((char *)dst + r0 * row_bytes, hs.in, nr * row_bytes, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
 int ensure_copy_streams()
 {
     if (G.cp_in) return 0;
@@ -1039,11 +1107,26 @@ int stage_rows(std::vector<HostIn> &ins, size_t nb, int k, hipStream_t s)
         bytes += a.inner * a.rows * nb * 8;
     }
     auto row_src = [&](const StagedRow &q) { const HostIn &a = ins[q.arr]; return a.src + a.inner * (a.src_col0 + a.src_ncol * q.row); };
+    // cached scans of the arrays declared static (the entry of this array and batch; filled below on a miss)
+    std::vector<ScanVal *> cache(ins.size(), nullptr);
+    std::vector<unsigned char> cache_hit(ins.size(), 0);
+    {
+        std::lock_guard<std::mutex> lk(g_scan_mu);
+        for (size_t ai = 0; ai < ins.size(); ai++) {
+            const HostIn &a = ins[ai];
+            if (!a.h || a.static_gen == 0 || a.src != a.h) continue;          // (an array the entry reduces on the host, tauctot, is formed anew per call)
+            ScanVal &v = g_scan[ScanKey{a.h, a.src_ncol, a.inner, a.rows, a.src_col0, nb}];
+            if (v.gen == a.static_gen && v.state.size() == a.rows) cache_hit[ai] = 1;
+            else { v.gen = a.static_gen; v.state.assign(a.rows, 0); v.bits.assign(a.rows, 0); }
+            cache[ai] = &v;                                                     // (map nodes do not move; entries are dropped under the entry lock only)
+        }
+    }
     host_parallel(bytes, [&](int t, int nt) {
         for (size_t j = (size_t)t; j < rows.size(); j += (size_t)nt) {
             StagedRow &q = rows[j];
             if (ins[q.arr].skip && ins[q.arr].skip[q.row]) { q.uniform = true; q.bits = 0; continue; }
             if (ins[q.arr].known && ins[q.arr].known[q.row]) { q.uniform = true; q.bits = ins[q.arr].known_bits[q.row]; continue; }
+            if (cache_hit[q.arr] && cache[q.arr]->state[q.row] != 0) { q.uniform = cache[q.arr]->state[q.row] == 1; q.bits = cache[q.arr]->bits[q.row]; continue; }
             const uint64_t *p = reinterpret_cast<const uint64_t *>(row_src(q));
             const size_t n = ins[q.arr].inner * nb;
             const uint64_t v = p[0];
@@ -1054,6 +1137,7 @@ int stage_rows(std::vector<HostIn> &ins, size_t nb, int k, hipStream_t s)
             for (; i < n && acc == 0; i++) acc |= p[i] ^ v;
             q.uniform = acc == 0;
             q.bits = v;
+            if (cache[q.arr]) { cache[q.arr]->bits[q.row] = v; cache[q.arr]->state[q.row] = q.uniform ? 1 : 2; }      // (one thread per row)
         }
     });
     size_t need = 0;
@@ -1133,6 +1217,7 @@ int host_pipeline_run(int ncol, int c0, int c1, int nbmax, std::vector<HostIn> &
         set += a.h ? a.inner * a.rows * (size_t)nbmax : 0;
         nrows += a.h ? a.rows + a.inner * a.rows * (size_t)nbmax / FILL_MAX + 1 : 0;
         a.pinned = a.h && host_range_pinned(a.h, a.inner * (size_t)ncol * a.rows * 8);
+        a.static_gen = a.h ? static_gen_of(a.h, a.inner * (size_t)ncol * a.rows * 8) : 0;
     }
     for (auto &a : outs) {
         set += a.rows * (size_t)nbmax;
@@ -1377,12 +1462,11 @@ int mt_states(hipStream_t s, uint32_t seed, unsigned long long per, int *M_out, 
 // the table of one (draws per sub-column, permuteseed) pair: entries 0 .. KJ_NGROUP-1 jump from the seed to sub-column 8 g, the last one
 // by one sub-column.  One table, rebuilt (after a device synchronisation: an earlier call may still read it) when the pair changes - a host
 // model keeps its permuteseed per call site, so in steady state this is a comparison.
-struct KissTable { unsigned long long stride = 0; long long seed = -1; KissJump host[KJ_NGROUP + 1]; KissJump *dev = nullptr; };
-KissTable g_kiss_table;
+// (struct KissTable: beside State, which holds one per device)
 
 int kiss_table(hipStream_t s, int stride, int permuteseed, const KissJump **dev, KissJump *jsub)
 {
-    KissTable &T = g_kiss_table;
+    KissTable &T = G.kiss;
     const long long seed = std::max(permuteseed, 0);
     if (!T.dev) HIP_TRY(hipMalloc((void **)&T.dev, sizeof(T.host)));
     if (T.stride != (unsigned long long)stride || T.seed != seed) {
@@ -1612,7 +1696,8 @@ static void finalize_state()
     if (first) {            // the queue and the generator's caches live on the first device
         if (Q.pinned) { forget_pinned(Q.pinned); (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
         Q.chunks.clear(); Q.ncol = 0; Q.open = false;
-        if (g_kiss_table.dev) { (void)hipFree(g_kiss_table.dev); g_kiss_table = KissTable{}; }
+        { std::lock_guard<std::mutex> lk(g_scan_mu); g_scan.clear(); }
+        g_static.clear();
         for (MtStates &S : g_mt) {
             if (S.dev) (void)hipFree(S.dev);
             if (S.polys) (void)hipFree(S.polys);
@@ -1620,6 +1705,7 @@ static void finalize_state()
         }
     }
     if (G.mask) (void)hipFree(G.mask);
+    if (G.kiss.dev) (void)hipFree(G.kiss.dev);
     if (G.d_rnd) { (void)hipFree(G.d_rnd); G.d_rnd = nullptr; G.rnd_bytes = 0; }
     if (G.d_ktab) (void)hipFree(G.d_ktab);
     if (G.d_stat) (void)hipFree(G.d_stat);
@@ -1679,6 +1765,16 @@ int rrtmg_lw_hip_set_overlap(int on)
     return 0;
 }
 
+// Cloudy batches of up to `ncol` columns take ONE sweep launch per band group (the cloud-zone kernel over all levels) instead of three
+// (one_sweep, above); 0 = never.  Results do not depend on it.  Returns the previous value.
+int rrtmg_lw_hip_set_one_sweep_max(int ncol)
+{
+    ENTRY_LOCK;
+    const int prev = g_one_sweep_max;
+    g_one_sweep_max = ncol < 0 ? 0 : ncol;
+    return prev;
+}
+
 // CU partition of the overlapped pipeline (device-pointer entries): k_layer of batch i + 1 on `layer_cus` CUs (rounded to a multiple of 8:
 // the same number from every XCD), the sweeps and k_flux of batch i on the others; 0 = no partition.  A value > 0 switches the overlap on.
 int rrtmg_lw_hip_set_cu_partition(int layer_cus)
@@ -1729,10 +1825,9 @@ long long rrtmg_lw_hip_workspace_bytes(void)
     size_t tot = 0;
     for (int d = 0; d < g_ndev; d++) {
         const State &S = g_states[d];
-        tot += S.ws_bytes + S.stage_bytes + S.mask_bytes + S.rnd_bytes;
+        tot += S.ws_bytes + S.stage_bytes + S.mask_bytes + S.rnd_bytes + (S.kiss.dev ? sizeof(KissJump) * (KJ_NGROUP + 1) : 0);
     }
     for (const MtStates &M : g_mt) tot += M.bytes();
-    tot += g_kiss_table.dev ? sizeof(KissJump) * (KJ_NGROUP + 1) : 0;
     return (long long)tot;
 }
 int rrtmg_lw_hip_num_chunks(void) { return NQUAD; }
@@ -1921,6 +2016,7 @@ int fan_out(int ncol, RangeFn range)
         if (c0 >= c1) break;
         th.emplace_back([&rcs, &range, d, c0, c1]() {
             g_cur = &g_states[d];
+            tl_pool = d; tl_share = g_ndev;
             if (hipSetDevice(G.device) != hipSuccess) { rcs[d] = fail(RRTMG_LW_HIP_EHIP, "hipSetDevice(%d) failed", G.device); return; }
             rcs[d] = range(c0, c1);
         });
@@ -1951,6 +2047,19 @@ int nomcica_host(int ncol, int nlay, int *icld, int idrv,
                               inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
     });
 }
+bool comb_enabled();
+int comb_max();
+long long comb_calls_total();
+long long comb_passes_total();
+int nomcica_combined(int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt);
 }   // namespace
 
 extern "C" {
@@ -1966,9 +2075,18 @@ int rrtmg_lw_hip_run_nomcica(
     double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
     double *duflx_dt, double *duflxc_dt)
 {
+    if (ncol >= 1 && ncol <= comb_max() && icld && comb_enabled()) return nomcica_combined(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
+                              inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
     ENTRY_LOCK;
     return nomcica_host(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
                               inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
+}
+
+// calls and device passes of the combining entry since the library was loaded (a pass serves one or more calls)
+void rrtmg_lw_hip_combine_stats(long long *calls, long long *passes)
+{
+    if (calls) *calls = comb_calls_total();
+    if (passes) *passes = comb_passes_total();
 }
 
 int rrtmg_lw_hip_run_columns(
@@ -2101,6 +2219,37 @@ int rrtmg_lw_hip_host_unregister(void *ptr)
     return 0;
 }
 
+// The caller declares [ptr, ptr + bytes) static: its contents stay as they are until rrtmg_lw_hip_host_changed(ptr).  The host-pointer entries
+// then scan each of its rows once per column batch shape instead of once per call (g_scan).  Nothing else changes: an array that is not
+// declared is scanned on every call.
+int rrtmg_lw_hip_host_static(const void *ptr, long long bytes)
+{
+    ENTRY_LOCK;
+    if (!ptr || bytes <= 0) return fail(RRTMG_LW_HIP_EARG, "bad range");
+    for (auto &r : g_static)
+        if (r.p == (const char *)ptr) { r.bytes = (size_t)bytes; r.gen = ++g_static_gen; return 0; }
+    g_static.push_back(StaticRange{(const char *)ptr, (size_t)bytes, ++g_static_gen});
+    return 0;
+}
+// The contents of the static range that starts at ptr have changed: its cached row scans are dropped and the next call scans it again.
+// keep = 0 also withdraws the declaration (before the array is freed).
+int rrtmg_lw_hip_host_changed(const void *ptr, int keep)
+{
+    ENTRY_LOCK;
+    for (size_t i = 0; i < g_static.size(); i++) {
+        if (g_static[i].p != (const char *)ptr) continue;
+        const char *lo = g_static[i].p, *hi = lo + g_static[i].bytes;
+        {
+            std::lock_guard<std::mutex> lk(g_scan_mu);
+            for (auto it = g_scan.begin(); it != g_scan.end();)
+                if ((const char *)it->first.base >= lo && (const char *)it->first.base < hi) it = g_scan.erase(it); else ++it;
+        }
+        if (keep) g_static[i].gen = ++g_static_gen; else g_static.erase(g_static.begin() + (long)i);
+        return 0;
+    }
+    return fail(RRTMG_LW_HIP_EARG, "no static range starts at this address");
+}
+
 // Streams `bytes` from one device buffer into another with 16 B per lane (k_calibrate): known traffic for PMC calibration.
 int rrtmg_lw_hip_calibrate_stream(long long bytes)
 {
@@ -2194,78 +2343,205 @@ int rrtmg_lw_hip_queue_add(
 template <class F>
 static void queue_parallel(size_t n, F f)
 {
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
-    if (n < 64 || nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([=, &f]() { for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) f(i); });
-    for (auto &x : th) x.join();
+    // (on the persistent host threads: a pass of the combining entry packs sixteen chunks, and eight thread starts cost more than that)
+    if (n < 4) { for (size_t i = 0; i < n; i++) f(i); return; }
+    const size_t want = std::min<size_t>(n, 8);
+    host_parallel(want << 20, [&](int t, int nt) { for (size_t i = n * (size_t)t / (size_t)nt; i < n * (size_t)(t + 1) / (size_t)nt; i++) f(i); });
 }
 
-extern "C" int rrtmg_lw_hip_queue_flush(void)
+// The chunks as ONE call: every array is [rows][columns][inner] - row r of a chunk goes to row r of the packed array at the chunk's column
+// offset (pinned set Q.pinned) - then nomcica_host on the packed arrays, then the outputs back to every chunk.  Caller holds the entry lock.
+static int solve_chunks(const std::vector<QueuedChunk> &chunks, long long N, int nlay, int icld_in, int idrv, int inflg, int iceflg, int liqflg)
 {
     size_t in_inner[23], in_rows[23], out_rows[8];
     double *in_p[23], *out_p[8];
-    long long N;
-    ENTRY_LOCK;             // held over pack, solve and scatter: another thread's queue_add / queue_begin / finalize must not touch the chunk list or the pinned set in between
-    {
-        if (!Q.open) return fail(RRTMG_LW_HIP_EARG, "rrtmg_lw_hip_queue_begin has not been called");
-        N = Q.ncol;
-        if (N == 0) return 0;
-        queue_shapes(Q.nlay, in_inner, in_rows, out_rows);
-        size_t tot = 0;
-        for (int k = 0; k < 23; k++) tot += in_inner[k] * in_rows[k] * (size_t)N;
-        for (int k = 0; k < 8; k++) tot += out_rows[k] * (size_t)N;
-        if (Q.pinned_doubles < tot) {
-            if (Q.pinned) { forget_pinned(Q.pinned); (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
-            HIP_TRY(hipHostMalloc((void **)&Q.pinned, tot * sizeof(double), hipHostMallocDefault));
-            Q.pinned_doubles = tot;
-            g_pinned.emplace_back((const char *)Q.pinned, tot * sizeof(double));
-        }
-        double *p = Q.pinned;
-        for (int k = 0; k < 23; k++) { in_p[k] = p; p += in_inner[k] * in_rows[k] * (size_t)N; }
-        for (int k = 0; k < 8; k++) { out_p[k] = p; p += out_rows[k] * (size_t)N; }
-        // pack: every array is [rows][columns][inner] - row r of a chunk goes to row r of the packed array at the chunk's column offset
-        const bool cloud = !(Q.icld == 0);
-        std::vector<size_t> offs(Q.chunks.size());
-        { size_t off = 0; for (size_t i = 0; i < Q.chunks.size(); i++) { offs[i] = off; off += (size_t)Q.chunks[i].ncol; } }
-        queue_parallel(Q.chunks.size(), [&](size_t i) {          // (the copies are many short rows: host-bound, spread over a few threads)
-            const QueuedChunk &c = Q.chunks[i];
-            for (int k = 0; k < 23; k++) {
-                const bool cloud_arr = k >= 16 && k <= 21;
-                if (cloud_arr && !cloud) continue;
-                const size_t w = in_inner[k] * (size_t)c.ncol;
-                for (size_t r = 0; r < in_rows[k]; r++)
-                    memcpy(in_p[k] + (r * (size_t)N + offs[i]) * in_inner[k], c.in[k] + r * w, w * sizeof(double));
-            }
-        });
+    queue_shapes(nlay, in_inner, in_rows, out_rows);
+    size_t tot = 0;
+    for (int k = 0; k < 23; k++) tot += in_inner[k] * in_rows[k] * (size_t)N;
+    for (int k = 0; k < 8; k++) tot += out_rows[k] * (size_t)N;
+    if (Q.pinned_doubles < tot) {
+        if (Q.pinned) { forget_pinned(Q.pinned); (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
+        HIP_TRY(hipHostMalloc((void **)&Q.pinned, tot * sizeof(double), hipHostMallocDefault));
+        Q.pinned_doubles = tot;
+        g_pinned.emplace_back((const char *)Q.pinned, tot * sizeof(double));
     }
-    int icld = Q.icld;
-    const bool cloud = !(Q.icld == 0);
-    const int rc = nomcica_host((int)N, Q.nlay, &icld, Q.idrv, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
-                                            in_p[8], in_p[9], in_p[10], in_p[11], in_p[12], in_p[13], in_p[14], in_p[15], Q.inflg, Q.iceflg, Q.liqflg,
+    double *p = Q.pinned;
+    for (int k = 0; k < 23; k++) { in_p[k] = p; p += in_inner[k] * in_rows[k] * (size_t)N; }
+    for (int k = 0; k < 8; k++) { out_p[k] = p; p += out_rows[k] * (size_t)N; }
+    const bool cloud = !(icld_in == 0);
+    std::vector<size_t> offs(chunks.size());
+    { size_t off = 0; for (size_t i = 0; i < chunks.size(); i++) { offs[i] = off; off += (size_t)chunks[i].ncol; } }
+    queue_parallel(chunks.size(), [&](size_t i) {          // (the copies are many short rows: host-bound, spread over a few threads)
+        const QueuedChunk &c = chunks[i];
+        for (int k = 0; k < 23; k++) {
+            const bool cloud_arr = k >= 16 && k <= 21;
+            if (cloud_arr && !cloud) continue;
+            const size_t w = in_inner[k] * (size_t)c.ncol;
+            for (size_t r = 0; r < in_rows[k]; r++)
+                memcpy(in_p[k] + (r * (size_t)N + offs[i]) * in_inner[k], c.in[k] + r * w, w * sizeof(double));
+        }
+    });
+    int icld = icld_in;
+    const int rc = nomcica_host((int)N, nlay, &icld, idrv, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
+                                            in_p[8], in_p[9], in_p[10], in_p[11], in_p[12], in_p[13], in_p[14], in_p[15], inflg, iceflg, liqflg,
                                             cloud ? in_p[16] : nullptr, cloud ? in_p[17] : nullptr, cloud ? in_p[18] : nullptr, cloud ? in_p[19] : nullptr,
                                             cloud ? in_p[20] : nullptr, cloud ? in_p[21] : nullptr, in_p[22],
                                             out_p[0], out_p[1], out_p[2], out_p[3], out_p[4], out_p[5],
-                                            Q.idrv == 1 ? out_p[6] : nullptr, Q.idrv == 1 ? out_p[7] : nullptr);
+                                            idrv == 1 ? out_p[6] : nullptr, idrv == 1 ? out_p[7] : nullptr);
     if (rc == 0) {
-        std::vector<size_t> offs(Q.chunks.size());
-        { size_t off = 0; for (size_t i = 0; i < Q.chunks.size(); i++) { offs[i] = off; off += (size_t)Q.chunks[i].ncol; } }
-        queue_parallel(Q.chunks.size(), [&](size_t i) {
-            const QueuedChunk &c = Q.chunks[i];
+        queue_parallel(chunks.size(), [&](size_t i) {
+            const QueuedChunk &c = chunks[i];
             for (int k = 0; k < 8; k++) {
-                if (!c.out[k] || (k >= 6 && Q.idrv != 1)) continue;
+                if (!c.out[k] || (k >= 6 && idrv != 1)) continue;
                 for (size_t r = 0; r < out_rows[k]; r++)
                     memcpy(c.out[k] + r * (size_t)c.ncol, out_p[k] + r * (size_t)N + offs[i], (size_t)c.ncol * sizeof(double));
             }
             if (c.icld) *c.icld = icld;
         });
     }
+    return rc;
+}
+
+extern "C" int rrtmg_lw_hip_queue_flush(void)
+{
+    ENTRY_LOCK;             // held over pack, solve and scatter: another thread's queue_add / queue_begin / finalize must not touch the chunk list or the pinned set in between
+    if (!Q.open) return fail(RRTMG_LW_HIP_EARG, "rrtmg_lw_hip_queue_begin has not been called");
+    if (Q.ncol == 0) return 0;
+    const int rc = solve_chunks(Q.chunks, Q.ncol, Q.nlay, Q.icld, Q.idrv, Q.inflg, Q.iceflg, Q.liqflg);
     Q.chunks.clear();
     Q.ncol = 0;
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Concurrent callers (threading): a host model that calls rrtmg_lw per chunk of columns from several OpenMP threads.
+// The reference is serial inside a call and hosts thread OVER calls (src/rrtmg_lw_rad.nomcica.f90:472); here a call costs ~0.9 ms
+// whatever its size below a few thousand columns, so N threads taking turns at one lock run at one chunk per 0.9 ms.  Instead a caller
+// that finds another call in flight leaves its request in a list and sleeps; whoever holds the turn solves everything that has gathered
+// with the same (nlay, icld, idrv, cloud flags) as ONE packed call (solve_chunks, the queue's own code) and wakes the owners.  Results do
+// not depend on the company a chunk had (tests/test_hip_parity.py::test_a_column_does_not_depend_on_its_neighbours).  No call-site change.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct CallReq {
+    QueuedChunk c;
+    int nlay, icld, idrv, inflg, iceflg, liqflg;
+    int rc = 0;
+    bool done = false, lead = false;
+    std::condition_variable cv;
+};
+std::mutex g_comb_mu;
+std::condition_variable g_comb_arrive;      // a request has joined the list
+std::vector<CallReq *> g_comb_pending;
+bool g_comb_busy = false;
+size_t g_comb_last = 1;                      // requests the previous pass served: so many callers are about to come back
+std::atomic<long long> g_comb_calls{0}, g_comb_passes{0};
+// calls of up to this many columns are candidates (larger ones fill the device on their own and go straight to the entry lock)
+const int COMBINE_MAX = []() { const char *e = getenv("RRTMG_LW_COMBINE_MAX"); return e ? atoi(e) : 8192; }();
+const int COMBINE_WAIT_US = []() { const char *e = getenv("RRTMG_LW_COMBINE_WAIT_US"); return e ? atoi(e) : 250; }();
+
+// everything that has gathered, group by group (the first request's shape, then what is left, ...)
+void comb_serve(std::vector<CallReq *> &batch)
+{
+    ENTRY_LOCK;
+    std::vector<char> served(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); i++) {
+        if (served[i]) continue;
+        CallReq &a = *batch[i];
+        std::vector<size_t> grp;
+        long long N = 0;
+        for (size_t j = i; j < batch.size(); j++) {
+            const CallReq &b = *batch[j];
+            if (!served[j] && b.nlay == a.nlay && b.icld == a.icld && b.idrv == a.idrv && b.inflg == a.inflg && b.iceflg == a.iceflg && b.liqflg == a.liqflg &&
+                N + b.c.ncol <= 0x7fffffffLL) { grp.push_back(j); N += b.c.ncol; }
+        }
+        auto alone = [&](CallReq &r) {
+            const QueuedChunk &c = r.c;
+            int icld = r.icld;
+            g_comb_passes++;
+            r.rc = nomcica_host(c.ncol, r.nlay, &icld, r.idrv, c.in[0], c.in[1], c.in[2], c.in[3], c.in[4], c.in[5], c.in[6], c.in[7], c.in[8], c.in[9], c.in[10],
+                                c.in[11], c.in[12], c.in[13], c.in[14], c.in[15], r.inflg, r.iceflg, r.liqflg, c.in[16], c.in[17], c.in[18], c.in[19], c.in[20], c.in[21],
+                                c.in[22], c.out[0], c.out[1], c.out[2], c.out[3], c.out[4], c.out[5], c.out[6], c.out[7]);
+            if (c.icld) *c.icld = icld;
+        };
+        if (grp.size() == 1) alone(a);
+        else {
+            std::vector<QueuedChunk> chunks;
+            for (size_t j : grp) chunks.push_back(batch[j]->c);
+            g_comb_passes++;
+            const int rc = solve_chunks(chunks, N, a.nlay, a.icld, a.idrv, a.inflg, a.iceflg, a.liqflg);
+            if (rc == 0) { for (size_t j : grp) batch[j]->rc = 0; }
+            else { for (size_t j : grp) alone(*batch[j]); }      // an error (one caller's bad particle size ...) belongs to the call that caused it: each chunk again, on its own
+        }
+        for (size_t j : grp) served[j] = 1;
+    }
+}
+
+int comb_call(CallReq &me)
+{
+    std::unique_lock<std::mutex> lk(g_comb_mu);
+    g_comb_calls++;
+    g_comb_pending.push_back(&me);
+    g_comb_arrive.notify_one();
+    if (g_comb_busy) {
+        me.cv.wait(lk, [&] { return me.done || me.lead; });
+        if (me.done) return me.rc;
+    }
+    g_comb_busy = true;                      // this thread has the turn: its own request is among the pending ones
+    while (!me.done) {
+        // The callers the previous pass served come back within the time of a call's return trip: a pass that starts the moment the first of
+        // them is here serves that one alone while the others queue up behind it (measured: passes of 1 and 15 chunks in turn).  Wait for as
+        // many as there were, a fraction of a pass's own time at most; a single-threaded host (previous pass: one request) never waits.
+        if (g_comb_last > 1)
+            g_comb_arrive.wait_for(lk, std::chrono::microseconds(COMBINE_WAIT_US), [&] { return g_comb_pending.size() >= g_comb_last; });
+        std::vector<CallReq *> batch;
+        batch.swap(g_comb_pending);
+        g_comb_last = batch.size();
+        lk.unlock();
+        comb_serve(batch);
+        lk.lock();
+        for (CallReq *r : batch) { r->done = true; if (r != &me) r->cv.notify_one(); }
+    }
+    if (!g_comb_pending.empty()) { g_comb_pending.front()->lead = true; g_comb_pending.front()->cv.notify_one(); }     // the turn goes to the first of those who came meanwhile
+    else g_comb_busy = false;
+    return me.rc;
+}
+
+int comb_max() { return COMBINE_MAX; }
+bool comb_enabled() { static const bool on = []() { const char *e = getenv("RRTMG_LW_COMBINE"); return !e || atoi(e) != 0; }(); return on; }
+long long comb_calls_total() { return g_comb_calls.load(); }
+long long comb_passes_total() { return g_comb_passes.load(); }
+
+int nomcica_combined(int ncol, int nlay, int *icld, int idrv,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp,
+    const double *reice, const double *reliq, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
+    double *duflx_dt, double *duflxc_dt)
+{
+    CallReq me;
+    me.c = QueuedChunk{ncol, icld,
+                       {play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
+                        cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer},
+                       {uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt}};
+    me.nlay = nlay; me.icld = *icld; me.idrv = idrv; me.inflg = inflglw; me.iceflg = iceflglw; me.liqflg = liqflglw;
+    // what a packed call could not report per chunk is checked here, per call: null arrays (the packing would read them)
+    const int icld_eff = (me.icld < 0 || me.icld > 3) ? 2 : me.icld;
+    bool bad = !uflx || !dflx || !hr || !uflxc || !dflxc || !hrc || (idrv == 1 && (!duflx_dt || !duflxc_dt)) || nlay < 1 || nlay > 603;
+    for (int k = 0; k < 23; k++) {
+        const bool cloud_arr = k >= 16 && k <= 21;
+        if (!me.c.in[k] && !(cloud_arr && icld_eff == 0)) bad = true;
+    }
+    if (bad) {          // let the plain entry say what is wrong
+        ENTRY_LOCK;
+        return nomcica_host(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
+                            inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
+    }
+    return comb_call(me);
+}
+}   // namespace
 
 extern "C" {
 
@@ -2395,42 +2671,38 @@ int rrtmg_lw_hip_mcica_subcol_device(
     return 0;
 }
 
-int rrtmg_lw_hip_mcica_subcol(
-    int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
+// columns [c0, c1) of the stand-alone generator with host arrays (ncol columns wide) on the calling thread's current device state
+static int subcol_host_range(
+    int ncol, int c0, int c1, int nlay, int icld, int permuteseed, int irng, const double *play, const double *cldfrac, const double *ciwp,
     const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
     double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl)
 {
-    ENTRY_LOCK;
-    if (int rc = check_mcica_build()) return rc;
-    if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
-    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
-    if (icld == 0) return 0;
-    const size_t n = (size_t)ncol, L = (size_t)nlay;
+    HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
+    const size_t n = (size_t)ncol, L = (size_t)nlay, nl = (size_t)(c1 - c0);
     const bool two = icld == 4 || icld == 5;
-    std::vector<HostIn> ins = {{play, 1, L, 0}, {cldfrac, 1, L, 0}, {ciwp, 1, L, 0}, {clwp, 1, L, 0}, {tauc, NBND, L, 0},
-                               {two ? alpha : nullptr, 1, L, 0}};
-    for (size_t k = 0; k < 5; k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null input array");
-    if (two && !alpha) return fail(RRTMG_LW_HIP_EARG, "icld = 4/5 needs alpha");
-    std::vector<HostOut> outs;                                   // outputs are copied with plain 1-D copies below
-    if (int rc = stage_alloc(ins, outs, n)) return rc;
+    // (only what the generator reads travels: pressures, cloud fractions, alpha; water paths and optical depths stay with the host threads below)
+    std::vector<HostIn> ins = {{play, 1, L, 0}, {cldfrac, 1, L, 0}, {two ? alpha : nullptr, 1, L, 0}};
+    std::vector<HostOut> outs;                                   // outputs are written by the host threads below
+    if (int rc = stage_alloc(ins, outs, nl)) return rc;
     hipStream_t s = G.stream;
-    if (int rc = stage_in(ins, n, 0, n, s)) return rc;
-    if (int rc = generate_mask(s, ncol, nlay, icld, permuteseed, *irng, ins[0].d, ins[1].d, ins[5].d)) return rc;
+    if (int rc = stage_in(ins, n, (size_t)c0, nl, s)) return rc;
+    if (int rc = generate_mask(s, (int)nl, nlay, icld, permuteseed, irng, ins[0].d, ins[1].d, ins[2].d)) return rc;
     // The sub-column arrays are implied by the mask (MASK_WORDS x 4 B per (column, layer)) and the grid-mean inputs, which the host holds:
     // the mask comes back over PCIe and the host threads write the four (ngpt, ncol, nlay) arrays - 4 x ngpt x 8 B per (column, layer), 224
     // times the mask - at memory speed (src/mcica_subcol_gen_lw.f90:664-680: where cloudy the layer's water paths and the band's optical
     // depth, elsewhere zero).  (Expanding on the device and copying 322 KB per 72-layer column back ran at 0.03 M columns/s.)
-    std::vector<unsigned> hmask((size_t)MASK_WORDS * L * n);
+    std::vector<unsigned> hmask((size_t)MASK_WORDS * L * nl);
     HIP_TRY(hipStreamSynchronize(s));
     if (int rc = bounce_d2h(hmask.data(), G.mask, hmask.size() * sizeof(unsigned))) return rc;
     int gband[NGPT];
     for (int ig = 0; ig < NGPT; ig++) { int b = 1; for (int B = 2; B <= NBND; B++) b += (ig >= band_g0(B)) ? 1 : 0; gband[ig] = b - 1; }
-    host_parallel((size_t)NGPT * n * L * 8 * 4, [&](int t, int nt) {
-        const size_t cells = n * L;
-        for (size_t cl = cells * (size_t)t / (size_t)nt; cl < cells * (size_t)(t + 1) / (size_t)nt; cl++) {
-            const size_t l = cl / n, gc = cl % n;                      // cl = gc + n * l: the arrays' (column, layer) order
+    host_parallel((size_t)NGPT * nl * L * 8 * 4, [&](int t, int nt) {
+        const size_t cells = nl * L;
+        for (size_t ci = cells * (size_t)t / (size_t)nt; ci < cells * (size_t)(t + 1) / (size_t)nt; ci++) {
+            const size_t l = ci / nl, lc = ci % nl;                    // the block's (column, layer) order
+            const size_t cl = (size_t)c0 + lc + n * l;                 // ... and the cell's place in the caller's arrays
             unsigned w[MASK_WORDS];
-            for (int k = 0; k < MASK_WORDS; k++) w[k] = hmask[((size_t)k * L + l) * n + gc];
+            for (int k = 0; k < MASK_WORDS; k++) w[k] = hmask[((size_t)k * L + l) * nl + lc];
             const double iw = ciwp[cl], lw = clwp[cl];
             const double *tc = tauc + (size_t)NBND * cl;
             double *o0 = cldfmcl + (size_t)NGPT * cl, *o1 = ciwpmcl + (size_t)NGPT * cl, *o2 = clwpmcl + (size_t)NGPT * cl, *o3 = taucmcl + (size_t)NGPT * cl;
@@ -2443,9 +2715,32 @@ int rrtmg_lw_hip_mcica_subcol(
             }
         }
     });
-    memcpy(reicmcl, rei, n * L * 8);                            // :283-284
-    memcpy(relqmcl, rel, n * L * 8);
+    for (size_t l = 0; l < L; l++) {                            // :283-284
+        memcpy(reicmcl + c0 + n * l, rei + c0 + n * l, nl * 8);
+        memcpy(relqmcl + c0 + n * l, rel + c0 + n * l, nl * 8);
+    }
     return read_physics_error(s);
+}
+
+int rrtmg_lw_hip_mcica_subcol(
+    int ncol, int nlay, int icld, int permuteseed, int *irng, const double *play, const double *cldfrac, const double *ciwp,
+    const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
+    double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl)
+{
+    ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
+    if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
+    if (icld == 0) return 0;
+    if (!play || !cldfrac || !ciwp || !clwp || !rei || !rel || !tauc) return fail(RRTMG_LW_HIP_EARG, "null input array");
+    if ((icld == 4 || icld == 5) && !alpha) return fail(RRTMG_LW_HIP_EARG, "icld = 4/5 needs alpha");
+    if (!cldfmcl || !ciwpmcl || !clwpmcl || !reicmcl || !relqmcl || !taucmcl) return fail(RRTMG_LW_HIP_EARG, "null output array");
+    const int rng = *irng;
+    auto range = [&](int c0, int c1) -> int {
+        return subcol_host_range(ncol, c0, c1, nlay, icld, permuteseed, rng, play, cldfrac, ciwp, clwp, rei, rel, tauc, alpha,
+                                 cldfmcl, ciwpmcl, clwpmcl, reicmcl, relqmcl, taucmcl);
+    };
+    if (rng != 0) return range(0, ncol);          // one Mersenne-Twister stream over all columns (:497-503): the first device draws it
+    return fan_out(ncol, range);                  // kissvec: a stream per column (:463-474)
 }
 
 // Fused generator + solver: mcica_subcol_lw followed by the McICA rrtmg_lw without materialising the (140,ncol,nlay)
@@ -2479,35 +2774,33 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     return run_pipelined(s, ncol, nlay, mode, idrv, g, inflglw, iceflglw, liqflglw, out, nullptr, gen);
 }
 
-int rrtmg_lw_hip_run_mcica_subcol(
-    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+// columns [c0, c1) of the fused generator + solver call on the calling thread's current device state (kissvec seeds its stream per
+// column, src/mcica_subcol_gen_lw.f90:463-474: a block of columns is generated and solved on its own; the Mersenne-Twister stream is one
+// sequence over all columns of a call, :497-503, and is drawn with c0 = 0, c1 = ncol only)
+static int mcica_subcol_host_range(
+    int ncol, int c0, int c1, int nlay, int icld_gen, int idrv, int permuteseed, int irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
     const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
     const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS)
 {
-    ENTRY_LOCK;
-    if (int rc = check_mcica_build()) return rc;
-    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
-    if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
-    if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
-    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
-    const int icld_gen = *icld;
-    if (*icld > 3) *icld = 2;
+    if (int rc = check_common(ncol, nlay)) return rc;
+    HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     const int mode = icld_gen == 0 ? 0 : 3;
     const bool cloud = mode == 3, two = icld_gen == 4 || icld_gen == 5;
-    const int nbmax = balanced_batch(ncol, std::min(G.batch, HOST_BATCH));
+    const int nloc = c1 - c0;
+    const int nbmax = balanced_batch(nloc, std::min(G.batch, HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, cloud, false)) return rc;
-    const size_t L = (size_t)nlay, n = (size_t)ncol;
+    const size_t L = (size_t)nlay, n = (size_t)ncol, nl = (size_t)nloc;
     hipStream_t s = G.stream;
-    // 1. masks of all columns (the Mersenne-Twister stream couples the columns): needs play, cldfr, alpha of every column
+    // 1. masks of the block's columns: needs play, cldfr, alpha of every one of them
     double *d_gen = nullptr;
     if (cloud) {
         if (!play || !cldfr || (two && !alpha)) return fail(RRTMG_LW_HIP_EARG, "null generator input");
-        HIP_TRY(hipMalloc((void **)&d_gen, n * L * 8 * 3));
+        HIP_TRY(hipMalloc((void **)&d_gen, nl * L * 8 * 3));
         // (through the library's own pinned buffer: see bounce_h2d)
-        int rc = bounce_h2d(d_gen, play, n * L * 8);
-        if (rc == 0) rc = bounce_h2d(d_gen + n * L, cldfr, n * L * 8);
-        if (rc == 0 && two) rc = bounce_h2d(d_gen + 2 * n * L, alpha, n * L * 8);
-        if (rc == 0) rc = generate_mask(s, ncol, nlay, icld_gen, permuteseed, *irng, d_gen, d_gen + n * L, two ? d_gen + 2 * n * L : nullptr);
+        int rc = bounce_h2d_rows(d_gen, play + c0, nl * 8, n * 8, L);
+        if (rc == 0) rc = bounce_h2d_rows(d_gen + nl * L, cldfr + c0, nl * 8, n * 8, L);
+        if (rc == 0 && two) rc = bounce_h2d_rows(d_gen + 2 * nl * L, alpha + c0, nl * 8, n * 8, L);
+        if (rc == 0) rc = generate_mask(s, nloc, nlay, icld_gen, permuteseed, irng, d_gen, d_gen + nl * L, two ? d_gen + 2 * nl * L : nullptr);
         if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(RRTMG_LW_HIP_EHIP, "generator failed");
         (void)hipFree(d_gen);
         if (rc) return rc;
@@ -2523,20 +2816,44 @@ int rrtmg_lw_hip_run_mcica_subcol(
     if (cloud) for (size_t k = 17; k < ins.size(); k++) if (!ins[k].h) return fail(RRTMG_LW_HIP_EARG, "null cloud array");
     std::vector<HostOut> outs = {{uflx, L + 1, 0, true}, {dflx, L + 1, 0, true}, {hr, L, 0, true}, {uflxc, L + 1, 0, true},
                                  {dflxc, L + 1, 0, true}, {hrc, L, 0, true}, {duflx_dt, L + 1, 0, idrv == 1}, {duflxc_dt, L + 1, 0, idrv == 1}};
+    for (size_t k = 0; k < 6; k++) if (!outs[k].h) return fail(RRTMG_LW_HIP_EARG, "null output array");
     auto body = [&](hipStream_t bs, int nb, int col0, std::vector<HostIn> &in, std::vector<HostOut> &out_) -> int {
         GcmIn g{in[0].d, in[1].d, in[2].d, in[3].d, in[4].d, in[5].d, in[6].d, in[7].d, in[8].d, in[9].d, in[10].d,
                 in[11].d, in[12].d, in[13].d, in[14].d, in[15].d, in[17].d, in[18].d, in[19].d, in[20].d, in[21].d, in[22].d, in[16].d};
         ColIn c{};
         FluxOut out{out_[0].d, out_[1].d, out_[2].d, out_[3].d, out_[4].d, out_[5].d, out_[6].d, out_[7].d, nullptr, nullptr};
-        G.W.mask_col0 = (size_t)col0;                             // staged arrays start at column 0, the mask holds all columns
+        G.W.mask_col0 = (size_t)(col0 - c0);                      // staged arrays start at column 0, the mask holds the block's columns
         return run_batch<true>(bs, nb, 0, nb, nlay, mode, idrv, 1, 16, g, c, inflglw, iceflglw, liqflglw, out, nullptr);
     };
     {
-        const int rc = host_pipeline(ncol, 0, ncol, nbmax, ins, outs, body);
+        const int rc = host_pipeline(ncol, c0, c1, nbmax, ins, outs, body);
         if (rc) { G.W.mask_col0 = 0; return rc; }
     }
     G.W.mask_col0 = 0;
     return read_physics_error(s);
+}
+
+int rrtmg_lw_hip_run_mcica_subcol(
+    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
+    const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS)
+{
+    ENTRY_LOCK;
+    if (int rc = check_mcica_build()) return rc;
+    if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
+    if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
+    if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
+    const int icld_gen = *icld, rng = *irng;
+    if (*icld > 3) *icld = 2;
+    auto range = [&](int c0, int c1) -> int {
+        return mcica_subcol_host_range(ncol, c0, c1, nlay, icld_gen, idrv, permuteseed, rng, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr,
+                                       n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis, inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp,
+                                       reice, reliq, alpha, tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
+    };
+    // the Mersenne-Twister stream (irng = 1) is ONE sequence over the (sub-column, column, layer) draws of the call
+    // (src/mcica_subcol_gen_lw.f90:497-503): a column's deviates depend on every column before it, so the call stays on the first device
+    if (rng != 0 && icld_gen != 0) return range(0, ncol);
+    return fan_out(ncol, range);
 }
 
 }  // extern "C"

@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
     }
     double amttl = 0.0, wvttl = 0.0, pzlo = pz0;
     int laytrop = 0;
+    // (a thread walks its column alone: unrolled, the loads of eight layers are in flight together instead of one round trip per layer -
+    // on the critical path of every call that is a single batch)
+#pragma unroll 8
     for (int lay = 1; lay <= nlay; lay++) {
         const size_t gi = gc + (size_t)nct * (lay - 1);
         const double pavel = GCM ? g.play[gi] : c.pavel[gi];
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
     const size_t ncb = W.ncolb;
     bool prevcld = false, rat1 = false, rat2 = false;       // upward sweep order = this loop's order
     double cfprev = 0.0;
+#pragma unroll 4
     for (int lay = 1; lay <= nlay; lay++) {
         const size_t gi = gc + (size_t)nct * (lay - 1);
         const double cf = cldfr[gi], ciwp = ciwp_[gi], clwp = clwp_[gi];
@@ -501,7 +505,7 @@ constexpr int SORT_MAXLAY = 603;                // parrrtm.f90:31 mxlay
 __host__ __device__ constexpr int nsb_fit(int n) { return n >= 12 ? 12 : n >= 6 ? 6 : n >= 4 ? 4 : n >= 3 ? 3 : n >= 2 ? 2 : 1; }
 __host__ __device__ constexpr int sort_slots(int nblk) { return (nblk + SORT_GROUP - 1) / SORT_GROUP * SORT_GROUP; }
 
-__global__ __launch_bounds__(256) void k_blocksort(Workspace W, int nblk)
+__global__ __launch_bounds__(256) void k_blocksort(Workspace W, int nblk, int force_top)
 {
     __shared__ unsigned short s_top[SORT_MAXBLK];
     __shared__ int s_cnt[SORT_MAXLAY + 1], s_start[SORT_MAXLAY + 1], s_gtop[SORT_MAXBLK / SORT_GROUP + 1];
@@ -534,8 +538,13 @@ __global__ __launch_bounds__(256) void k_blocksort(Workspace W, int nblk)
         int lo = 0, hi = nlay;                  // largest u with s_start[nlay - u] <= q
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_start[nlay - mid] <= q) lo = mid; else hi = mid - 1; }
         while (lo > 0 && s_cnt[nlay - lo] == 0) lo--;      // (an empty run at the end of equal starts)
-        s_gtop[g] = nlay - lo;
-        W.hgrp[g] = nlay - lo;
+        // force_top (a batch too small to fill the chip): every group hands off at the top of the column, i.e. the cloud-zone sweep walks
+        // all levels - with its clear-sky body below the lowest cloud and its clear-sky branch above the highest - and the two clear-sky
+        // launches, each a latency chain of its own, are not made (driver.hip: one_sweep).  Same numbers: a level's partial does not depend
+        // on the kernel that swept it.
+        const int top = force_top ? nlay : nlay - lo;
+        s_gtop[g] = top;
+        W.hgrp[g] = top;
     }
     __syncthreads();
     // placement by the first wave, 64 blocks at a time in block order: the lanes that hold the same value as the first unplaced lane take
@@ -3179,6 +3188,11 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         for (int k = 0; k < G; k++) {
             const double2 h0 = hand[(size_t)k * ncb * 2], h1 = hand[(size_t)k * ncb * 2 + 1];
             rad[4 * k] = h0.x; rad[4 * k + 1] = h0.y; rad[4 * k + 2] = h1.x; rad[4 * k + 3] = h1.y;
+        }
+        if (ltop == nlay) {         // the zone reaches the top of the column: nothing comes down into it (rtrn :352 radld = 0); with the zone
+#pragma unroll                      // kernel walking all levels (k_blocksort, force_top) no clear-sky launch has written the hand-off array
+            for (int j = 0; j < NG; j++) rad[j] = 0.0;
+            if (incol && ty == 0) bstore_f64(W.gdn1 + gslab + (size_t)nlay * ncb, (unsigned)col * 8u, 0.0);      // downward flux at the top level
         }
 #pragma unroll
         for (int j = 0; j < NG; j++) radc[j] = rad[j];

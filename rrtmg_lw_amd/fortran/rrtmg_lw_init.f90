@@ -39,6 +39,18 @@
             type(c_ptr), value :: ptr
             integer(c_int) :: rc
          end function rrtmg_lw_hip_host_unregister
+         function rrtmg_lw_hip_host_static(ptr, bytes) bind(C, name='rrtmg_lw_hip_host_static') result(rc)
+            import :: c_ptr, c_long_long, c_int
+            type(c_ptr), value :: ptr
+            integer(c_long_long), value :: bytes
+            integer(c_int) :: rc
+         end function rrtmg_lw_hip_host_static
+         function rrtmg_lw_hip_host_changed(ptr, keep) bind(C, name='rrtmg_lw_hip_host_changed') result(rc)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: ptr
+            integer(c_int), value :: keep
+            integer(c_int) :: rc
+         end function rrtmg_lw_hip_host_changed
          function rrtmg_lw_hip_gpoints() bind(C, name='rrtmg_lw_hip_gpoints') result(n)
             import :: c_int
             integer(c_int) :: n        ! ngptlw of the linked library: 140, or 256 (librrtmg_lw_hip_g256.so)
@@ -128,6 +140,34 @@
       endif
       if (rrtmg_lw_hip_host_unregister(c_loc(a)) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_unpin')
       end subroutine rrtmg_lw_unpin
+
+!  Optional: declare an input array of rrtmg_lw STATIC - it keeps its contents from call to call (well-mixed gases, aerosol optical depths
+!  that are set once, emissivities): rrtmg_lw then looks at its rows once instead of on every call.  After changing such an array:
+!  call rrtmg_lw_changed(a); before deallocating it: call rrtmg_lw_changed(a, .false.).  `a` is the whole, contiguous array.
+      subroutine rrtmg_lw_static(a)
+      real(kind=rb), intent(in), target :: a(..)
+      if (size(a) < 1) return
+      if (.not. is_contiguous(a)) then
+         write(*,*) 'rrtmg_lw_static: the array is not contiguous (pass the whole array, not a section)'
+         error stop 1
+      endif
+      if (rrtmg_lw_hip_host_static(c_loc(a), int(size(a), c_long_long) * 8_c_long_long) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_static')
+      end subroutine rrtmg_lw_static
+
+      subroutine rrtmg_lw_changed(a, keep)
+      real(kind=rb), intent(in), target :: a(..)
+      logical, intent(in), optional :: keep
+      integer(c_int) :: k
+      k = 1_c_int
+      if (present(keep)) then
+         if (.not. keep) k = 0_c_int
+      endif
+      if (.not. is_contiguous(a)) then
+         write(*,*) 'rrtmg_lw_changed: the array is not contiguous (pass the whole array that was declared)'
+         error stop 1
+      endif
+      if (rrtmg_lw_hip_host_changed(c_loc(a), k) /= 0) call rrtmg_lw_hip_abort('rrtmg_lw_changed')
+      end subroutine rrtmg_lw_changed
 
 !  Turns a non-zero status of the C ABI into the reference's behaviour: print the message and stop.
       subroutine rrtmg_lw_hip_abort(where)

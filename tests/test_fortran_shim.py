@@ -144,6 +144,58 @@ def test_fortran_host_model_with_chunk_queue(tmp_path, oracle, config, icld, chu
         assert np.abs(got - ref[k]).max() <= 5e-5, k
 
 
+def _compile_omp(tmp, link):
+    objs = []
+    for f in ("parkind.f90", "rrtmg_lw_init.f90", "rrtmg_lw_rad.nomcica.f90"):
+        o = os.path.join(tmp, f + ".o")
+        subprocess.run([FLANG, "-c", "-O2", "-fPIC", os.path.join(SHIM, f), "-o", o], check=True, cwd=tmp)
+        objs.append(o)
+    drv = os.path.join(tmp, "drive_omp.o")
+    subprocess.run([FLANG, "-fopenmp", "-c", "-O2", os.path.join(ROOT, "tests", "fortran", "drive_omp.f90"), "-o", drv], check=True, cwd=tmp)
+    if not link:
+        return None
+    exe = os.path.join(tmp, "drive_omp")
+    libdir = os.path.join(ROOT, "rrtmg_lw_amd")
+    subprocess.run([FLANG, "-fopenmp", "-o", exe, drv, *objs, f"-L{libdir}", "-lrrtmg_lw_hip", f"-Wl,-rpath,{libdir}"], check=True, cwd=tmp)
+    return exe
+
+
+@needs_flang
+def test_openmp_host_model_compiles(tmp_path):
+    _compile_omp(str(tmp_path), link=False)
+
+
+@needs_flang
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,icld,chunk,threads", [("cloudy", 2, 64, 16), ("aer_idrv", 1, 24, 5)])
+def test_openmp_host_model_calls_rrtmg_lw_from_many_threads(tmp_path, oracle, config, icld, chunk, threads):
+    """An OpenMP host model (flang -fopenmp) calls rrtmg_lw UNCHANGED per chunk of columns from all its threads (hosts thread
+    over calls).  Calls that arrive while another is in flight are solved together (driver.hip: comb_call): same numbers as one thread
+    calling chunk after chunk, bit for bit, and the oracle's; the driver prints both wall times (profiles/round4_concurrent_callers.md)."""
+    tmp = str(tmp_path)
+    exe = _compile_omp(tmp, link=True)
+    ncol, nlay = 64 * 128 + 17, 40
+    d = make_gcm_inputs(ncol, nlay, config, col0=5)
+    _write_nomcica_inputs(os.path.join(tmp, "in.bin"), d, ncol, nlay, icld)
+    env = dict(os.environ, RRTMG_LW_STATIC_TABLES=os.path.join(ROOT, "rrtmg_lw_amd", "data", "lw_static.bin"),
+               RRTMG_LW_KDATA=os.path.join(ROOT, "rrtmg_lw_amd", "data", "standin.kdata.bin"), OMP_NUM_THREADS=str(threads))
+    r = subprocess.run([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin"), str(chunk)], check=True, env=env, cwd=tmp, timeout=600,
+                       capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert "max_abs_diff_omp_vs_serial= 0.000E+00" in r.stdout
+    raw = open(os.path.join(tmp, "out.bin"), "rb").read()
+    a = np.frombuffer(raw, dtype=np.float64, offset=4)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, d["idrv"], d)
+    pos = 0
+    for k, nl in (("uflx", nlay + 1), ("dflx", nlay + 1), ("hr", nlay), ("uflxc", nlay + 1), ("dflxc", nlay + 1), ("hrc", nlay),
+                  ("duflx_dt", nlay + 1), ("duflxc_dt", nlay + 1)):
+        got = a[pos:pos + ncol * nl].reshape((ncol, nl), order="F")
+        pos += ncol * nl
+        if k.startswith("du") and d["idrv"] != 1:
+            continue
+        assert np.abs(got - ref[k]).max() <= 5e-5, k
+
+
 @needs_flang
 def test_oversized_host_model_compiles(tmp_path):
     _compile(str(tmp_path), link=False, prog="drive_shim_ld")

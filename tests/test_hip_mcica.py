@@ -8,6 +8,7 @@ import pytest
 from rrtmg_lw_amd.synth import make_gcm_inputs
 
 pytestmark = pytest.mark.gpu
+from test_hip_parity import sweeps  # noqa: E402,F401  (fixture: one / three sweep launches)
 
 FLUX_TOL = 0.01      # W m-2     (BASELINE.json north_star)
 HR_TOL = 0.001       # K day-1
@@ -200,7 +201,7 @@ def test_mcica_entry_ignores_subcolumn_arrays_where_no_subcolumn_has_cloud(hip, 
 
 
 @pytest.mark.parametrize("icld", [2, 5])
-def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld):
+def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld, sweeps):
     """rtrnmc through the array entry and through the fused generator entry on cloud decks whose top differs from one 64-column
     block to the next (0 / 14 / nlay / 1 ...): the hand-off level between the clear-sky sweeps and the cloud-zone sweep is per group
     of blocks (k_blocksort), the generator's own walk ends per 16 columns."""
@@ -219,6 +220,34 @@ def test_mcica_cloud_top_changes_from_block_to_block(hip, oracle, icld):
     for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
         assert np.array_equal(got[k], fused[k]), k
     assert np.abs(ref["dflx"] - ref["dflxc"]).max() > 1.0
+
+
+def test_fused_entry_and_generator_fan_out_over_devices(hip, oracle):
+    """rrtmg_lw_hip_init_devices with three (virtual) devices: the fused generator + solver host entry and the stand-alone generator split
+    their columns over the devices when the generator is kissvec (a stream per column, src/mcica_subcol_gen_lw.f90:463-474) - results and
+    masks equal the one-device call bit for bit, for exponential-random overlap as well; with the Mersenne Twister (ONE stream over all
+    columns, :497-503) the call stays on the first device and still gives the same numbers."""
+    ncol, nlay = 1100, 40
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=8)
+    dz, lat = _geometry(ncol, nlay)
+    alpha = oracle.get_alpha(ncol, nlay, 5, 0, 2500.0, dz, lat, 100, d["cldfr"])
+    cases = [(2, 0, None), (5, 0, alpha), (2, 1, None)]
+    one = [hip.rrtmg_lw_mcica_subcol_from_dict(d, 7, irng, icld=icld, alpha=al) for icld, irng, al in cases]
+    one_gen = [hip.mcica_subcol_lw(ncol, nlay, icld, 7, irng, *_gen_args(d), alpha=al) for icld, irng, al in cases]
+    try:
+        hip.init_devices([0, 0, 0], kdata=hip.STANDIN_KDATA)
+        three = [hip.rrtmg_lw_mcica_subcol_from_dict(d, 7, irng, icld=icld, alpha=al) for icld, irng, al in cases]
+        three_gen = [hip.mcica_subcol_lw(ncol, nlay, icld, 7, irng, *_gen_args(d), alpha=al) for icld, irng, al in cases]
+    finally:
+        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+    for a, b, (icld, irng, _) in zip(one, three, cases):
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+            assert np.array_equal(a[k], b[k]), (icld, irng, k)
+    for a, b, (icld, irng, _) in zip(one_gen, three_gen, cases):
+        for k in SUB:
+            assert np.array_equal(a[k], b[k]), (icld, irng, k)
+    sc = oracle.mcica_subcol(ncol, nlay, 5, 7, 0, *_gen_args(d), alpha)
+    assert np.array_equal(three_gen[1]["cldfmcl"], sc["cldfmcl"])
 
 
 def test_mcica_tallest_column(hip, oracle):

@@ -20,6 +20,15 @@ TIGHT_FLUX = 5e-5
 TIGHT_HR = 5e-5
 
 
+@pytest.fixture(params=["three sweep launches", "one sweep launch"])
+def sweeps(request, hip):
+    """Cloudy batches of up to 4096 columns take one sweep launch per band group (the cloud-zone kernel over all levels) instead of three
+    (rrtmg_lw_hip_set_one_sweep_max): the tests of the cloud structure run both ways."""
+    prev = hip.set_one_sweep_max(0 if request.param.startswith("three") else 1 << 30)
+    yield request.param
+    hip.set_one_sweep_max(prev)
+
+
 def _compare(got, ref, idrv, tag):
     dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
     dhr = max(np.abs(got[k] - ref[k]).max() for k in ("hr", "hrc"))
@@ -301,7 +310,7 @@ def _special_cloud_inputs(ncol, nlay, kind):
 
 @pytest.mark.parametrize("kind", ["inflag0", "overcast", "thin", "toplayer", "bottomonly", "nocloud"])
 @pytest.mark.parametrize("icld", [1, 2])
-def test_special_cloud_configurations(hip, oracle, kind, icld):
+def test_special_cloud_configurations(hip, oracle, kind, icld, sweeps):
     ncol, nlay = 300, 60
     d = _special_cloud_inputs(ncol, nlay, kind)
     got = hip.rrtmg_lw_from_dict(d, icld=icld)
@@ -370,7 +379,7 @@ def _block_top_inputs(ncol, nlay, tops, seed=5, bases=None):
 
 @pytest.mark.parametrize("icld", [1, 2])
 @pytest.mark.parametrize("idrv", [0, 1])
-def test_cloud_top_changes_from_block_to_block(hip, oracle, icld, idrv):
+def test_cloud_top_changes_from_block_to_block(hip, oracle, icld, idrv, sweeps):
     """The sweeps hand over between the clear-sky kernels and the cloud-zone kernel at a level chosen per group of 64-column blocks
     (k_blocksort): neighbouring blocks with tops 0 / 14 / nlay / 1 / ..., more blocks than one hand-off group, a ragged last block."""
     nlay = 60
@@ -384,7 +393,7 @@ def test_cloud_top_changes_from_block_to_block(hip, oracle, icld, idrv):
 
 @pytest.mark.parametrize("icld", [1, 2])
 @pytest.mark.parametrize("idrv", [0, 1])
-def test_cloud_base_changes_from_block_to_block(hip, oracle, icld, idrv):
+def test_cloud_base_changes_from_block_to_block(hip, oracle, icld, idrv, sweeps):
     """Below the lowest cloud of a group of blocks the cloud-zone sweep runs its clear-sky levels without the cloudy-level inputs
     (k_sweepz, layers 1 .. lbot - 1): decks with bases at layers 1 / 9 / 30 / top (one-layer decks) / nlay, next to blocks without cloud."""
     nlay = 60
@@ -399,7 +408,7 @@ def test_cloud_base_changes_from_block_to_block(hip, oracle, icld, idrv):
 
 
 @pytest.mark.parametrize("config", ["cloudy_deep", "cloudy_towers", "cloudy_scatter"])
-def test_cloud_field_variants(hip, oracle, config):
+def test_cloud_field_variants(hip, oracle, config, sweeps):
     ncol, nlay = 1500, 72
     d = make_gcm_inputs(ncol, nlay, config, col0=31 * 1000)
     got = hip.rrtmg_lw_from_dict(d)
@@ -575,7 +584,7 @@ def test_several_devices_from_one_process(hip, oracle):
 
 
 @pytest.mark.parametrize("icld,idrv,ncol", [(2, 1, 70), (0, 0, 65), (1, 0, 64)])
-def test_tallest_column_the_interface_accepts(hip, oracle, icld, idrv, ncol):
+def test_tallest_column_the_interface_accepts(hip, oracle, icld, idrv, ncol, sweeps):
     """nlay = 603 = mxlay of modules/parrrtm.f90:31, the largest value the entries accept: level tiles of k_flux, the sweeps' level loops,
     k_blocksort's histogram, 603 k_layer rows.  (Layers down to 0.002 hPa thick.)"""
     nlay = 603
@@ -616,6 +625,177 @@ def test_device_entry_from_two_streams(hip, oracle):
         got = {k: o[k][:, :200].T.cpu().numpy() for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")}
         got["icld"] = ref["icld"]
         _compare(got, ref, 0, f"two streams, col0={d0}")
+
+
+@pytest.mark.parametrize("config,mcica", [("cloudy", 0), ("aer_idrv", 0), ("cloudy", 5)])
+def test_overlap_and_cu_partition_are_transparent(hip, config, mcica):
+    """Device-pointer entries: k_layer of batch i + 1 beside the sweeps of batch i (rrtmg_lw_hip_set_overlap), and the two on their own
+    compute units (rrtmg_lw_hip_set_cu_partition: streams with a CU mask; first / last batch on the whole chip) - several batches, the
+    caller's stream the null stream and a stream of its own: the packed outputs equal the plain pipeline's bit for bit."""
+    import torch
+    from rrtmg_lw_amd.shard import output_rows, output_views
+    dev = torch.device("cuda", 0)
+    ncol, nlay = 5000, 40
+    d = make_gcm_inputs(ncol, nlay, config, col0=77, backend="torch", device=dev)
+    idrv = d["idrv"]
+    alpha = None
+    if mcica:
+        dz = 29.2717 * d["tlay"] * torch.log(d["plev"][:, :-1] / d["plev"][:, 1:])
+        a = torch.exp(-0.5 * (dz[:, 1:] + dz[:, :-1]) / 2500.0)
+        alpha = torch.cat([torch.zeros_like(a[:, :1]), a], dim=1).t().contiguous().t()
+
+    def run(stream):
+        buf = torch.zeros((output_rows(nlay, idrv), ncol), dtype=torch.float64, device=dev)
+        o = output_views(buf, nlay, idrv)
+        if mcica:
+            hip.rrtmg_lw_mcica_subcol_device(d, o, 1, 0, alpha=alpha, icld=mcica, stream=stream)
+        else:
+            hip.rrtmg_lw_device(d, o, stream=stream)
+        hip.check(stream)
+        return buf.cpu().numpy().view(np.int64)
+
+    own = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    hip.set_batch(1024)
+    try:
+        plain = run(0)
+        hip.set_overlap(True)
+        over = run(0)
+        hip.set_cu_partition(96)
+        assert hip.cu_partition() == 96
+        part0, part1 = run(0), run(own.cuda_stream)
+        hip.set_cu_partition(200)                      # (rounded to the XCD count: 8 CUs per XCD left for the sweeps)
+        assert hip.cu_partition() == 200
+        part2 = run(own.cuda_stream)
+    finally:
+        hip.set_cu_partition(0)
+        hip.set_overlap(False)
+        hip.set_batch(131072)
+    assert hip.cu_partition() == 0
+    for other in (over, part0, part1, part2):
+        assert np.array_equal(plain, other)
+
+
+@pytest.mark.parametrize("config,icld,idrv,mcica", [("cloudy", 2, 0, 0), ("cloudy_deep", 1, 1, 0), ("cloudy_towers", 2, 1, 0), ("cloudy", 2, 0, 5), ("cloudy_scatter", 2, 0, 2)])
+def test_one_sweep_launch_is_transparent(hip, oracle, config, icld, idrv, mcica):
+    """The cloud-zone kernel over all levels (small batches) against the three launches: the outputs are equal bit for bit - non-McICA
+    rtrn / rtrnmr with and without d/dT, and the fused McICA entry (mask flavour of rtrnmc)."""
+    ncol, nlay = 1700, 72
+    d = make_gcm_inputs(ncol, nlay, config, col0=3)
+
+    def run():
+        if mcica:
+            dz = np.full((ncol, nlay), 400.0)
+            alpha = oracle.get_alpha(ncol, nlay, mcica, 0, 2500.0, dz, np.zeros(ncol), 100, d["cldfr"])
+            return hip.rrtmg_lw_mcica_subcol_from_dict(d, 3, 0, icld=mcica, alpha=alpha, idrv=idrv)
+        return hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+
+    prev = hip.set_one_sweep_max(0)
+    try:
+        three = run()
+        assert hip.set_one_sweep_max(1 << 30) == 0
+        one = run()
+    finally:
+        hip.set_one_sweep_max(prev)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if idrv else ()):
+        assert np.array_equal(three[k], one[k]), k
+
+
+def test_static_arrays_are_scanned_once(hip, oracle):
+    """rrtmg_lw_hip_host_static: the row scans of a declared array are kept per column batch; rrtmg_lw_hip_host_changed drops them.  Same
+    numbers with and without the declaration, over several batches; a change announced by host_changed is seen, rows of a static array
+    that are not uniform still travel (a gas profile that varies from column to column), and withdrawing the declaration works."""
+    ncol, nlay = 2500, 40
+    d = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=21)
+    hip.set_batch(1024)
+    try:
+        want = hip.rrtmg_lw_from_dict(d, icld=2)
+        static = [d[k] for k in ("tauaer", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "emis", "o3vmr")]     # (o3vmr varies per column: non-uniform rows)
+        for a in static:
+            hip.host_static(a)
+        first = hip.rrtmg_lw_from_dict(d, icld=2)
+        second = hip.rrtmg_lw_from_dict(d, icld=2)                # every declared row comes from the cache
+        co2 = d["co2vmr"]
+        co2 *= 2.0                                                # the host model changes a static array ...
+        hip.host_changed(co2)                                     # ... and says so
+        changed = hip.rrtmg_lw_from_dict(d, icld=2)
+        ref = oracle.rrtmg_lw(ncol, nlay, 2, d["idrv"], d)
+        aer = d["tauaer"]
+        aer[:, :5, :] *= 0.5
+        hip.host_changed(aer, keep=False)                         # declaration withdrawn: scanned on every call again
+        undeclared = hip.rrtmg_lw_from_dict(d, icld=2)
+        ref2 = oracle.rrtmg_lw(ncol, nlay, 2, d["idrv"], d)
+        with pytest.raises(hip.RrtmgLwError, match="no static range"):
+            hip.host_changed(aer)
+    finally:
+        for a in static:
+            try:
+                hip.host_changed(a, keep=False)
+            except hip.RrtmgLwError:
+                pass
+        hip.set_batch(131072)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt"):
+        assert np.array_equal(want[k], first[k]) and np.array_equal(want[k], second[k]), k
+    assert np.abs(changed["uflx"] - want["uflx"]).max() > 0.1
+    _compare(changed, ref, 1, "static co2vmr doubled, host_changed")
+    _compare(undeclared, ref2, 1, "tauaer halved after its declaration was withdrawn")
+
+
+def test_concurrent_callers_are_combined(hip, oracle):
+    """Several threads call the host-pointer entry at once with chunks of a few columns (an OpenMP host model): calls that arrive while
+    another is in flight are solved together in one device pass (driver.hip, comb_call).  Every chunk's result equals that of the same
+    columns in one big call bit for bit, a chunk with a physics error fails alone, and fewer passes than calls were made."""
+    import threading
+    ncol, nlay, chunk, nthreads = 1536, 40, 32, 8
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=64)
+    whole = hip.rrtmg_lw_from_dict(d)
+    keys = [k for k, v in d.items() if isinstance(v, np.ndarray)]
+
+    def part(c0, c1):
+        p = dict(d)
+        p["ncol"] = c1 - c0
+        for k in keys:
+            v = d[k]
+            if v.ndim == 1:
+                p[k] = np.ascontiguousarray(v[c0:c1])
+            elif k == "taucld":
+                p[k] = np.asfortranarray(v[:, c0:c1, :])
+            else:
+                p[k] = np.asfortranarray(v[c0:c1])
+        return p
+
+    chunks = [part(c0, min(ncol, c0 + chunk)) for c0 in range(0, ncol, chunk)]
+    bad = 17
+    r = np.array(chunks[bad]["reice"]); r[3, 8] = 500.0
+    chunks[bad]["reice"] = np.asfortranarray(r)
+    for k, v in (("cldfr", 0.5), ("cicewp", 10.0)):
+        a = np.array(chunks[bad][k]); a[3, 8] = v; chunks[bad][k] = np.asfortranarray(a)
+    results, errors = [None] * len(chunks), [None] * len(chunks)
+    calls0, passes0 = hip.combine_stats()
+
+    def worker(t):
+        for rep in range(2):                                      # (the second round finds the others in flight for certain)
+            for i in range(t, len(chunks), nthreads):
+                try:
+                    results[i] = hip.rrtmg_lw_from_dict(chunks[i])
+                except hip.RrtmgLwError as e:
+                    errors[i] = str(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    calls, passes = hip.combine_stats()
+    print(f"combining entry: {calls - calls0} calls in {passes - passes0} device passes")
+    assert calls - calls0 == 2 * len(chunks) and passes - passes0 < calls - calls0
+    for i, c0 in enumerate(range(0, ncol, chunk)):
+        if i == bad:
+            assert errors[i] and "ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS" in errors[i]
+            continue
+        assert errors[i] is None, (i, errors[i])
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+            assert np.array_equal(results[i][k], whole[k][c0:c0 + chunk]), (i, k)
 
 
 @pytest.mark.parametrize("icld,lo", [(2, 0.45), (0, 0.70)])
