@@ -2491,8 +2491,19 @@ int comb_call(CallReq &me)
         // The callers the previous pass served come back within the time of a call's return trip: a pass that starts the moment the first of
         // them is here serves that one alone while the others queue up behind it (measured: passes of 1 and 15 chunks in turn).  Wait for as
         // many as there were, a fraction of a pass's own time at most; a single-threaded host (previous pass: one request) never waits.
-        if (g_comb_last > 1)
-            g_comb_arrive.wait_for(lk, std::chrono::microseconds(COMBINE_WAIT_US), [&] { return g_comb_pending.size() >= g_comb_last; });
+        // The window adapts: a wait that ended with everybody here keeps (or restores) it, one that ran out halves it - two threads of
+        // which one comes back only after ten milliseconds of its own work must not cost the other 250 us per call - and every 64th pass
+        // tries a short window again.
+        if (g_comb_last > 1) {
+            static int window_us = COMBINE_WAIT_US;
+            static unsigned npass = 0;
+            int w = window_us;
+            if (w < 20 && (++npass & 63u) == 0u) w = std::min(60, COMBINE_WAIT_US);
+            if (w >= 20) {
+                const bool all = g_comb_arrive.wait_for(lk, std::chrono::microseconds(w), [&] { return g_comb_pending.size() >= g_comb_last; });
+                window_us = all ? std::min(COMBINE_WAIT_US, std::max(60, 2 * w)) : w / 2;
+            }
+        }
         std::vector<CallReq *> batch;
         batch.swap(g_comb_pending);
         g_comb_last = batch.size();

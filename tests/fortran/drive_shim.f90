@@ -2,10 +2,10 @@
 ! (use rrtmg_lw_init / use rrtmg_lw_rad), reading its inputs from a stream file written by tests/test_fortran_shim.py.
 program drive_shim
   use parkind, only: im => kind_im, rb => kind_rb
-  use rrtmg_lw_init, only: rrtmg_lw_ini, rrtmg_lw_pin, rrtmg_lw_unpin
+  use rrtmg_lw_init, only: rrtmg_lw_ini, rrtmg_lw_pin, rrtmg_lw_unpin, rrtmg_lw_static, rrtmg_lw_changed
   use rrtmg_lw_rad, only: rrtmg_lw
   implicit none
-  integer(im) :: ncol, nlay, icld, idrv, inflg, iceflg, liqflg
+  integer(im) :: ncol, nlay, icld, idrv, inflg, iceflg, liqflg, icld0
   integer :: hdr(7), u
   real(rb), allocatable :: play(:,:), plev(:,:), tlay(:,:), tlev(:,:), tsfc(:), gas(:,:,:), emis(:,:)
   real(rb), allocatable :: cld(:,:,:), taucld(:,:,:), tauaer(:,:,:)
@@ -37,6 +37,25 @@ program drive_shim
      call rrtmg_lw_pin(tauaer, size(tauaer)); call rrtmg_lw_pin(uflx, size(uflx)); call rrtmg_lw_pin(dflx, size(dflx))
      call rrtmg_lw_pin(hr, size(hr)); call rrtmg_lw_pin(uflxc, size(uflxc)); call rrtmg_lw_pin(dflxc, size(dflxc))
      call rrtmg_lw_pin(hrc, size(hrc)); call rrtmg_lw_pin(du, size(du)); call rrtmg_lw_pin(duc, size(duc))
+     ! ... and declares what it sets once static (rrtmg_lw_static): a first call fills the scan cache, the aerosol optical depths are then
+     ! scaled and the change announced (rrtmg_lw_changed), scaled back and announced again - the call below must see the original values
+     call rrtmg_lw_static(tauaer); call rrtmg_lw_static(emis); call rrtmg_lw_static(gas)
+     icld0 = icld
+     call rrtmg_lw(ncol, nlay, icld0, idrv, play, plev, tlay, tlev, tsfc, &
+                   gas(:,:,1), gas(:,:,2), gas(:,:,3), gas(:,:,4), gas(:,:,5), gas(:,:,6), &
+                   gas(:,:,7), gas(:,:,8), gas(:,:,9), gas(:,:,10), emis, inflg, iceflg, liqflg, &
+                   cld(:,:,1), taucld, cld(:,:,2), cld(:,:,3), cld(:,:,4), cld(:,:,5), tauaer, &
+                   uflx, dflx, hr, uflxc, dflxc, hrc, du, duc)
+     tauaer = 4._rb * tauaer
+     call rrtmg_lw_changed(tauaer)
+     icld0 = icld
+     call rrtmg_lw(ncol, nlay, icld0, idrv, play, plev, tlay, tlev, tsfc, &
+                   gas(:,:,1), gas(:,:,2), gas(:,:,3), gas(:,:,4), gas(:,:,5), gas(:,:,6), &
+                   gas(:,:,7), gas(:,:,8), gas(:,:,9), gas(:,:,10), emis, inflg, iceflg, liqflg, &
+                   cld(:,:,1), taucld, cld(:,:,2), cld(:,:,3), cld(:,:,4), cld(:,:,5), tauaer, &
+                   uflx, dflx, hr, uflxc, dflxc, hrc, du, duc)
+     tauaer = 0.25_rb * tauaer
+     call rrtmg_lw_changed(tauaer)
   endif
   ! gas order in the file: h2o, o3, co2, ch4, n2o, o2, cfc11, cfc12, cfc22, ccl4 ; cld: cldfr, cicewp, cliqwp, reice, reliq
   call rrtmg_lw(ncol, nlay, icld, idrv, play, plev, tlay, tlev, tsfc, &
@@ -50,6 +69,7 @@ program drive_shim
      call rrtmg_lw_unpin(gas); call rrtmg_lw_unpin(emis); call rrtmg_lw_unpin(cld); call rrtmg_lw_unpin(taucld); call rrtmg_lw_unpin(tauaer)
      call rrtmg_lw_unpin(uflx); call rrtmg_lw_unpin(dflx); call rrtmg_lw_unpin(hr); call rrtmg_lw_unpin(uflxc); call rrtmg_lw_unpin(dflxc)
      call rrtmg_lw_unpin(hrc); call rrtmg_lw_unpin(du); call rrtmg_lw_unpin(duc)
+     call rrtmg_lw_changed(tauaer, .false.); call rrtmg_lw_changed(emis, .false.); call rrtmg_lw_changed(gas, .false.)
   endif
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
   write(u) int(icld), uflx, dflx, hr, uflxc, dflxc, hrc, du, duc
