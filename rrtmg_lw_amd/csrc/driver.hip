@@ -417,7 +417,7 @@ void drop_sweep_set(int k)
 
 // A cloudy batch too small to fill the chip is a latency chain of six kernels; three of them are the sweeps (down above the clouds, the
 // cloud zone, up above the clouds).  Up to ONE_SWEEP_MAX columns the cloud-zone kernel walks all levels instead (k_blocksort, force_top)
-// and the two clear-sky launches are not made: 1 024 cloudy columns 0.58 -> MEASURED ms.  Larger batches keep the three launches - above the
+// and the two clear-sky launches are not made: 1 024 cloudy columns 0.609 -> 0.587 ms (profiles/round4_small_calls.md).  Larger batches keep the three launches - above the
 // clouds k_sweepc costs a third of k_sweepz's clear-sky body per level.
 int g_one_sweep_max = []() { const char *e = getenv("RRTMG_LW_ONE_SWEEP_MAX"); return e ? atoi(e) : 4096; }();       // rrtmg_lw_hip_set_one_sweep_max
 bool one_sweep(int nb, int mode) { return mode != 0 && nb <= g_one_sweep_max; }
@@ -674,7 +674,10 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
 {
     if (int rc = ensure_pipeline()) return rc;
     const int nbmax = balanced_batch(ncol, G.batch);
-    const hipStream_t aux = G.aux;
+    // a call that is ONE batch has nothing for its per-column kernels to run beside: they go on the caller's stream, one cross-stream
+    // event hop (~20 us of a 0.6 ms call) less
+    const bool single = ncol <= nbmax && !(G.split_sweep && G.cu_layer > 0);
+    const hipStream_t aux = single ? s : G.aux;
     ColIn c{};
     // sub-column arrays mode keeps per-g-point cloud arrays (odg/cfef) in one set only: no layer/sweep overlap there
     const bool split = G.split_sweep && G.ws_two_scr && !(mode == 3 && mc);
@@ -684,8 +687,10 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         if (int rc = make_stream(&G.lay_m, 0, G.cu_layer)) return rc;
     }
     if (G.ev_last_valid) HIP_TRY(hipStreamWaitEvent(s, G.ev_last, 0));      // an earlier call, possibly on another stream, still owns the workspace
-    HIP_TRY(hipEventRecord(G.ev_in, s));                 // inputs are ready when the caller's stream gets here
-    HIP_TRY(hipStreamWaitEvent(aux, G.ev_in, 0));
+    if (!single) {
+        HIP_TRY(hipEventRecord(G.ev_in, s));             // inputs are ready when the caller's stream gets here
+        HIP_TRY(hipStreamWaitEvent(aux, G.ev_in, 0));
+    }
     int i = 0;
     for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
@@ -701,10 +706,10 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
 #endif
             if (int rc = launch_kiss(aux, Wk, ncol, col0, nb, nlay, gen.icld, gen.permuteseed, SubcolIn{g.play, g.cldfr, gen.alpha})) return rc;
         }
-        HIP_TRY(hipEventRecord(G.ev_ready[k], aux));
+        if (!single) HIP_TRY(hipEventRecord(G.ev_ready[k], aux));
         // (with a CU partition nothing is enqueued on the caller's stream inside the loop: streams with a CU mask are blocking streams, and
         // where the caller's stream is the null stream every operation on it would be a barrier between them)
-        if (!part) HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
+        if (!part && !single) HIP_TRY(hipStreamWaitEvent(s, G.ev_ready[k], 0));
         if (split) {
             // k_layer of this batch on the caller's stream, its sweep on the sweep set's main stream: the HBM-bound sweep of batch i
             // overlaps the issue-bound k_layer of batch i+1 (scratch set k is free once the sweep of batch i-2 is done).

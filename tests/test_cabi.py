@@ -46,6 +46,15 @@ def test_no_device_is_a_loud_error():
     lib.rrtmg_lw_hip_last_error.restype = ctypes.c_char_p
     assert lib.rrtmg_lw_hip_kdata_is_standin() == -1
     assert lib.rrtmg_lw_hip_check(None) == 4          # RRTMG_LW_HIP_ENOTINIT
+    # the host-pointer entry - a small call goes through the combining entry for concurrent callers, a large one straight to the lock -
+    # says the same instead of touching a device that is not there
+    from rrtmg_lw_amd.synth import make_gcm_inputs
+    for ncol in (8, 9000):
+        with pytest.raises(api.RrtmgLwError, match="rrtmg_lw_hip_init has not been called"):
+            api.rrtmg_lw_from_dict(make_gcm_inputs(ncol, 20, "cloudy"))
+    assert api.combine_stats()[0] >= 1
+    with pytest.raises(api.RrtmgLwError, match="has not been called"):
+        api.set_cu_partition(96)
 
 
 def test_product_does_not_import_oracle():
