@@ -309,6 +309,7 @@ def main():
                          # the contract's per-kernel figure (whole-column algorithmic bytes / this kernel's time) overstates a kernel that is
                          # a fraction of the path; kept for continuity with round 1, next to the share-weighted one
                          whole_column_bytes_over_kernel_time_GBps=round(bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9, 3),
+                         frac_by_kernel_formula=round(bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          traffic=None)
             # PMC-measured HBM bytes (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 passes, one entry per
             # configuration): the PATH's bytes per column x this rank's columns per step, and the dominant kernel's per launch
