@@ -29,3 +29,13 @@ def hip():
     api.rrtmg_lw_ini(1004.0, kdata=api.STANDIN_KDATA, device=0)
     yield api
     api.finalize()
+
+
+@pytest.fixture(params=["three sweep launches", "one sweep launch"])
+def sweeps(request, hip):
+    """Cloudy batches of up to 4096 columns take one sweep launch per band group (the cloud-zone kernel over all levels) instead of three
+    (rrtmg_lw_hip_set_one_sweep_max).  The tests' column counts are below that, so the tests that pin the sweeps - the reference fixtures,
+    the cloud-structure cases, the fuzz - run both ways: the three launches are what every production-size batch takes."""
+    prev = hip.set_one_sweep_max(0 if request.param.startswith("three") else 1 << 30)
+    yield request.param
+    hip.set_one_sweep_max(prev)

@@ -25,7 +25,7 @@ def _cases(seed, n):
 
 
 @pytest.mark.parametrize("c", _cases(20260104, 28), ids=lambda c: "%(config)s-L%(nlay)d-n%(ncol)d-icld%(icld)d-idrv%(idrv)d-b%(batch)d" % c)
-def test_random_gcm_calls(hip, oracle, c):
+def test_random_gcm_calls(hip, oracle, c, sweeps):
     d = make_gcm_inputs(c["ncol"], c["nlay"], c["config"], col0=c["col0"])
     hip.set_batch(c["batch"])
     try:
@@ -71,7 +71,7 @@ def _mc_cases(seed, n):
 
 
 @pytest.mark.parametrize("c", _mc_cases(20260105, 12), ids=lambda c: "%(config)s-L%(nlay)d-n%(ncol)d-icld%(icld)d-idrv%(idrv)d-seed%(seed)d-b%(batch)d" % c)
-def test_random_mcica_calls(hip, oracle, c):
+def test_random_mcica_calls(hip, oracle, c, sweeps):
     """The fused entry (kissvec generator by jump-ahead -> cldprmc -> rtrnmc) against the oracle's generator + McICA solver: random
     overlap rule, seed (= how far the jump tables reach), layer count (= draws per sub-column), batch size."""
     ncol, nlay = c["ncol"], c["nlay"]

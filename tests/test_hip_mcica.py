@@ -8,7 +8,6 @@ import pytest
 from rrtmg_lw_amd.synth import make_gcm_inputs
 
 pytestmark = pytest.mark.gpu
-from test_hip_parity import sweeps  # noqa: E402,F401  (fixture: one / three sweep launches)
 
 FLUX_TOL = 0.01      # W m-2     (BASELINE.json north_star)
 HR_TOL = 0.001       # K day-1
@@ -155,7 +154,7 @@ def _with_subcolumns(oracle, d, icld, irng=0, permuteseed=140, alpha=None):
     ("aer_idrv", 33, 1, 64, (2, 3, 1)),
     ("cloudy", 72, 9, 65, None),              # out-of-range icld is reset to 2 (src/rrtmg_lw_rad.f90:469)
 ])
-def test_mcica_entry_matches_oracle(hip, oracle, config, nlay, icld, ncol, flags):
+def test_mcica_entry_matches_oracle(hip, oracle, config, nlay, icld, ncol, flags, sweeps):
     d = make_gcm_inputs(ncol, nlay, config, col0=77)
     if flags is not None:
         d["inflglw"], d["iceflglw"], d["liqflglw"] = flags
@@ -347,7 +346,7 @@ def test_mcica_errors(hip, oracle):
     (5, 1, "aer_idrv", 33, 64),
     (0, 0, "cloudy", 72, 64),
 ])
-def test_fused_generator_and_solver_matches_oracle(hip, oracle, icld, irng, config, nlay, ncol):
+def test_fused_generator_and_solver_matches_oracle(hip, oracle, icld, irng, config, nlay, ncol, sweeps):
     """rrtmg_lw_hip_run_mcica_subcol == mcica_subcol_lw followed by the McICA rrtmg_lw."""
     d = make_gcm_inputs(ncol, nlay, config, col0=31)
     dz, lat = _geometry(ncol, nlay)
@@ -370,7 +369,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_mcica_*.npz"))), ids=os.path.basename)
-def test_against_reference_fixture(hip, path):
+def test_against_reference_fixture(hip, path, sweeps):
     """HIP generator and McICA solver against outputs of the REFERENCE's own Fortran (tools/gen_ref_fixtures.py):
     masks bit-exact, fluxes within the north-star bars.  The Mersenne-Twister fixtures were generated column by
     column (one freshly seeded stream each, as the reference's column driver does)."""

@@ -20,15 +20,6 @@ TIGHT_FLUX = 5e-5
 TIGHT_HR = 5e-5
 
 
-@pytest.fixture(params=["three sweep launches", "one sweep launch"])
-def sweeps(request, hip):
-    """Cloudy batches of up to 4096 columns take one sweep launch per band group (the cloud-zone kernel over all levels) instead of three
-    (rrtmg_lw_hip_set_one_sweep_max): the tests of the cloud structure run both ways."""
-    prev = hip.set_one_sweep_max(0 if request.param.startswith("three") else 1 << 30)
-    yield request.param
-    hip.set_one_sweep_max(prev)
-
-
 def _compare(got, ref, idrv, tag):
     dflux = max(np.abs(got[k] - ref[k]).max() for k in ("uflx", "dflx", "uflxc", "dflxc"))
     dhr = max(np.abs(got[k] - ref[k]).max() for k in ("hr", "hrc"))

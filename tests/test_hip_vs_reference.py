@@ -40,7 +40,7 @@ def _check(got, f, idrv, tag):
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_gcm_*.npz"))), ids=os.path.basename)
-def test_gcm_entry_matches_reference_fixture(hip, path):
+def test_gcm_entry_matches_reference_fixture(hip, path, sweeps):
     f = np.load(path)
     ncol, nlay, icld = int(f["ncol"]), int(f["nlay"]), int(f["icld"])
     d = make_gcm_inputs(ncol, nlay, str(f["config"]), col0=int(f["col0"]))
@@ -49,7 +49,7 @@ def test_gcm_entry_matches_reference_fixture(hip, path):
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_stress_*.npz"))), ids=os.path.basename)
-def test_stress_inputs_match_reference_fixture(hip, path):
+def test_stress_inputs_match_reference_fixture(hip, path, sweeps):
     """2x-8x CO2 / 2x-3x N2O (the `ratx > thr` adjustment, src/rrtmg_lw_taumol.f90:547-554 and its four sibling sites),
     temperatures outside 160-339 K (Planck-index and jt clamps, src/rrtmg_lw_setcoef.f90:174-178,294-305), laytrop = 0 and
     laytrop = nlay."""
@@ -61,7 +61,7 @@ def test_stress_inputs_match_reference_fixture(hip, path):
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "ref_col_*.npz"))), ids=os.path.basename)
-def test_prepared_columns_match_reference_fixture(hip, path):
+def test_prepared_columns_match_reference_fixture(hip, path, sweeps):
     """Prepared-column entry vs the reference's column-driver sequence; ref_col_MLS-clr.npz is BASELINE configs[0]
     (single MLS clear-sky column, 51 layers) with the total and every one of the 16 per-band blocks."""
     f = np.load(path)
