@@ -231,7 +231,7 @@ int rrtmg_lw_hip_queue_flush(void);
 /* columns queued since the last flush */
 int rrtmg_lw_hip_queue_columns(void);
 
-/* Columns processed per internal batch (bounds the device workspace); default 262144 (about 0.2 MB of device workspace per column at 72 layers). */
+/* Columns processed per internal batch (bounds the device workspace); default 262144 (0.06-0.16 MB of device workspace per column at 72 layers, by call shape: see rrtmg_lw_hip_workspace_bytes). */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
 /* on = 1: device-pointer entries run the sweeps / k_flux of column batch i on a second stream while k_layer of batch i+1 runs on the
  * caller's stream (second scratch set, +0.1 MB of workspace per column).  Default 0: a sweep workgroup owns a CU (transmittance table in
@@ -248,8 +248,9 @@ int rrtmg_lw_hip_cu_partition(void);
  * above the clouds).  Batches of up to `ncol` columns (default 4096; RRTMG_LW_ONE_SWEEP_MAX) take ONE sweep launch per band group instead:
  * the cloud-zone kernel walks all levels.  0 = never.  Results do not depend on it (bit for bit).  Returns the previous value. */
 int rrtmg_lw_hip_set_one_sweep_max(int ncol);
-/* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (about 0.2 MB per column of the batch
- * at 72 layers, 0.37 MB at 137: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer
+/* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (it holds what the call shapes seen so far need and only
+ * grows: per column of the batch at 72 layers 62 KB for cloud-free calls, 144 KB for rtrnmr, 149 KB for rtrn, 163 KB with idrv = 1; 303 KB at
+ * 137 layers with idrv = 1: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer
  * (<= 512 MB, or one slab) and the cached chunk states (<= 2 x 180 MB) of the Mersenne-Twister stream. */
 long long rrtmg_lw_hip_workspace_bytes(void);
 /* Measurement only: 1 = cloud-free GCM calls take the prototype of the "one column per wavefront" mapping (k_n1, profiles/round2_n1_expf.md)

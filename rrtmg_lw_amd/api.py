@@ -166,6 +166,12 @@ def set_cu_partition(layer_cus):
     _check(lib().rrtmg_lw_hip_set_cu_partition(C.c_int(int(layer_cus))))
 
 
+def workspace_bytes():
+    """device memory the library holds right now (rrtmg_lw_hip_workspace_bytes)"""
+    lib().rrtmg_lw_hip_workspace_bytes.restype = C.c_longlong
+    return int(lib().rrtmg_lw_hip_workspace_bytes())
+
+
 def set_one_sweep_max(ncol):
     """cloudy batches of up to `ncol` columns take one sweep launch per band group instead of three (0 = never); returns the previous value"""
     return int(lib().rrtmg_lw_hip_set_one_sweep_max(C.c_int(int(ncol))))

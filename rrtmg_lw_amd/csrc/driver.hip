@@ -49,7 +49,8 @@ struct State {
     void *ws_base = nullptr;
     size_t ws_bytes = 0;
     int ws_nlay = 0, ws_ncolb = 0;
-    bool ws_cloud = false, ws_mc = false;
+    bool ws_cloud = false, ws_mc = false, ws_gdp = false, ws_efcl = false, ws_ovl = false;
+    int ws_groups = 0;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
     struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; } prep[2] = {};
@@ -74,7 +75,7 @@ struct State {
     size_t mask_bytes = 0;
     double *d_rnd = nullptr;   // one slab of Mersenne-Twister deviates (irng = 1)
     size_t rnd_bytes = 0;
-    int batch = 262144;     // columns per internal batch: ~0.19 MB of workspace per column at 72 layers (50 GB of the 288); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
+    int batch = 262144;     // columns per internal batch: 0.06-0.16 MB of workspace per column at 72 layers by call shape (38 GB of the 288 for the benchmark's); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
     bool split_sweep = false;    // run the sweeps / k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: a sweep
                                  // workgroup owns a CU (transmittance table in LDS), so the two do not share a CU (measured: 1-2 % gain for twice the code scratch)
     bool sweep_attrs = false;    // the sweeps' dynamic-LDS limit has been raised on this device
@@ -277,25 +278,60 @@ int ensure_sweep_attrs()
     return 0;
 }
 
-// (re)allocate the per-batch workspace
-int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
+// The sweeps' band groups: the bands in [istart, iend] by their number of quads, at most as many per group as one sweep workgroup holds
+// (a group is one workgroup in k_sweepc and in k_sweepz: what fits the wave slots of both).  Every group has its own partial slabs.
+struct SweepGroups { int n = 0; int nb[NGROUP_MAX]; unsigned long long bands[NGROUP_MAX]; int gq[NGROUP_MAX]; };
+bool make_groups(int mode, int idrv, int istart, int iend, SweepGroups &fg)
 {
-    if (G.ws_base && G.ws_nlay == nlay && G.ws_ncolb >= ncolb && (G.ws_cloud || !cloud) && (G.ws_mc || !mc) && (G.ws_two_scr || !G.split_sweep)) return 0;
+    unsigned long long lists[5] = {0, 0, 0, 0, 0};
+    int nbs[5] = {0, 0, 0, 0, 0};
+    for (int nq = 1; nq <= 4; nq++)
+        for (int B = 1; B <= NBND; B++)
+            if (band_nquad(B) == nq && B >= istart && B <= iend) lists[nq] |= (unsigned long long)(B - 1) << (4 * nbs[nq]++);
+    fg.n = 0;
+    for (int nq = 4; nq >= 1; nq--) {
+        const int zcap = sweepz_group_cap(nq, idrv == 1);
+        const int cap = std::max(1, std::min(sweepc_group_cap(nq), mode != 0 ? zcap : 99));
+        for (int k0 = 0; k0 < nbs[nq]; k0 += cap) {
+            if (fg.n >= NGROUP_MAX) return false;
+            const int nbg = std::min(cap, nbs[nq] - k0);
+            fg.nb[fg.n] = nbg;
+            fg.bands[fg.n] = (lists[nq] >> (4 * k0)) & (nbg >= 16 ? ~0ull : ((1ull << (4 * nbg)) - 1ull));
+            fg.gq[fg.n++] = nq;
+        }
+    }
+    return true;
+}
+
+// (re)allocate the per-batch workspace.  It holds what the call shapes seen so far need and grows with them: the partial slabs of as many
+// band groups as the sweeps form (4 without d/dT, up to NGROUP_MAX with), the d/dT slab only for idrv = 1, rtrn's / rtrnmc's emissivity
+// term only for modes 1 and 3, rtrnmr's overlap factors only for mode 2.  mode: 0 clear, 1 rtrn, 2 rtrnmr, 3 rtrnmc; -1 = everything.
+int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv = 1, int mode = -1)
+{
+    SweepGroups fgw;
+    int groups = NGROUP_MAX;
+    if (mode >= 0 && make_groups(mode, idrv, 1, NBND, fgw)) groups = fgw.n;
+    const bool gdp = idrv == 1, efcl = cloud && (mode < 0 || mode == 1 || mode == 3), ovl = cloud && (mode < 0 || mode == 2);
+    if (G.ws_base && G.ws_nlay == nlay && G.ws_ncolb >= ncolb && (G.ws_cloud || !cloud) && (G.ws_mc || !mc) && (G.ws_two_scr || !G.split_sweep) &&
+        G.ws_groups >= groups && (G.ws_gdp || !gdp) && (G.ws_efcl || !efcl) && (G.ws_ovl || !ovl)) return 0;
     if (G.ws_base) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.ws_base)); G.ws_base = nullptr; }
-    ncolb = std::max(ncolb, G.ws_nlay == nlay ? G.ws_ncolb : 0);
+    const bool same = G.ws_nlay == nlay;
+    ncolb = std::max(ncolb, same ? G.ws_ncolb : 0);
     cloud = cloud || G.ws_cloud || mc;
     mc = mc || G.ws_mc;
+    const int ng = std::max(groups, G.ws_groups);
+    const bool want_gdp = gdp || G.ws_gdp, want_efcl = efcl || G.ws_efcl, want_ovl = ovl || G.ws_ovl;
     const size_t n = (size_t)ncolb, L = (size_t)nlay;
     struct Item { void **p; size_t bytes; };
     Workspace &W = G.W;
     W = Workspace{};
     std::vector<Item> items = {
-        {(void **)&W.gdn1, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(double)},
-        {(void **)&W.gup1, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(double)},
-        {(void **)&W.gup, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.gdp, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.gdn, (size_t)NGROUP_MAX * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.gdn1, (size_t)ng * (L + 1) * n * sizeof(double)},
+        {(void **)&W.gup1, (size_t)ng * (L + 1) * n * sizeof(double)},
+        {(void **)&W.gup, (size_t)ng * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.gdn, (size_t)ng * (L + 1) * n * sizeof(Part2)},
     };
+    if (want_gdp) items.push_back({(void **)&W.gdp, (size_t)ng * (L + 1) * n * sizeof(Part2)});
     const bool two_scr = G.split_sweep;
     G.scrset[1] = State::ScrSet{};
     for (int k = 0; k < (two_scr ? 2 : 1); k++) {
@@ -323,8 +359,8 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     if (cloud) {
         for (auto &ps : G.prep) {
             items.push_back({(void **)&ps.odcld, 16 * L * n * 8});
-            items.push_back({(void **)&ps.efcl, 16 * L * n * 8});
-            items.push_back({(void **)&ps.ovl, (size_t)2 * (L + 1) * 3 * n * sizeof(double2)});
+            if (want_efcl) items.push_back({(void **)&ps.efcl, 16 * L * n * 8});
+            if (want_ovl) items.push_back({(void **)&ps.ovl, (size_t)2 * (L + 1) * 3 * n * sizeof(double2)});
         }
     }
     if (mc) {
@@ -353,6 +389,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false)
     G.ws_cloud = cloud;
     G.ws_mc = mc;
     G.ws_two_scr = two_scr;
+    G.ws_groups = ng; G.ws_gdp = want_gdp; G.ws_efcl = want_efcl; G.ws_ovl = want_ovl;
     return 0;
 }
 
@@ -529,26 +566,10 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     // k_sweepc<., 2> (layers above, upward).  The classes are independent of each other: with `fan` each class has its own stream;
     // on one stream the launches go phase by phase (all downward ones, then the cloud zone, then the upward ones) so that consecutive
     // launches never wait for each other's last workgroups.
-    unsigned long long lists[5] = {0, 0, 0, 0, 0};
-    int nbs[5] = {0, 0, 0, 0, 0};
-    for (int nq = 1; nq <= 4; nq++)
-        for (int B = 1; B <= NBND; B++)
-            if (band_nquad(B) == nq && B >= istart && B <= iend) lists[nq] |= (unsigned long long)(B - 1) << (4 * nbs[nq]++);
-    // k_sweepc's groups: the bands of a class, at most sweepc_group_cap of them per workgroup
-    struct { int n = 0; int nb[NGROUP_MAX]; unsigned long long bands[NGROUP_MAX]; } fg;
-    int gq[NGROUP_MAX];
-    for (int nq = 4; nq >= 1; nq--) {
-        // (a group is one workgroup in k_sweepc and in k_sweepz: what fits the wave slots of both)
-        const int zcap = sweepz_group_cap(nq, idrv == 1);
-        const int cap = std::max(1, std::min(sweepc_group_cap(nq), mode != 0 ? zcap : 99));
-        for (int k0 = 0; k0 < nbs[nq]; k0 += cap) {
-            if (fg.n >= NGROUP_MAX) return fail(RRTMG_LW_HIP_EARG, "internal: more than %d sweep groups", NGROUP_MAX);
-            const int nbg = std::min(cap, nbs[nq] - k0);
-            fg.nb[fg.n] = nbg;
-            fg.bands[fg.n] = (lists[nq] >> (4 * k0)) & (nbg >= 16 ? ~0ull : ((1ull << (4 * nbg)) - 1ull));
-            gq[fg.n++] = nq;
-        }
-    }
+    SweepGroups fg;
+    if (!make_groups(mode, idrv, istart, iend, fg)) return fail(RRTMG_LW_HIP_EARG, "internal: more than %d sweep groups", NGROUP_MAX);
+    if (fg.n > G.ws_groups || (idrv == 1 && !G.ws_gdp)) return fail(RRTMG_LW_HIP_EARG, "internal: workspace holds %d band groups, the call needs %d", G.ws_groups, fg.n);
+    const int *gq = fg.gq;
 #define SWEEPC_I(Q, PH, I)                                                                                           \
     do {                                                                                                             \
         constexpr int nt = sweepc_nt(Q, PH, I);                                                                      \
@@ -1633,7 +1654,7 @@ static int init_state(const char *static_tables_path, const char *kdata_path, do
     D.absice0[0] = G.H.absice0[0]; D.absice0[1] = G.H.absice0[1];
     D.abscld1 = G.H.abscld1; D.absliq0 = G.H.absliq0;
     D.heatfac = G.H.heatfac; D.fluxfac = G.H.fluxfac; D.oneminus = G.H.oneminus; D.bpade = G.H.bpade;
-    if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; G.ws_mc = false; }
+    if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; G.ws_mc = false; G.ws_groups = 0; G.ws_gdp = G.ws_efcl = G.ws_ovl = false; }
     G.device = device;
     G.n1 = false;
     G.init = true;
@@ -1908,7 +1929,7 @@ int rrtmg_lw_hip_run_nomcica_device(
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);      // :546-560 (icld=0 -> rtrnmr clear branch)
     const int nbmax = balanced_batch(ncol, G.batch);
-    if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false, idrv, mode)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
     FluxOut out{uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt, nullptr, nullptr};
@@ -1936,7 +1957,7 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
     // host arrays: the copies bound the rate (PCIe), and they overlap with the kernels only across batches - smaller batches than
     // the device-resident default
     const int nbmax = balanced_batch(c1 - c0, std::min(G.batch, HOST_BATCH));
-    if (int rc = ensure_workspace(nlay, nbmax, mode != 0)) return rc;
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false, idrv, mode)) return rc;
     const size_t L = (size_t)nlay;
     // What the copies need not carry (62 % of a column's bytes are taucld and tauaer, 2 x 16 nlay values):
     //  * with inflglw >= 1 cldprop reads taucld only through the sum over the bands, tauctot (src/rrtmg_lw_cldprop.f90:173-186): the sum is
@@ -2110,7 +2131,7 @@ int rrtmg_lw_hip_run_columns(
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
     if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns handles at most one batch (%d columns)", G.batch);
     const int mode = icld == 0 ? 0 : (icld == 1 ? 1 : 2);
-    if (int rc = ensure_workspace(nlayers, ncol, true)) return rc;
+    if (int rc = ensure_workspace(nlayers, ncol, true, false, idrv, mode)) return rc;
     const size_t n = (size_t)ncol, L = (size_t)nlayers;
     struct In { const double *h; size_t cnt; double *d; };
     In ins[] = {{pavel, n * L, 0}, {tavel, n * L, 0}, {pz, n * (L + 1), 0}, {tz, n * (L + 1), 0}, {tbound, n, 0}, {semiss, 16 * n, 0},
@@ -2162,7 +2183,7 @@ int rrtmg_lw_hip_run_columns_mcica(
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
     if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns_mcica handles at most one batch (%d columns)", G.batch);
     const int mode = icld == 0 ? 0 : 3;
-    if (int rc = ensure_workspace(nlayers, ncol, true, true)) return rc;
+    if (int rc = ensure_workspace(nlayers, ncol, true, true, idrv, mode)) return rc;
     const size_t n = (size_t)ncol, L = (size_t)nlayers;
     struct In { const double *h; size_t cnt; double *d; };
     In ins[] = {{pavel, n * L, 0}, {tavel, n * L, 0}, {pz, n * (L + 1), 0}, {tz, n * (L + 1), 0}, {tbound, n, 0}, {semiss, 16 * n, 0},
@@ -2585,7 +2606,7 @@ int rrtmg_lw_hip_run_mcica_device(
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : 3;                         // inatm leaves the cloud arrays zero when icld = 0 (:899-911)
     const int nbmax = balanced_batch(ncol, G.batch);
-    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, mode == 3)) return rc;
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, mode == 3, idrv, mode)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tauaer};
     McIn m{cldfmcl, taucmcl, ciwpmcl, clwpmcl, reicmcl, relqmcl};
@@ -2612,7 +2633,7 @@ int rrtmg_lw_hip_run_mcica(
     // the sub-column arrays are 4 x 140 x nlay doubles per column: bound the batch so that staging stays below ~4 GB
     const int mcmax = (int)std::max<size_t>(64, ((size_t)1 << 30) / ((size_t)4 * NGPT * nlay * 8));        // (HOST_SETS staging sets of 1 GiB)
     const int nbmax = balanced_batch(c1 - c0, std::min(std::min(G.batch, HOST_BATCH), cloud ? mcmax : HOST_BATCH));
-    if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud)) return rc;
+    if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud, idrv, mode)) return rc;
     const size_t L = (size_t)nlay;
     std::vector<HostIn> ins = {
         {play, 1, L, 0}, {plev, 1, L + 1, 0}, {tlay, 1, L, 0}, {tlev, 1, L + 1, 0}, {tsfc, 1, 1, 0},
@@ -2776,7 +2797,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     const int mode = icld_gen == 0 ? 0 : 3;
     hipStream_t s = (hipStream_t)stream;
     const int nbmax = balanced_batch(ncol, G.batch);
-    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false)) return rc;      // mask path: no per-g-point cloud arrays
+    if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false, idrv, mode)) return rc;      // mask path: no per-g-point cloud arrays
     KissGen gen{false, icld_gen, permuteseed, alpha};
     if (mode == 3) {
         if (*irng == 0) {          // kissvec: every column owns its stream -> generated batch by batch on the auxiliary stream
@@ -2804,7 +2825,7 @@ static int mcica_subcol_host_range(
     const bool cloud = mode == 3, two = icld_gen == 4 || icld_gen == 5;
     const int nloc = c1 - c0;
     const int nbmax = balanced_batch(nloc, std::min(G.batch, HOST_BATCH));
-    if (int rc = ensure_workspace(nlay, nbmax, cloud, false)) return rc;
+    if (int rc = ensure_workspace(nlay, nbmax, cloud, false, idrv, mode)) return rc;
     const size_t L = (size_t)nlay, n = (size_t)ncol, nl = (size_t)nloc;
     hipStream_t s = G.stream;
     // 1. masks of the block's columns: needs play, cldfr, alpha of every one of them

@@ -692,6 +692,29 @@ def test_one_sweep_launch_is_transparent(hip, oracle, config, icld, idrv, mcica)
         assert np.array_equal(three[k], one[k]), k
 
 
+def test_workspace_grows_with_call_shapes(hip, oracle):
+    """The per-batch workspace holds what the call shapes seen so far need (partial slabs of 4 band groups without d/dT and up to 8 with,
+    the d/dT slab, rtrn's emissivity term, rtrnmr's overlap factors): a library initialised afresh sees the shapes in an order that makes
+    it grow at every step, then in reverse, and every result equals the one a fresh library gives for that shape alone."""
+    ncol, nlay = 900, 50
+    shapes = [("clear", 0, 0), ("cloudy", 2, 0), ("cloudy", 1, 0), ("aer_idrv", 2, 1), ("aer_idrv", 1, 1)]
+    inputs = {sh: make_gcm_inputs(ncol, nlay, sh[0], col0=70) for sh in shapes}
+    alone = {}
+    for sh in shapes:
+        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+        alone[sh] = hip.rrtmg_lw_from_dict(inputs[sh], icld=sh[1], idrv=sh[2])
+    hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+    sizes = []
+    for sh in shapes + shapes[::-1]:
+        got = hip.rrtmg_lw_from_dict(inputs[sh], icld=sh[1], idrv=sh[2])
+        sizes.append(hip.workspace_bytes())
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if sh[2] else ()):
+            assert np.array_equal(got[k], alone[sh][k]), (sh, k)
+    assert sizes[0] < sizes[1] <= sizes[2] < sizes[3] and sizes[4] == sizes[-1], sizes
+    ref = oracle.rrtmg_lw(ncol, nlay, 1, 1, inputs[shapes[-1]])
+    _compare(alone[shapes[-1]], ref, 1, "rtrn + aerosol + d/dT on a fresh workspace")
+
+
 def test_static_arrays_are_scanned_once(hip, oracle):
     """rrtmg_lw_hip_host_static: the row scans of a declared array are kept per column batch; rrtmg_lw_hip_host_changed drops them.  Same
     numbers with and without the declaration, over several batches; a change announced by host_changed is seen, rows of a static array
