@@ -59,6 +59,7 @@ int rrtmg_lw_hip_num_devices(void);     /* 0 before initialisation */
 int rrtmg_lw_hip_kdata_is_standin(void);
 
 void rrtmg_lw_hip_finalize(void);
+/* Text of the calling THREAD's last error (concurrent callers each read their own); of the library's last one if this thread has had none. */
 const char *rrtmg_lw_hip_last_error(void);
 
 /* rrtmg_lw, non-McICA  -  reference: src/rrtmg_lw_rad.nomcica.f90:99-588.  HOST pointers.

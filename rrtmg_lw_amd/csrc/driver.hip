@@ -136,6 +136,10 @@ struct DeviceGuard {
 };
 #define ENTRY_LOCK std::lock_guard<std::mutex> lk(g_mu); DeviceGuard dg_
 
+// The text of an error belongs to the THREAD whose call failed (concurrent callers: another thread's failure a moment later must not
+// replace it before the caller has read it); the state keeps a copy for threads that have had no error of their own.
+thread_local std::string tl_err;
+
 int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -144,6 +148,7 @@ int fail(int code, const char *fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     G.err = buf;
+    tl_err = buf;
     return code;
 }
 
@@ -1616,7 +1621,11 @@ int check_subcol_args(int ncol, int nlay, int icld, int *irng)
 
 extern "C" {
 
-const char *rrtmg_lw_hip_last_error(void) { return G.err.c_str(); }
+const char *rrtmg_lw_hip_last_error(void)
+{
+    if (tl_err.empty()) { std::lock_guard<std::mutex> lk(g_mu); tl_err = g_states[0].err; }
+    return tl_err.c_str();
+}
 
 static int init_state(const char *static_tables_path, const char *kdata_path, double cpdair, int device)
 {
@@ -1659,6 +1668,7 @@ static int init_state(const char *static_tables_path, const char *kdata_path, do
     G.n1 = false;
     G.init = true;
     G.err.clear();
+    tl_err.clear();
     return 0;
 }
 
@@ -1693,6 +1703,7 @@ int rrtmg_lw_hip_init_devices(const char *static_tables_path, const char *kdata_
         for (int d = std::max(g_ndev, done + 1) - 1; d >= 0; d--) { g_cur = &g_states[d]; G.init = G.init || G.d_ktab || G.d_stat || G.d_err || G.stream; finalize_state(); }
         g_ndev = 1;
         g_states[0].err = err;
+        tl_err = err;
     }
     g_cur = &g_states[0];
     (void)hipSetDevice(g_states[0].device >= 0 ? g_states[0].device : 0);
@@ -2049,7 +2060,7 @@ int fan_out(int ncol, RangeFn range)
     }
     for (auto &x : th) x.join();
     for (int d = 0; d < g_ndev; d++)
-        if (rcs[d] != 0) { if (&g_states[d] != home) home->err = g_states[d].err; return rcs[d]; }
+        if (rcs[d] != 0) { if (&g_states[d] != home) home->err = g_states[d].err; tl_err = g_states[d].err; return rcs[d]; }       // (the worker's thread-local text is not this thread's)
     return 0;
 }
 
@@ -2453,6 +2464,7 @@ struct CallReq {
     int nlay, icld, idrv, inflg, iceflg, liqflg;
     int rc = 0;
     bool done = false, lead = false;
+    std::string err;                           // the text of rc != 0, handed to the owner's thread
     std::condition_variable cv;
 };
 std::mutex g_comb_mu;
@@ -2488,6 +2500,7 @@ void comb_serve(std::vector<CallReq *> &batch)
                                 c.in[11], c.in[12], c.in[13], c.in[14], c.in[15], r.inflg, r.iceflg, r.liqflg, c.in[16], c.in[17], c.in[18], c.in[19], c.in[20], c.in[21],
                                 c.in[22], c.out[0], c.out[1], c.out[2], c.out[3], c.out[4], c.out[5], c.out[6], c.out[7]);
             if (c.icld) *c.icld = icld;
+            if (r.rc != 0) r.err = G.err;
         };
         if (grp.size() == 1) alone(a);
         else {
@@ -2510,7 +2523,7 @@ int comb_call(CallReq &me)
     g_comb_arrive.notify_one();
     if (g_comb_busy) {
         me.cv.wait(lk, [&] { return me.done || me.lead; });
-        if (me.done) return me.rc;
+        if (me.done) { if (me.rc != 0) tl_err = me.err; return me.rc; }
     }
     g_comb_busy = true;                      // this thread has the turn: its own request is among the pending ones
     while (!me.done) {
@@ -2540,6 +2553,7 @@ int comb_call(CallReq &me)
     }
     if (!g_comb_pending.empty()) { g_comb_pending.front()->lead = true; g_comb_pending.front()->cv.notify_one(); }     // the turn goes to the first of those who came meanwhile
     else g_comb_busy = false;
+    if (me.rc != 0) tl_err = me.err;
     return me.rc;
 }
 

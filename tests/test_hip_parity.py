@@ -758,7 +758,8 @@ def test_static_arrays_are_scanned_once(hip, oracle):
 def test_concurrent_callers_are_combined(hip, oracle):
     """Several threads call the host-pointer entry at once with chunks of a few columns (an OpenMP host model): calls that arrive while
     another is in flight are solved together in one device pass (driver.hip, comb_call).  Every chunk's result equals that of the same
-    columns in one big call bit for bit, a chunk with a physics error fails alone, and fewer passes than calls were made."""
+    columns in one big call bit for bit, a chunk with a physics error fails alone and its caller reads ITS error text, and fewer passes
+    than calls were made."""
     import threading
     ncol, nlay, chunk, nthreads = 1536, 40, 32, 8
     d = make_gcm_inputs(ncol, nlay, "cloudy", col0=64)
@@ -784,6 +785,11 @@ def test_concurrent_callers_are_combined(hip, oracle):
     chunks[bad]["reice"] = np.asfortranarray(r)
     for k, v in (("cldfr", 0.5), ("cicewp", 10.0)):
         a = np.array(chunks[bad][k]); a[3, 8] = v; chunks[bad][k] = np.asfortranarray(a)
+    bad2 = 30                                                     # a second caller's error, another text: each thread reads its own
+    r = np.array(chunks[bad2]["reliq"]); r[5, 9] = 1.0
+    chunks[bad2]["reliq"] = np.asfortranarray(r)
+    for k, v in (("cldfr", 0.5), ("cliqwp", 10.0)):
+        a = np.array(chunks[bad2][k]); a[5, 9] = v; chunks[bad2][k] = np.asfortranarray(a)
     results, errors = [None] * len(chunks), [None] * len(chunks)
     calls0, passes0 = hip.combine_stats()
 
@@ -806,6 +812,9 @@ def test_concurrent_callers_are_combined(hip, oracle):
     for i, c0 in enumerate(range(0, ncol, chunk)):
         if i == bad:
             assert errors[i] and "ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS" in errors[i]
+            continue
+        if i == bad2:
+            assert errors[i] and "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS" in errors[i]
             continue
         assert errors[i] is None, (i, errors[i])
         for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
