@@ -249,6 +249,14 @@ int rrtmg_lw_hip_cu_partition(void);
  * above the clouds).  Batches of up to `ncol` columns (default 4096; RRTMG_LW_ONE_SWEEP_MAX) take ONE sweep launch per band group instead:
  * the cloud-zone kernel walks all levels.  0 = never.  Results do not depend on it (bit for bit).  Returns the previous value. */
 int rrtmg_lw_hip_set_one_sweep_max(int ncol);
+/* The sweeps decide per wavefront - 64 consecutive columns of a batch - where the clouds end; one deep tower among 64 shallow columns sends
+ * all of them through the cloud-zone sweep up to its top.  By default (RRTMG_LW_COLSORT=0 to switch off) the columns of a cloudy non-McICA
+ * batch are therefore TAKEN in another order than they lie: within each window of 256 consecutive columns by their highest cloudy layer,
+ * deepest first (k_colsort); the caller's arrays stay as they are and are read / written through that order.  A window is reordered only
+ * where that takes at least `min_gain` block-levels out of the cloud zone (sum over its four 64-column blocks of the highest cloudy layer,
+ * as the columns lie against sorted; default 40, RRTMG_LW_COLSORT_MIN; < 0 keeps the value): reading the caller's arrays out of order has a
+ * price.  on = 1 / off = 0; results do not depend on it (bit for bit).  Returns the previous `on`. */
+int rrtmg_lw_hip_set_column_sort(int on, int min_gain);
 /* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (it holds what the call shapes seen so far need and only
  * grows: per column of the batch at 72 layers 62 KB for cloud-free calls, 144 KB for rtrnmr, 149 KB for rtrn, 163 KB with idrv = 1; 303 KB at
  * 137 layers with idrv = 1: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer

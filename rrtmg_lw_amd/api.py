@@ -177,6 +177,12 @@ def set_one_sweep_max(ncol):
     return int(lib().rrtmg_lw_hip_set_one_sweep_max(C.c_int(int(ncol))))
 
 
+def set_column_sort(on, min_gain=-1):
+    """columns of a cloudy non-McICA batch are taken by cloud top within windows of 256 where that removes >= min_gain block-levels from the
+    cloud zone (rrtmg_lw_hip_set_column_sort; min_gain < 0 keeps the threshold); returns the previous on / off"""
+    return int(lib().rrtmg_lw_hip_set_column_sort(C.c_int(1 if on else 0), C.c_int(int(min_gain))))
+
+
 def cu_partition():
     return int(lib().rrtmg_lw_hip_cu_partition())
 

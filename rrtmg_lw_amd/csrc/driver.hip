@@ -53,7 +53,7 @@ struct State {
     int ws_groups = 0;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *inv; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -359,6 +359,8 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
         items.push_back({(void **)&ps.hgrp, (nslot / SORT_GROUP) * 4});
         items.push_back({(void **)&ps.bbot, nblk * 4});
         items.push_back({(void **)&ps.hbot, (nslot / SORT_GROUP) * 4});
+        items.push_back({(void **)&ps.perm, align_up(n, COLSORT_WIN) * 4});
+        items.push_back({(void **)&ps.inv, align_up(n, COLSORT_WIN) * 4});
     }
     if (cloud) items.push_back({(void **)&W.hand, (size_t)5 * NQUAD * 4 * n * 8});
     if (cloud) {
@@ -409,11 +411,20 @@ int ensure_mask(int nlay, size_t ncol)
     return 0;
 }
 
-// the workspace view of prep set k (see State::prep)
-Workspace ws_for(int k)
+// Columns of a cloudy non-McICA batch are taken in the order k_colsort gives them (by cloud top within windows of 256: the sweeps decide
+// per 64 positions where the clouds end).  rrtmg_lw_hip_set_column_sort / RRTMG_LW_COLSORT=0 switch it off; results do not depend on it.
+bool g_colsort = []() { const char *e = getenv("RRTMG_LW_COLSORT"); return !e || atoi(e) != 0; }();
+bool use_colsort(bool gcm, int mode) { return g_colsort && gcm && (mode == 1 || mode == 2); }
+// block-levels a window's reordering must take out of the cloud zone (k_colsort; measured break-even on an MI355X, profiles/round4_column_order.md)
+int g_colsort_min = []() { const char *e = getenv("RRTMG_LW_COLSORT_MIN"); return e ? atoi(e) : 40; }();
+
+// the workspace view of prep set k (see State::prep); sorted: the batch's columns go through k_colsort's order
+Workspace ws_for(int k, bool sorted)
 {
     Workspace w = G.W;
     const State::PrepSet &ps = G.prep[k];
+    w.perm = sorted ? ps.perm : nullptr;
+    w.inv = sorted ? ps.inv : nullptr;
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
     w.odcld = ps.odcld; w.efcl = ps.efcl; w.ovl = ps.ovl;
     w.btop = ps.btop; w.order = ps.order; w.hgrp = ps.hgrp; w.hblk = ps.hblk; w.bbot = ps.bbot; w.hbot = ps.hbot;
@@ -472,6 +483,7 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
 {
     // thread-per-column kernels: one wave per workgroup so that a batch (one wave per 64 columns) spreads over all 256 CUs
     const dim3 cgrid1((nb + 63) / 64), cblock1(64);
+    if (Wk.perm) LAUNCH("k_colsort", (k_colsort<GCM>), dim3((nb + COLSORT_WIN - 1) / COLSORT_WIN), dim3(COLSORT_WIN), s, Wk, g, c, nb, col0, nct, g_colsort_min);
     LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, idrv, istart);
     if (mode == 1 || mode == 2) {
         LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag, mode);
@@ -661,7 +673,7 @@ template <bool GCM>
 int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
               const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
 {
-    const Workspace Wk = ws_for(0);
+    const Workspace Wk = ws_for(0, use_colsort(GCM, mode) && !mc);
     if (int rc = run_prep<GCM>(s, Wk, nb, col0, nct, mode, idrv, istart, g, c, inflag, iceflag, liqflag)) return rc;
     if (int rc = run_layer<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, mc)) return rc;
     return run_sweep<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, out, mc);
@@ -720,7 +732,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
     int i = 0;
     for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
-        const Workspace Wk = ws_for(k);
+        const Workspace Wk = ws_for(k, use_colsort(true, mode) && !mc && !gen.on);
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(aux, G.ev_done[k], 0));       // prep set k is free again (sweep of batch i-2 done)
         // (The per-column kernels of batch i thus run beside k_layer of batch i-1.  Their few long-lived waves cost whatever runs beside
         // them about what the overlap saves - measured per 1e6 columns: k_layer 32.7 ms beside them, 28.3 alone, step 93.9 vs 96.0 on one
@@ -1809,6 +1821,18 @@ int rrtmg_lw_hip_set_one_sweep_max(int ncol)
     ENTRY_LOCK;
     const int prev = g_one_sweep_max;
     g_one_sweep_max = ncol < 0 ? 0 : ncol;
+    return prev;
+}
+
+// The columns of a cloudy non-McICA batch are taken in k_colsort's order (by cloud top within windows of 256 columns): on = 1 / off = 0.
+// min_gain >= 0: the block-levels a window's reordering must take out of the cloud zone (k_colsort; < 0 keeps the value).
+// Results do not depend on it.  Returns the previous value.
+int rrtmg_lw_hip_set_column_sort(int on, int min_gain)
+{
+    ENTRY_LOCK;
+    const int prev = g_colsort ? 1 : 0;
+    g_colsort = on != 0;
+    if (min_gain >= 0) g_colsort_min = min_gain;
     return prev;
 }
 

@@ -113,7 +113,22 @@ struct Workspace {
     unsigned *mask;     // [MASK_WORDS][nlay][mask_stride]      sub-column cloud mask of ALL columns of the call (indexed by the global
     size_t mask_stride; //                             column mask_col0 + col0 + col), bit k of word w = sub-column 32 w + k
     size_t mask_col0;
+    // The order in which the batch's columns are taken (k_colsort): position (slot) -> column of the batch, or null = as they come.  Every
+    // workspace array above is indexed by SLOT, the caller's arrays by COLUMN (pcol).
+    int *perm;          // [ncolb rounded up to whole windows]
+    int *inv;           // ... and column -> position (k_flux writes the caller's arrays column by column)
 };
+__device__ __forceinline__ int pcol(const Workspace &W, int slot) { return W.perm ? W.perm[slot] : slot; }
+// One value of a row of the caller's (column-fastest) arrays: wave-uniform row pointer in a buffer descriptor, the lane's column as a 32-bit
+// byte offset - the column is a loaded value (pcol), and as part of a 64-bit address it would cost every load its own address arithmetic.
+__device__ __forceinline__ double col_load(const double *row, unsigned off8)
+{
+    typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
+    const u32x2c v = __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(row), 0, 0x7ffffff0, 0x00020000), (int)off8, 0, 0);
+    double r;
+    __builtin_memcpy(&r, &v, 8);
+    return r;
+}
 
 // GCM-interface inputs (device pointers, column stride = ncol_total), reference src/rrtmg_lw_rad.nomcica.f90:219-276
 struct GcmIn {
@@ -165,6 +180,58 @@ __device__ __forceinline__ double fdiv(double a, double b)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_colsort : the order in which every later kernel takes the batch's columns.  The sweeps decide per wavefront - 64 consecutive positions -
+//             where the clouds end (Workspace::btop): one deep tower among 64 shallow columns sends all of them through the cloud-zone sweep
+//             up to its top, and one cloudy column among clear ones likewise.  Within each window of COLSORT_WIN consecutive columns (the
+//             columns of ONE k_layer workgroup, so that what a workgroup reads of the caller's arrays is the same few cache lines in any
+//             order) the columns are ordered by their highest cloudy layer, deepest first, equal tops in column order - a homogeneous window
+//             keeps its order.  Results do not depend on the order (a column does not depend on its neighbours); the reference has no
+//             counterpart: it takes the columns one by one (src/rrtmg_lw_rad.nomcica.f90:472).
+// ------------------------------------------------------------------------------------------------
+#ifndef RRLW_COLSORT_WIN
+#define RRLW_COLSORT_WIN 256
+#endif
+constexpr int COLSORT_WIN = RRLW_COLSORT_WIN;
+// A window is reordered only where that pays: reading the caller's arrays out of order costs every kernel something (eight-byte accesses
+// spread over the window's cache lines instead of consecutive ones), so the order is taken when it removes at least `min_gain` block-levels
+// from the cloud zone - the sum over the window's four 64-column blocks of the block's highest cloudy layer, as the columns lie against
+// sorted - and the window keeps its order otherwise (a homogeneous deck, a tower system that fills whole blocks).
+template <bool GCM>
+__global__ __launch_bounds__(COLSORT_WIN) void k_colsort(Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int min_gain)
+{
+    constexpr int NB = COLSORT_WIN / 64;
+    __shared__ int s_key[COLSORT_WIN];
+    __shared__ int s_nat[NB], s_srt[NB];
+    const int t = threadIdx.x, w0 = blockIdx.x * COLSORT_WIN, col = w0 + t;
+    const int nlay = W.nlay;
+    int top = -1;                                   // a position past the last column: after everything
+    if (col < ncol) {
+        const double *cf = (GCM ? g.cldfr : c.cldfrac) + (size_t)col0 + col;
+        top = 0;
+#pragma unroll 8
+        for (int lay = 1; lay <= nlay; lay++) { if (cf[(size_t)nct * (lay - 1)] >= 1.e-6) top = lay; }      // (k_cloudscan's `cloudy`)
+    }
+    const int key = (nlay - top) * COLSORT_WIN + t; // deepest first, then column order
+    s_key[t] = key;
+    int mx = max(top, 0);                           // the block's top as the columns lie: a wave = 64 consecutive columns
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) s_nat[t >> 6] = mx;
+    __syncthreads();
+    int rank = 0;
+#pragma unroll 8
+    for (int i = 0; i < COLSORT_WIN; i++) rank += s_key[i] < key ? 1 : 0;
+    if ((rank & 63) == 0) s_srt[rank >> 6] = max(top, 0);      // ... and sorted: the first of every 64 is the deepest
+    __syncthreads();
+    int gain = 0;
+#pragma unroll
+    for (int b = 0; b < NB; b++) gain += s_nat[b] - s_srt[b];
+    if (gain * 4 < min_gain * NB) rank = t;         // (uniform over the workgroup; min_gain is quoted for four blocks)
+    W.perm[w0 + rank] = col;
+    W.inv[col] = w0 + rank;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_colprep : the per-column reductions of inatm (src/rrtmg_lw_rad.nomcica.f90:785-870: amttl, wvttl ->
 //             pwvcm), setcoef's laytrop count and surface Planck terms (src/rrtmg_lw_setcoef.f90:173-215,
 //             :312-313) and the diffusivity secants (src/rrtmg_lw_rtrn.f90:265-288).
@@ -174,7 +241,7 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
-    const size_t gc = (size_t)col0 + col;
+    const size_t gc = (size_t)col0 + pcol(W, col);
     const int nlay = W.nlay;
     const double *S = T.stat;
     const double *totplnk = S + T.sl.totplnk, *totplnkd = S + T.sl.totplnkderiv;
@@ -323,7 +390,7 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
-    const size_t gc = (size_t)col0 + col;
+    const size_t gc = (size_t)col0 + pcol(W, col);
     const int nlay = W.nlay;
     const double *cldfr = GCM ? g.cldfr : c.cldfrac;
     const double *ciwp_ = GCM ? g.cicewp : c.ciwp, *clwp_ = GCM ? g.cliqwp : c.clwp;
@@ -395,7 +462,7 @@ __global__ __launch_bounds__(256) void k_cloudlay(DevTables T, Workspace W, GcmI
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
     const int lay = blockIdx.y + 1;
-    const size_t gc = (size_t)col0 + col;
+    const size_t gc = (size_t)col0 + pcol(W, col);
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
     const size_t gi = gc + (size_t)nct * (lay - 1);
@@ -1489,7 +1556,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 
 // workgroup-level state of the LDS staging: the staged region (lower / upper atmosphere), first pressure plane and first minor-gas
 // temperature slice, this thread's place in the copy loops, and whether this thread's cell lies inside the staged window
-struct LayerWg { double2 *lds; int jp0, im0, tid, nth; bool lower, ok; };
+struct LayerWg { double2 *lds; int jp0, im0, tid, nth, pc; bool lower, ok; };      // pc: the thread's column of the batch (caller arrays; `col` is its position)
 
 // all cells of band B for one (layer, column); BASE_LO / BASE_UP: where the band's tables start in the staging buffer of its pass
 template <int B, int CLOUD, int BASE_LO, int BASE_UP>
@@ -1502,11 +1569,11 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
 #pragma unroll
     for (int r = 0; r < NROLE; r++) delta[r] = 0u;
     const bool use_lds = __builtin_amdgcn_ballot_w64(!wg.ok) == 0ull;       // wave-uniform: every cell of the wave lies in the staged window
-    const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + col;
+    const size_t ncb = W.ncolb, gcx = (size_t)a.col0 + wg.pc;
     double odcld = 0.0;
     if constexpr (CLOUD == 1 || CLOUD == 3) { if (cloudy) odcld = W.odcld[((size_t)(B - 1) * W.nlay + (lay - 1)) * ncb + col]; }   // (written for cloudy layers only)
     const double secdiff = W.percol[(size_t)(PC_SECDIFF + B - 1) * ncb + col];
-    const double taua = a.tauaer[gcx + (size_t)a.nct * ((lay - 1) + (size_t)W.nlay * (B - 1))];
+    const double taua = col_load(a.tauaer + (size_t)a.col0 + (size_t)a.nct * ((lay - 1) + (size_t)W.nlay * (B - 1)), (unsigned)wg.pc * 8u);
     unsigned gbits = 0u;
     if constexpr (CLOUD == 3) {
         // the band's bits of the sub-column mask: the one or two words that hold them, read here (all five held from the top of the kernel
@@ -1597,7 +1664,8 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
     const bool incol = colr < a.ncol;
     const int col = incol ? colr : a.ncol - 1;      // threads past the end shadow the last column (they take part in the staging and the barriers)
     const int lay = blockIdx.y + 1;
-    const size_t gc = (size_t)a.col0 + col;
+    const int pc = pcol(W, col);                    // the column this position holds (k_colsort)
+    const size_t gc = (size_t)a.col0 + pc;
     const int nct = a.nct;
     const size_t gi = gc + (size_t)nct * (lay - 1);
     const double *S = T.stat;
@@ -1608,11 +1676,13 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
     double pavel, tavel, coldry, wbrodl, w1, w2, w3, w4, w5, w6, w7;
     LayerCoef C;
     if (GCM) {
-        pavel = g.play[gi];
-        tavel = g.tlay[gi];
-        const double pz_lo = g.plev[gi], pz_hi = g.plev[gc + (size_t)nct * lay];
-        w1 = g.h2ovmr[gi]; w2 = g.co2vmr[gi]; w3 = g.o3vmr[gi]; w4 = g.n2ovmr[gi];
-        w5 = 0.0; w6 = g.ch4vmr[gi]; w7 = g.o2vmr[gi];
+        const size_t ro = (size_t)a.col0 + (size_t)nct * (lay - 1);      // the layer's row of a (ncol, nlay) array (uniform)
+        const unsigned o8 = (unsigned)pc * 8u;
+        pavel = col_load(g.play + ro, o8);
+        tavel = col_load(g.tlay + ro, o8);
+        const double pz_lo = col_load(g.plev + ro, o8), pz_hi = col_load(g.plev + ro + nct, o8);
+        w1 = col_load(g.h2ovmr + ro, o8); w2 = col_load(g.co2vmr + ro, o8); w3 = col_load(g.o3vmr + ro, o8); w4 = col_load(g.n2ovmr + ro, o8);
+        w5 = 0.0; w6 = col_load(g.ch4vmr + ro, o8); w7 = col_load(g.o2vmr + ro, o8);
         const double amm = (1. - w1) * amd + w1 * amw;
         coldry = fdiv((pz_lo - pz_hi) * 1.e3 * avogad, 1.e2 * grav * amm * (1. + w1));
         double summol = 0.0;
@@ -1621,10 +1691,10 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
         wbrodl = coldry * (1. - summol);
         w1 = coldry * w1; w2 = coldry * w2; w3 = coldry * w3; w4 = coldry * w4;
         w5 = coldry * w5; w6 = coldry * w6; w7 = coldry * w7;
-        C.f[F_WX1] = coldry * g.ccl4vmr[gi] * 1.e-20;
-        C.f[F_WX2] = coldry * g.cfc11vmr[gi] * 1.e-20;
-        C.f[F_WX3] = coldry * g.cfc12vmr[gi] * 1.e-20;
-        C.f[F_WX4] = coldry * g.cfc22vmr[gi] * 1.e-20;
+        C.f[F_WX1] = coldry * col_load(g.ccl4vmr + ro, o8) * 1.e-20;
+        C.f[F_WX2] = coldry * col_load(g.cfc11vmr + ro, o8) * 1.e-20;
+        C.f[F_WX3] = coldry * col_load(g.cfc12vmr + ro, o8) * 1.e-20;
+        C.f[F_WX4] = coldry * col_load(g.cfc22vmr + ro, o8) * 1.e-20;
     } else {
         pavel = c.pavel[gi];
         tavel = c.tavel[gi];
@@ -1712,7 +1782,7 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
     if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; s_wg[2] = 99; }
     __syncthreads();
     LayerWg wg;
-    wg.lds = s_tab; wg.tid = threadIdx.x; wg.nth = blockDim.x;
+    wg.lds = s_tab; wg.tid = threadIdx.x; wg.nth = blockDim.x; wg.pc = pc;
     wg.lower = s_wg[0] != 0;
     if (lower == wg.lower) { atomicMin(&s_wg[1], jp); atomicMin(&s_wg[2], indminor); }
     __syncthreads();
@@ -2752,7 +2822,8 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     const int colc = incol ? col : a.ncol - 1;
     const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B) + part * G);
     const int g0 = NG * part;                                                   // first of this thread's g-points within the band
-    const size_t gc = (size_t)a.col0 + colc;
+    const int pc = pcol(W, colc);                                               // the column at this position (caller arrays)
+    const size_t gc = (size_t)a.col0 + pc;
     const int nlay = W.nlay, nct = a.nct;
     const size_t ncb = W.ncolb;
     const bool alt16 = (B == 16 && a.istart == 16);
@@ -2768,7 +2839,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
     const double *__restrict__ tlay = a.tlay + a.col0;
     const double *__restrict__ tlev = a.tlev + a.col0;
-    const unsigned offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
+    const unsigned offc = (unsigned)colc * (unsigned)CODE_BYTES, off8p = (unsigned)pc * 8u, off4 = (unsigned)colc * 4u;
     const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;        // (uniform: the group's slabs; a lane's column is the 32-bit offset of a buffer store)
     double *__restrict__ gdn1 = W.gdn1 + gslab;
     double *__restrict__ gup1 = W.gup1 + gslab;
@@ -2784,8 +2855,8 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     // temperature the sweep direction needs: 0 = level lev - 1 (below the layer, downward sweep), 1 = level lev (above, upward sweep)
     auto fill_t = [&](auto bin_tag, int lev, int zoff, SweepcLev<G> &q) {
         const int l = min(max(lev, 1), nlay);
-        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8);
-        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8);
+        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8p);
+        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8p);
         if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
     };
     auto ld_c = [&](int lev, int k) -> pk4 {
@@ -3081,7 +3152,8 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     const int colc = incol ? col : a.ncol - 1;
     const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B) + part * G);
     const int g0 = NG * part;
-    const size_t gc = (size_t)a.col0 + colc;
+    const int pc = pcol(W, colc);                                               // (see k_sweepc)
+    const size_t gc = (size_t)a.col0 + pc;
     const int nlay = W.nlay, nct = a.nct;
     const size_t ncb = W.ncolb;
     const bool alt16 = (B == 16 && a.istart == 16);
@@ -3100,7 +3172,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     const double *__restrict__ tlay = a.tlay + a.col0;
     const double *__restrict__ tlev = a.tlev + a.col0;
     const double *__restrict__ cldf = a.cldfrac + a.col0;
-    const unsigned off16 = (unsigned)colc * 16u, offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
+    const unsigned off16 = (unsigned)colc * 16u, offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off8p = (unsigned)pc * 8u, off4 = (unsigned)colc * 4u;
     const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;
     Part2 *__restrict__ gdn = W.gdn + gslab;
     Part2 *__restrict__ gup = W.gup + gslab;
@@ -3120,10 +3192,10 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     // (LITE: a level below the group's lowest cloud - no column of the workgroup is cloudy there: its cloud fraction and flag word are not read)
     auto fill_t = [&](auto bin_tag, auto lite_tag, int lev, int zoff, SweepzLev &q) {
         const int l = clampl(lev);
-        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8);
-        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8);
+        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8p);
+        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8p);
         if constexpr (!decltype(lite_tag)::value) {
-            q.cf = bload_f64(cldf + (size_t)nct * (l - 1), off8);
+            q.cf = bload_f64(cldf + (size_t)nct * (l - 1), off8p);
             q.flag = bload_u32(sFlag + (size_t)l * ncb, off4);
         }
         if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
@@ -3679,20 +3751,21 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
 {
     __shared__ double s_net[FLUX_LV + 1][64], s_netc[FLUX_LV + 1][64];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * 64 + tx;
+    const int col = blockIdx.x * 64 + tx;                   // a COLUMN of the batch: the caller's arrays are written 64 consecutive columns at a time ...
     const int nlay = W.nlay;
     const int lev = blockIdx.y * FLUX_LV + ty;              // ty = FLUX_LV: the first level of the next workgroup (sums only)
     const bool on = col < ncol && lev <= nlay;
     const size_t gc = (size_t)col0 + col;
+    const int slot = (on && W.inv) ? W.inv[col] : col;      // ... and the partials read at the position the column was swept at (k_colsort)
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
     if (on) {
         // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
         // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
-        const int ltop = clear_from_total ? 0 : W.hblk[blockIdx.x];                          // hand-off level of this 64-column block
-        const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // uniform over the wave
+        const int ltop = clear_from_total ? 0 : W.hblk[slot >> 6];                           // hand-off level of the position's 64-column block
+        const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // (uniform over the wave unless the window was reordered)
         for (int g = 0; g < ngroups; g++) {
-            const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;
+            const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + slot;
             Part2 su, sd, sq{0.0, 0.0};
             if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
             if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];

@@ -31,11 +31,15 @@ def hip():
     api.finalize()
 
 
-@pytest.fixture(params=["three sweep launches", "one sweep launch"])
+@pytest.fixture(params=["three sweep launches", "one sweep launch", "columns taken by cloud top"])
 def sweeps(request, hip):
     """Cloudy batches of up to 4096 columns take one sweep launch per band group (the cloud-zone kernel over all levels) instead of three
     (rrtmg_lw_hip_set_one_sweep_max).  The tests' column counts are below that, so the tests that pin the sweeps - the reference fixtures,
-    the cloud-structure cases, the fuzz - run both ways: the three launches are what every production-size batch takes."""
-    prev = hip.set_one_sweep_max(0 if request.param.startswith("three") else 1 << 30)
+    the cloud-structure cases, the fuzz - run both ways: the three launches are what every production-size batch takes.  Third way: every
+    window of 256 columns reordered by cloud top (rrtmg_lw_hip_set_column_sort with threshold 0; by default only windows where that pays
+    are, which small test inputs rarely reach), three launches."""
+    prev = hip.set_one_sweep_max(1 << 30 if request.param.startswith("one") else 0)
+    prev_sort = hip.set_column_sort(True, 0 if request.param.startswith("columns") else 1 << 20)
     yield request.param
     hip.set_one_sweep_max(prev)
+    hip.set_column_sort(prev_sort, 40)

@@ -692,6 +692,32 @@ def test_one_sweep_launch_is_transparent(hip, oracle, config, icld, idrv, mcica)
         assert np.array_equal(three[k], one[k]), k
 
 
+@pytest.mark.parametrize("config,icld,idrv", [("cloudy_scatter", 2, 0), ("cloudy_deep", 2, 0), ("cloudy_deep", 1, 0), ("aer_idrv", 2, 1), ("cloudy", 2, 0)])
+def test_column_order_is_transparent(hip, oracle, config, icld, idrv):
+    """k_colsort takes the columns of a cloudy batch by cloud top within windows of 256 where that pays (rrtmg_lw_hip_set_column_sort): the
+    caller's arrays are read and written through that order and the outputs are equal bit for bit to those of the columns as they lie -
+    every window reordered (threshold 0), the default threshold, a column count that ends inside a window, several batches per call, and
+    against the oracle."""
+    ncol, nlay = 1333, 72
+    d = make_gcm_inputs(ncol, nlay, config, col0=40)
+    prev = hip.set_column_sort(False)
+    try:
+        plain = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+        res = {}
+        for name, mn, batch in (("every window", 0, 131072), ("default threshold", 40, 131072), ("three batches", 0, 512)):
+            hip.set_column_sort(True, mn)
+            hip.set_batch(batch)
+            res[name] = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+    finally:
+        hip.set_batch(131072)
+        hip.set_column_sort(prev, 40)
+    for name, got in res.items():
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if idrv else ()):
+            assert np.array_equal(plain[k], got[k]), (name, k)
+    ref = oracle.rrtmg_lw(ncol, nlay, icld, idrv, d)
+    _compare_thin_layers(res["every window"], ref, d, idrv, f"column order {config} icld={icld}")
+
+
 def test_workspace_grows_with_call_shapes(hip, oracle):
     """The per-batch workspace holds what the call shapes seen so far need (partial slabs of 4 band groups without d/dT and up to 8 with,
     the d/dT slab, rtrn's emissivity term, rtrnmr's overlap factors): a library initialised afresh sees the shapes in an order that makes
