@@ -414,7 +414,7 @@ int ensure_mask(int nlay, size_t ncol)
 // Columns of a cloudy non-McICA batch are taken in the order k_colsort gives them (by cloud top within windows of 256: the sweeps decide
 // per 64 positions where the clouds end).  rrtmg_lw_hip_set_column_sort / RRTMG_LW_COLSORT=0 switch it off; results do not depend on it.
 bool g_colsort = []() { const char *e = getenv("RRTMG_LW_COLSORT"); return !e || atoi(e) != 0; }();
-bool use_colsort(bool gcm, int mode) { return g_colsort && gcm && (mode == 1 || mode == 2); }
+bool use_colsort(bool gcm, int mode, int nb);
 // block-levels a window's reordering must take out of the cloud zone (k_colsort; measured break-even on an MI355X, profiles/round4_column_order.md)
 int g_colsort_min = []() { const char *e = getenv("RRTMG_LW_COLSORT_MIN"); return e ? atoi(e) : 40; }();
 
@@ -474,6 +474,8 @@ void drop_sweep_set(int k)
 // clouds k_sweepc costs a third of k_sweepz's clear-sky body per level.
 int g_one_sweep_max = []() { const char *e = getenv("RRTMG_LW_ONE_SWEEP_MAX"); return e ? atoi(e) : 4096; }();       // rrtmg_lw_hip_set_one_sweep_max
 bool one_sweep(int nb, int mode) { return mode != 0 && nb <= g_one_sweep_max; }
+// (a batch that takes one sweep launch walks every level in the cloud-zone kernel whatever its blocks hold: nothing to gain from an order)
+bool use_colsort(bool gcm, int mode, int nb) { return g_colsort && gcm && (mode == 1 || mode == 2) && !one_sweep(nb, mode); }
 
 // per-column part of one batch: k_colprep (+ k_cloudscan / k_cloudlay for rtrn / rtrnmr): it runs on the
 // auxiliary stream one batch ahead of the heavy kernels (run_pipelined).
@@ -673,7 +675,7 @@ template <bool GCM>
 int run_batch(hipStream_t s, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
               const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, const FluxOut &out, const McIn *mc = nullptr)
 {
-    const Workspace Wk = ws_for(0, use_colsort(GCM, mode) && !mc);
+    const Workspace Wk = ws_for(0, use_colsort(GCM, mode, nb) && !mc);
     if (int rc = run_prep<GCM>(s, Wk, nb, col0, nct, mode, idrv, istart, g, c, inflag, iceflag, liqflag)) return rc;
     if (int rc = run_layer<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, inflag, iceflag, liqflag, mc)) return rc;
     return run_sweep<GCM>(s, Wk, nb, col0, nct, nlay, mode, idrv, istart, iend, g, c, out, mc);
@@ -732,7 +734,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
     int i = 0;
     for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
-        const Workspace Wk = ws_for(k, use_colsort(true, mode) && !mc && !gen.on);
+        const Workspace Wk = ws_for(k, use_colsort(true, mode, nb) && !mc && !gen.on);
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(aux, G.ev_done[k], 0));       // prep set k is free again (sweep of batch i-2 done)
         // (The per-column kernels of batch i thus run beside k_layer of batch i-1.  Their few long-lived waves cost whatever runs beside
         // them about what the overlap saves - measured per 1e6 columns: k_layer 32.7 ms beside them, 28.3 alone, step 93.9 vs 96.0 on one
