@@ -53,7 +53,7 @@ struct State {
     int ws_groups = 0;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *inv; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *inv, *wsort; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -361,6 +361,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
         items.push_back({(void **)&ps.hbot, (nslot / SORT_GROUP) * 4});
         items.push_back({(void **)&ps.perm, align_up(n, COLSORT_WIN) * 4});
         items.push_back({(void **)&ps.inv, align_up(n, COLSORT_WIN) * 4});
+        items.push_back({(void **)&ps.wsort, (align_up(n, COLSORT_WIN) / COLSORT_WIN) * 4});
     }
     if (cloud) items.push_back({(void **)&W.hand, (size_t)5 * NQUAD * 4 * n * 8});
     if (cloud) {
@@ -425,6 +426,7 @@ Workspace ws_for(int k, bool sorted)
     const State::PrepSet &ps = G.prep[k];
     w.perm = sorted ? ps.perm : nullptr;
     w.inv = sorted ? ps.inv : nullptr;
+    w.wsort = sorted ? ps.wsort : nullptr;
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
     w.odcld = ps.odcld; w.efcl = ps.efcl; w.ovl = ps.ovl;
     w.btop = ps.btop; w.order = ps.order; w.hgrp = ps.hgrp; w.hblk = ps.hblk; w.bbot = ps.bbot; w.hbot = ps.hbot;

@@ -117,6 +117,7 @@ struct Workspace {
     // workspace array above is indexed by SLOT, the caller's arrays by COLUMN (pcol).
     int *perm;          // [ncolb rounded up to whole windows]
     int *inv;           // ... and column -> position (k_flux writes the caller's arrays column by column)
+    int *wsort;         // [windows] 1: the window's columns are taken in another order than they lie
 };
 __device__ __forceinline__ int pcol(const Workspace &W, int slot) { return W.perm ? W.perm[slot] : slot; }
 // One value of a row of the caller's (column-fastest) arrays: wave-uniform row pointer in a buffer descriptor, the lane's column as a 32-bit
@@ -226,7 +227,9 @@ __global__ __launch_bounds__(COLSORT_WIN) void k_colsort(Workspace W, GcmIn g, C
     int gain = 0;
 #pragma unroll
     for (int b = 0; b < NB; b++) gain += s_nat[b] - s_srt[b];
-    if (gain * 4 < min_gain * NB) rank = t;         // (uniform over the workgroup; min_gain is quoted for four blocks)
+    const bool keep = gain * 4 < min_gain * NB;     // (uniform over the workgroup; min_gain is quoted for four blocks)
+    if (keep) rank = t;
+    if (t == 0) W.wsort[blockIdx.x] = keep ? 0 : 1;
     W.perm[w0 + rank] = col;
     W.inv[col] = w0 + rank;
 }
@@ -3756,13 +3759,16 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
     const int lev = blockIdx.y * FLUX_LV + ty;              // ty = FLUX_LV: the first level of the next workgroup (sums only)
     const bool on = col < ncol && lev <= nlay;
     const size_t gc = (size_t)col0 + col;
-    const int slot = (on && W.inv) ? W.inv[col] : col;      // ... and the partials read at the position the column was swept at (k_colsort)
+    // ... and the partials read at the position the column was swept at (k_colsort); a window that kept its order - one scalar flag says so -
+    // takes the position for the column and its block's hand-off level from a scalar register, as without an order
+    const bool moved = W.inv && W.wsort[blockIdx.x / (COLSORT_WIN / 64)] != 0;      // (uniform)
+    const int slot = (on && moved) ? W.inv[col] : col;
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
     if (on) {
         // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
         // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
-        const int ltop = clear_from_total ? 0 : W.hblk[slot >> 6];                           // hand-off level of the position's 64-column block
+        const int ltop = clear_from_total ? 0 : (moved ? W.hblk[slot >> 6] : W.hblk[blockIdx.x]);     // hand-off level of the position's 64-column block
         const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // (uniform over the wave unless the window was reordered)
         for (int g = 0; g < ngroups; g++) {
             const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + slot;
