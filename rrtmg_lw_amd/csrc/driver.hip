@@ -477,7 +477,9 @@ void drop_sweep_set(int k)
 int g_one_sweep_max = []() { const char *e = getenv("RRTMG_LW_ONE_SWEEP_MAX"); return e ? atoi(e) : 4096; }();       // rrtmg_lw_hip_set_one_sweep_max
 bool one_sweep(int nb, int mode) { return mode != 0 && nb <= g_one_sweep_max; }
 // (a batch that takes one sweep launch walks every level in the cloud-zone kernel whatever its blocks hold: nothing to gain from an order)
-bool use_colsort(bool gcm, int mode, int nb) { return g_colsort && gcm && (mode == 1 || mode == 2) && !one_sweep(nb, mode); }
+// (McICA, mode 3: with the generator's mask - the grid-mean cloud fraction gives the key; the sub-column ARRAYS of the reference's McICA
+// argument list come without one and keep their order: the call sites pass `!mc`)
+bool use_colsort(bool gcm, int mode, int nb) { return g_colsort && gcm && (mode == 1 || mode == 2 || mode == 3) && !one_sweep(nb, mode); }
 
 // per-column part of one batch: k_colprep (+ k_cloudscan / k_cloudlay for rtrn / rtrnmr): it runs on the
 // auxiliary stream one batch ahead of the heavy kernels (run_pipelined).
@@ -736,7 +738,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
     int i = 0;
     for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
-        const Workspace Wk = ws_for(k, use_colsort(true, mode, nb) && !mc && !gen.on);
+        const Workspace Wk = ws_for(k, use_colsort(true, mode, nb) && !mc);
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(aux, G.ev_done[k], 0));       // prep set k is free again (sweep of batch i-2 done)
         // (The per-column kernels of batch i thus run beside k_layer of batch i-1.  Their few long-lived waves cost whatever runs beside
         // them about what the overlap saves - measured per 1e6 columns: k_layer 32.7 ms beside them, 28.3 alone, step 93.9 vs 96.0 on one

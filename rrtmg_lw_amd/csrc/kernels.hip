@@ -119,7 +119,18 @@ struct Workspace {
     int *inv;           // ... and column -> position (k_flux writes the caller's arrays column by column)
     int *wsort;         // [windows] 1: the window's columns are taken in another order than they lie
 };
-__device__ __forceinline__ int pcol(const Workspace &W, int slot) { return W.perm ? W.perm[slot] : slot; }
+#ifndef RRLW_COLSORT_WIN
+#define RRLW_COLSORT_WIN 256
+#endif
+constexpr int COLSORT_WIN = RRLW_COLSORT_WIN;       // columns of a k_colsort window
+// (a wavefront's positions lie in ONE window - 64 consecutive positions from a multiple of 64, or all the last column's: the window's flag is
+// a scalar load, and a window that kept its order does not wait for its `perm` entries, a cold vector load at the head of every kernel)
+__device__ __forceinline__ int pcol(const Workspace &W, int slot)
+{
+    if (!W.perm) return slot;
+    const int moved = W.wsort[__builtin_amdgcn_readfirstlane(slot) / COLSORT_WIN];     // (uniform address: a scalar load)
+    return moved ? W.perm[slot] : slot;
+}
 // One value of a row of the caller's (column-fastest) arrays: wave-uniform row pointer in a buffer descriptor, the lane's column as a 32-bit
 // byte offset - the column is a loaded value (pcol), and as part of a 64-bit address it would cost every load its own address arithmetic.
 __device__ __forceinline__ double col_load(const double *row, unsigned off8)
@@ -189,10 +200,6 @@ __device__ __forceinline__ double fdiv(double a, double b)
 //             keeps its order.  Results do not depend on the order (a column does not depend on its neighbours); the reference has no
 //             counterpart: it takes the columns one by one (src/rrtmg_lw_rad.nomcica.f90:472).
 // ------------------------------------------------------------------------------------------------
-#ifndef RRLW_COLSORT_WIN
-#define RRLW_COLSORT_WIN 256
-#endif
-constexpr int COLSORT_WIN = RRLW_COLSORT_WIN;
 // A window is reordered only where that pays: reading the caller's arrays out of order costs every kernel something (eight-byte accesses
 // spread over the window's cache lines instead of consecutive ones), so the order is taken when it removes at least `min_gain` block-levels
 // from the cloud zone - the sum over the window's four 64-column blocks of the block's highest cloudy layer, as the columns lie against
@@ -1822,7 +1829,7 @@ __global__ __launch_bounds__(256) void k_cloudmc(DevTables T, Workspace W, McIn 
     const int lay = blockIdx.y + 1;
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
-    const size_t gc = (size_t)col0 + col;
+    const size_t gc = (size_t)col0 + pcol(W, col);
     const size_t cl = gc + (size_t)nct * (lay - 1);
     const double *S = T.stat;
     const double *absice1 = S + T.sl.absice1, *absice2 = S + T.sl.absice2, *absice3 = S + T.sl.absice3, *absliq1 = S + T.sl.absliq1;
