@@ -5,6 +5,8 @@
 // store of profile, scratch and flux data a full-width coalesced access.  The work is split where the
 // reference's data dependence allows it:
 //
+//   k_colsort  cloudy batches: the order in which the later kernels take the columns - by cloud top within windows of 256, where that
+//              makes the sweeps' 64-column blocks alike (workspace arrays by position, the caller's arrays by column)   1 workgroup / window
 //   k_colprep  per-column scalars: laytrop, precipitable water -> diffusivity secants, surface Planck
 //              terms                                                    1 thread / column
 //   k_cloudscan / k_cloudlay   cldprop, cloud optical depth per spectral band: the one quantity cldprop carries from layer
