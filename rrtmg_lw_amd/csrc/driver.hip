@@ -53,7 +53,7 @@ struct State {
     int ws_groups = 0;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *inv, *wsort; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *inv, *wsort; double *tlayc, *tlevc, *cldfc; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -362,6 +362,11 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
         items.push_back({(void **)&ps.perm, align_up(n, COLSORT_WIN) * 4});
         items.push_back({(void **)&ps.inv, align_up(n, COLSORT_WIN) * 4});
         items.push_back({(void **)&ps.wsort, (align_up(n, COLSORT_WIN) / COLSORT_WIN) * 4});
+        if (cloud) {        // (reordered windows: the temperature and cloud-fraction rows of the caller once more, in position order)
+            items.push_back({(void **)&ps.tlayc, L * n * 8});
+            items.push_back({(void **)&ps.tlevc, (L + 1) * n * 8});
+            items.push_back({(void **)&ps.cldfc, L * n * 8});
+        }
     }
     if (cloud) items.push_back({(void **)&W.hand, (size_t)5 * NQUAD * 4 * n * 8});
     if (cloud) {
@@ -427,6 +432,7 @@ Workspace ws_for(int k, bool sorted)
     w.perm = sorted ? ps.perm : nullptr;
     w.inv = sorted ? ps.inv : nullptr;
     w.wsort = sorted ? ps.wsort : nullptr;
+    w.tlayc = ps.tlayc; w.tlevc = ps.tlevc; w.cldfc = ps.cldfc;
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
     w.odcld = ps.odcld; w.efcl = ps.efcl; w.ovl = ps.ovl;
     w.btop = ps.btop; w.order = ps.order; w.hgrp = ps.hgrp; w.hblk = ps.hblk; w.bbot = ps.bbot; w.hbot = ps.hbot;
@@ -667,6 +673,11 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     {
         const dim3 fgrid2((nb + 63) / 64, (nlay + 1 + FLUX_LV - 1) / FLUX_LV), fblock(64, FLUX_LV + 1);
         LAUNCH("k_flux", k_flux, fgrid2, fblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
+        if (Wk.perm) {      // the windows whose columns were taken in another order (k_colsort)
+            const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, (nlay + 1 + FLUXW_LV - 1) / FLUXW_LV), wblock(COLSORT_WIN, FLUXW_TY);
+            if (idrv == 1) LAUNCH("k_fluxw", (k_fluxw<true>), wgrid, wblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
+            else LAUNCH("k_fluxw", (k_fluxw<false>), wgrid, wblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));

@@ -120,6 +120,9 @@ struct Workspace {
     int *perm;          // [ncolb rounded up to whole windows]
     int *inv;           // ... and column -> position (k_flux writes the caller's arrays column by column)
     int *wsort;         // [windows] 1: the window's columns are taken in another order than they lie
+    // ... and for such windows the rows the sweeps read of the caller's arrays at EVERY level - layer and interface temperatures, cloud
+    // fraction - once more in position order (k_colprep): [nlay | nlay+1 | nlay][ncolb]
+    double *tlayc, *tlevc, *cldfc;
 };
 #ifndef RRLW_COLSORT_WIN
 #define RRLW_COLSORT_WIN 256
@@ -127,6 +130,7 @@ struct Workspace {
 constexpr int COLSORT_WIN = RRLW_COLSORT_WIN;       // columns of a k_colsort window
 // (a wavefront's positions lie in ONE window - 64 consecutive positions from a multiple of 64, or all the last column's: the window's flag is
 // a scalar load, and a window that kept its order does not wait for its `perm` entries, a cold vector load at the head of every kernel)
+__device__ __forceinline__ bool pmoved(const Workspace &W, int slot) { return W.perm && W.wsort[__builtin_amdgcn_readfirstlane(slot) / COLSORT_WIN] != 0; }
 __device__ __forceinline__ int pcol(const Workspace &W, int slot)
 {
     if (!W.perm) return slot;
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
     const size_t gc = (size_t)col0 + pcol(W, col);
+    const bool moved = GCM && pmoved(W, col);
     const int nlay = W.nlay;
     const double *S = T.stat;
     const double *totplnk = S + T.sl.totplnk, *totplnkd = S + T.sl.totplnkderiv;
@@ -284,6 +289,14 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
         const size_t gi = gc + (size_t)nct * (lay - 1);
         const double pavel = GCM ? g.play[gi] : c.pavel[gi];
         if (!(log(pavel) <= 4.56)) laytrop++;
+        if constexpr (GCM) {
+            if (moved) {        // (uniform) the rows the sweeps read at every level, in position order
+                const size_t o = (size_t)(lay - 1) * W.ncolb + col;
+                W.tlayc[o] = g.tlay[gi];
+                W.tlevc[o + W.ncolb] = g.tlev[gc + (size_t)nct * lay];
+                W.cldfc[o] = g.cldfr ? g.cldfr[gi] : 0.0;
+            }
+        }
         if (GCM) {
             const double w1v = g.h2ovmr[gi];
             const double pzl = g.plev[gc + (size_t)nct * lay];
@@ -316,6 +329,7 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
         }
         W.percol[(size_t)(PC_SECDIFF + b) * W.ncolb + col] = sd;
     }
+    if constexpr (GCM) { if (moved) W.tlevc[col] = g.tlev[gc]; }
     W.ncbands[col] = 1;
     W.cflag[col] = 0;
     if ((col & 63) == 0) { W.btop[col >> 6] = 0; W.bbot[col >> 6] = nlay + 1; }          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
@@ -2849,9 +2863,13 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     const size_t qstride = (size_t)nlay * ncb;
     const unsigned *__restrict__ sC = W.scr[S_CODE] + (size_t)quad * qstride * CODE_WORDS;
     const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
-    const double *__restrict__ tlay = a.tlay + a.col0;
-    const double *__restrict__ tlev = a.tlev + a.col0;
-    const unsigned offc = (unsigned)colc * (unsigned)CODE_BYTES, off8p = (unsigned)pc * 8u, off4 = (unsigned)colc * 4u;
+    // (temperatures: the caller's rows - or, for a window whose columns are taken in another order, their copies in position order: the
+    // lane's offset is its position either way, eight consecutive bytes per lane)
+    const bool moved = pmoved(W, colc);
+    const double *__restrict__ tlay = moved ? W.tlayc : a.tlay + a.col0;
+    const double *__restrict__ tlev = moved ? W.tlevc : a.tlev + a.col0;
+    const size_t tstride = moved ? ncb : (size_t)nct;
+    const unsigned offc = (unsigned)colc * (unsigned)CODE_BYTES, off8p = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
     const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;        // (uniform: the group's slabs; a lane's column is the 32-bit offset of a buffer store)
     double *__restrict__ gdn1 = W.gdn1 + gslab;
     double *__restrict__ gup1 = W.gup1 + gslab;
@@ -2867,8 +2885,8 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     // temperature the sweep direction needs: 0 = level lev - 1 (below the layer, downward sweep), 1 = level lev (above, upward sweep)
     auto fill_t = [&](auto bin_tag, int lev, int zoff, SweepcLev<G> &q) {
         const int l = min(max(lev, 1), nlay);
-        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8p);
-        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8p);
+        q.tl = bload_f64(tlay + tstride * (l - 1), off8p);
+        q.tz = bload_f64(tlev + tstride * (l - 1 + zoff), off8p);
         if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
     };
     auto ld_c = [&](int lev, int k) -> pk4 {
@@ -3181,10 +3199,12 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     const unsigned *__restrict__ sCt = W.scr[S_CODET] + (size_t)quad * qstride * CODE_WORDS;
     const unsigned *__restrict__ sFw = W.fw + (size_t)fw_slot(B) * nlay * ncb;
     const int *__restrict__ sFlag = W.cflag;
-    const double *__restrict__ tlay = a.tlay + a.col0;
-    const double *__restrict__ tlev = a.tlev + a.col0;
-    const double *__restrict__ cldf = a.cldfrac + a.col0;
-    const unsigned off16 = (unsigned)colc * 16u, offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off8p = (unsigned)pc * 8u, off4 = (unsigned)colc * 4u;
+    const bool moved = pmoved(W, colc);                                         // (see k_sweepc)
+    const double *__restrict__ tlay = moved ? W.tlayc : a.tlay + a.col0;
+    const double *__restrict__ tlev = moved ? W.tlevc : a.tlev + a.col0;
+    const double *__restrict__ cldf = moved ? W.cldfc : a.cldfrac + a.col0;
+    const size_t tstride = moved ? ncb : (size_t)nct;
+    const unsigned off16 = (unsigned)colc * 16u, offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
     const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;
     Part2 *__restrict__ gdn = W.gdn + gslab;
     Part2 *__restrict__ gup = W.gup + gslab;
@@ -3204,10 +3224,10 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     // (LITE: a level below the group's lowest cloud - no column of the workgroup is cloudy there: its cloud fraction and flag word are not read)
     auto fill_t = [&](auto bin_tag, auto lite_tag, int lev, int zoff, SweepzLev &q) {
         const int l = clampl(lev);
-        q.tl = bload_f64(tlay + (size_t)nct * (l - 1), off8p);
-        q.tz = bload_f64(tlev + (size_t)nct * (l - 1 + zoff), off8p);
+        q.tl = bload_f64(tlay + tstride * (l - 1), off8);
+        q.tz = bload_f64(tlev + tstride * (l - 1 + zoff), off8);
         if constexpr (!decltype(lite_tag)::value) {
-            q.cf = bload_f64(cldf + (size_t)nct * (l - 1), off8p);
+            q.cf = bload_f64(cldf + tstride * (l - 1), off8);
             q.flag = bload_u32(sFlag + (size_t)l * ncb, off4);
         }
         if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
@@ -3771,6 +3791,9 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
     // ... and the partials read at the position the column was swept at (k_colsort); a window that kept its order - one scalar flag says so -
     // takes the position for the column and its block's hand-off level from a scalar register, as without an order
     const bool moved = W.inv && W.wsort[blockIdx.x / (COLSORT_WIN / 64)] != 0;      // (uniform)
+#ifndef RRLW_FLUX_GATHER
+    if (moved) return;                                      // k_fluxw's window (before any barrier: the whole workgroup leaves)
+#endif
     const int slot = (on && moved) ? W.inv[col] : col;
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
@@ -3808,6 +3831,69 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
         const double dp = pz[lo] - pz[hi];
         out.hr[lo] = T.heatfac * (s_net[ty][tx] - s_net[ty + 1][tx]) / dp;
         out.hrc[lo] = T.heatfac * (s_netc[ty][tx] - s_netc[ty + 1][tx]) / dp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fluxw : k_flux for the windows whose columns were taken in another order (k_colsort; the others leave at once, as these leave k_flux).
+//           Read at the column's position, eight bytes per lane, the partial slabs cost k_flux a third more (sixteen cache lines per
+//           access instead of four).  Here a workgroup covers a WINDOW and FLUXW_LV levels: thread (t, .) sums the groups at POSITION
+//           w0 + t exactly as k_flux does (coalesced), the values change places in LDS - position -> column - and thread (t, .) writes
+//           COLUMN w0 + t of the caller's arrays (coalesced); the level above the workgroup's is summed once more for the heating rate of
+//           its last layer, as in k_flux (rtrn :583-604: the same expressions, operands in the same order).
+// ------------------------------------------------------------------------------------------------
+constexpr int FLUXW_LV = 4, FLUXW_TY = 2;
+template <bool IDRV>
+__global__ __launch_bounds__(COLSORT_WIN * FLUXW_TY) void k_fluxw(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct, int ngroups)
+{
+    constexpr int NV = IDRV ? 6 : 4;
+    __shared__ double s_v[FLUXW_LV + 1][NV][COLSORT_WIN];
+    if (W.wsort[blockIdx.x] == 0) return;                   // (uniform) the window kept its order: k_flux's
+    const int t = threadIdx.x, ty = threadIdx.y, w0 = blockIdx.x * COLSORT_WIN;
+    const int slot = w0 + t, col = w0 + t;                  // the position whose partials this thread sums, the column it writes
+    const bool son = slot < ncol, con = col < ncol;
+    const int nlay = W.nlay, lev0 = blockIdx.y * FLUXW_LV;
+    const size_t ncb = W.ncolb, gc = (size_t)col0 + col;
+    const int dst = son ? W.perm[slot] - w0 : t;            // where the position's column lies in the window
+    const int ltop = son ? W.hblk[slot >> 6] : 0;           // hand-off level of the position's block (uniform over the wave)
+    for (int lc = ty; lc <= FLUXW_LV; lc += FLUXW_TY) {
+        const int lev = lev0 + lc;
+        if (son && lev <= nlay) {
+            const bool dn1 = lev >= ltop;
+            double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
+            for (int g = 0; g < ngroups; g++) {
+                const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + slot;
+                Part2 su, sd, sq{0.0, 0.0};
+                if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
+                su = W.gup[go];
+                if constexpr (IDRV) sq = W.gdp[go];
+                u = u + su.a; uc = uc + su.b;
+                d = d + sd.a; dc = dc + sd.b;
+                du = du + sq.a; duc = duc + sq.b;
+            }
+            u = u * T.fluxfac; d = d * T.fluxfac;
+            uc = uc * T.fluxfac; dc = dc * T.fluxfac;
+            s_v[lc][0][dst] = u; s_v[lc][1][dst] = d; s_v[lc][2][dst] = uc; s_v[lc][3][dst] = dc;
+            if constexpr (IDRV) { s_v[lc][4][dst] = du; s_v[lc][5][dst] = duc; }
+        }
+    }
+    __syncthreads();
+    for (int lc = ty; lc < FLUXW_LV; lc += FLUXW_TY) {
+        const int lev = lev0 + lc;
+        if (con && lev <= nlay) {
+            const double u = s_v[lc][0][t], d = s_v[lc][1][t], uc = s_v[lc][2][t], dc = s_v[lc][3][t];
+            const size_t o = gc + (size_t)nct * lev;
+            out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = uc; out.dflxc[o] = dc;
+            if constexpr (IDRV) { out.duflx_dt[o] = s_v[lc][4][t]; out.duflxc_dt[o] = s_v[lc][5][t]; }
+            if (out.fnet) { out.fnet[o] = u - d; out.fnetc[o] = uc - dc; }
+            if (lev < nlay) {
+                const double net = u - d, netc = uc - dc;
+                const double above = s_v[lc + 1][0][t] - s_v[lc + 1][1][t], abovec = s_v[lc + 1][2][t] - s_v[lc + 1][3][t];
+                const double dp = pz[o] - pz[o + (size_t)nct];
+                out.hr[o] = T.heatfac * (net - above) / dp;
+                out.hrc[o] = T.heatfac * (netc - abovec) / dp;
+            }
+        }
     }
 }
 
