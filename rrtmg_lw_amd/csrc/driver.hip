@@ -495,7 +495,11 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
 {
     // thread-per-column kernels: one wave per workgroup so that a batch (one wave per 64 columns) spreads over all 256 CUs
     const dim3 cgrid1((nb + 63) / 64), cblock1(64);
-    if (Wk.perm) LAUNCH("k_colsort", (k_colsort<GCM>), dim3((nb + COLSORT_WIN - 1) / COLSORT_WIN), dim3(COLSORT_WIN), s, Wk, g, c, nb, col0, nct, g_colsort_min);
+    if (Wk.perm) {
+        const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN);
+        LAUNCH("k_colsort", (k_colsort<GCM>), wgrid, dim3(COLSORT_WIN), s, Wk, g, c, nb, col0, nct, g_colsort_min);
+        if constexpr (GCM) LAUNCH("k_rowcopy", k_rowcopy, dim3(wgrid.x, 4), dim3(COLSORT_WIN), s, Wk, g.tlay, g.tlev, g.cldfr, nb, col0, nct);
+    }
     LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, idrv, istart);
     if (mode == 1 || mode == 2) {
         LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag, mode);
@@ -674,7 +678,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         const dim3 fgrid2((nb + 63) / 64, (nlay + 1 + FLUX_LV - 1) / FLUX_LV), fblock(64, FLUX_LV + 1);
         LAUNCH("k_flux", k_flux, fgrid2, fblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
         if (Wk.perm) {      // the windows whose columns were taken in another order (k_colsort)
-            const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, (nlay + 1 + FLUXW_LV - 1) / FLUXW_LV), wblock(COLSORT_WIN, FLUXW_TY);
+            const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, std::min(5, (nlay + 1 + FLUXW_LV - 1) / FLUXW_LV)), wblock(COLSORT_WIN, FLUXW_TY);
             if (idrv == 1) LAUNCH("k_fluxw", (k_fluxw<true>), wgrid, wblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
             else LAUNCH("k_fluxw", (k_fluxw<false>), wgrid, wblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
         }

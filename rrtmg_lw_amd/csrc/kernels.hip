@@ -121,7 +121,7 @@ struct Workspace {
     int *inv;           // ... and column -> position (k_flux writes the caller's arrays column by column)
     int *wsort;         // [windows] 1: the window's columns are taken in another order than they lie
     // ... and for such windows the rows the sweeps read of the caller's arrays at EVERY level - layer and interface temperatures, cloud
-    // fraction - once more in position order (k_colprep): [nlay | nlay+1 | nlay][ncolb]
+    // fraction - once more in position order (k_rowcopy): [nlay | nlay+1 | nlay][ncolb]
     double *tlayc, *tlevc, *cldfc;
 };
 #ifndef RRLW_COLSORT_WIN
@@ -247,6 +247,23 @@ __global__ __launch_bounds__(COLSORT_WIN) void k_colsort(Workspace W, GcmIn g, C
     W.inv[col] = w0 + rank;
 }
 
+// k_rowcopy : for the windows k_colsort reordered, the rows of the caller's arrays that the sweeps read at every level - layer and
+//             interface temperatures, cloud fraction - once more in position order (Workspace::tlayc ..): one thread per (position,
+//             level), reads through `perm`, writes consecutive.  The other windows leave at once.
+__global__ __launch_bounds__(COLSORT_WIN) void k_rowcopy(Workspace W, const double *tlay, const double *tlev, const double *cldfr, int ncol, int col0, int nct)
+{
+    if (W.wsort[blockIdx.x] == 0) return;                   // (uniform; few workgroups per window: one that leaves costs its dispatch)
+    const int slot = blockIdx.x * COLSORT_WIN + threadIdx.x;
+    if (slot >= ncol) return;
+    const size_t g0 = (size_t)col0 + W.perm[slot];
+#pragma unroll 4
+    for (int lev = blockIdx.y; lev <= W.nlay; lev += gridDim.y) {       // level 0 .. nlay; layer lev + 1 for the two layer arrays
+        const size_t gi = g0 + (size_t)nct * lev, o = (size_t)lev * W.ncolb + slot;
+        W.tlevc[o] = tlev[gi];
+        if (lev < W.nlay) { W.tlayc[o] = tlay[gi]; W.cldfc[o] = cldfr ? cldfr[gi] : 0.0; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_colprep : the per-column reductions of inatm (src/rrtmg_lw_rad.nomcica.f90:785-870: amttl, wvttl ->
 //             pwvcm), setcoef's laytrop count and surface Planck terms (src/rrtmg_lw_setcoef.f90:173-215,
@@ -258,7 +275,6 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
     const size_t gc = (size_t)col0 + pcol(W, col);
-    const bool moved = GCM && pmoved(W, col);
     const int nlay = W.nlay;
     const double *S = T.stat;
     const double *totplnk = S + T.sl.totplnk, *totplnkd = S + T.sl.totplnkderiv;
@@ -289,14 +305,6 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
         const size_t gi = gc + (size_t)nct * (lay - 1);
         const double pavel = GCM ? g.play[gi] : c.pavel[gi];
         if (!(log(pavel) <= 4.56)) laytrop++;
-        if constexpr (GCM) {
-            if (moved) {        // (uniform) the rows the sweeps read at every level, in position order
-                const size_t o = (size_t)(lay - 1) * W.ncolb + col;
-                W.tlayc[o] = g.tlay[gi];
-                W.tlevc[o + W.ncolb] = g.tlev[gc + (size_t)nct * lay];
-                W.cldfc[o] = g.cldfr ? g.cldfr[gi] : 0.0;
-            }
-        }
         if (GCM) {
             const double w1v = g.h2ovmr[gi];
             const double pzl = g.plev[gc + (size_t)nct * lay];
@@ -329,7 +337,6 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
         }
         W.percol[(size_t)(PC_SECDIFF + b) * W.ncolb + col] = sd;
     }
-    if constexpr (GCM) { if (moved) W.tlevc[col] = g.tlev[gc]; }
     W.ncbands[col] = 1;
     W.cflag[col] = 0;
     if ((col & 63) == 0) { W.btop[col >> 6] = 0; W.bbot[col >> 6] = nlay + 1; }          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
@@ -3852,10 +3859,12 @@ __global__ __launch_bounds__(COLSORT_WIN * FLUXW_TY) void k_fluxw(DevTables T, W
     const int t = threadIdx.x, ty = threadIdx.y, w0 = blockIdx.x * COLSORT_WIN;
     const int slot = w0 + t, col = w0 + t;                  // the position whose partials this thread sums, the column it writes
     const bool son = slot < ncol, con = col < ncol;
-    const int nlay = W.nlay, lev0 = blockIdx.y * FLUXW_LV;
+    const int nlay = W.nlay;
     const size_t ncb = W.ncolb, gc = (size_t)col0 + col;
     const int dst = son ? W.perm[slot] - w0 : t;            // where the position's column lies in the window
     const int ltop = son ? W.hblk[slot >> 6] : 0;           // hand-off level of the position's block (uniform over the wave)
+    // (a workgroup takes every gridDim.y-th chunk of levels: few workgroups per window - one that leaves costs its dispatch)
+    for (int lev0 = blockIdx.y * FLUXW_LV; lev0 <= nlay; lev0 += gridDim.y * FLUXW_LV) {
     for (int lc = ty; lc <= FLUXW_LV; lc += FLUXW_TY) {
         const int lev = lev0 + lc;
         if (son && lev <= nlay) {
@@ -3894,6 +3903,8 @@ __global__ __launch_bounds__(COLSORT_WIN * FLUXW_TY) void k_fluxw(DevTables T, W
                 out.hrc[o] = T.heatfac * (netc - abovec) / dp;
             }
         }
+    }
+    __syncthreads();                                        // (the next chunk writes the buffer again)
     }
 }
 
