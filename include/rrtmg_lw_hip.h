@@ -254,7 +254,7 @@ int rrtmg_lw_hip_set_one_sweep_max(int ncol);
  * batch are therefore TAKEN in another order than they lie: within each window of 256 consecutive columns by their highest cloudy layer,
  * deepest first (k_colsort); the caller's arrays stay as they are and are read / written through that order.  A window is reordered only
  * where that takes at least `min_gain` block-levels out of the cloud zone (sum over its four 64-column blocks of the highest cloudy layer,
- * as the columns lie against sorted; default 40, RRTMG_LW_COLSORT_MIN; < 0 keeps the value): reading the caller's arrays out of order has a
+ * as the columns lie against sorted; default 24, RRTMG_LW_COLSORT_MIN; < 0 keeps the value): reading the caller's arrays out of order has a
  * price.  on = 1 / off = 0; results do not depend on it (bit for bit).  Returns the previous `on`. */
 int rrtmg_lw_hip_set_column_sort(int on, int min_gain);
 /* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (it holds what the call shapes seen so far need and only

@@ -422,7 +422,7 @@ int ensure_mask(int nlay, size_t ncol)
 bool g_colsort = []() { const char *e = getenv("RRTMG_LW_COLSORT"); return !e || atoi(e) != 0; }();
 bool use_colsort(bool gcm, int mode, int nb);
 // block-levels a window's reordering must take out of the cloud zone (k_colsort; measured break-even on an MI355X, profiles/round4_column_order.md)
-int g_colsort_min = []() { const char *e = getenv("RRTMG_LW_COLSORT_MIN"); return e ? atoi(e) : 40; }();
+int g_colsort_min = []() { const char *e = getenv("RRTMG_LW_COLSORT_MIN"); return e ? atoi(e) : 24; }();
 
 // the workspace view of prep set k (see State::prep); sorted: the batch's columns go through k_colsort's order
 Workspace ws_for(int k, bool sorted)

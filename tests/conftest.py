@@ -42,4 +42,4 @@ def sweeps(request, hip):
     prev_sort = hip.set_column_sort(True, 0 if request.param.startswith("columns") else 1 << 20)
     yield request.param
     hip.set_one_sweep_max(prev)
-    hip.set_column_sort(prev_sort, 40)
+    hip.set_column_sort(prev_sort, 24)

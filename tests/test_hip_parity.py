@@ -705,13 +705,13 @@ def test_column_order_is_transparent(hip, oracle, config, icld, idrv):
     try:
         plain = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
         res = {}
-        for name, mn, batch in (("every window", 0, 131072), ("default threshold", 40, 131072), ("three batches", 0, 512)):
+        for name, mn, batch in (("every window", 0, 131072), ("default threshold", 24, 131072), ("three batches", 0, 512)):
             hip.set_column_sort(True, mn)
             hip.set_batch(batch)
             res[name] = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
     finally:
         hip.set_batch(131072)
-        hip.set_column_sort(prev, 40)
+        hip.set_column_sort(prev, 24)
         hip.set_one_sweep_max(prev_one)
     for name, got in res.items():
         for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if idrv else ()):
