@@ -2157,8 +2157,11 @@ constexpr int KJ_NGROUP = 4 * KJ_NWORD;             // 8-sub-column groups, the 
 
 // RULE 1 random, 2 maximum-random, 3 maximum, 4 exponential / exponential-random (icld 4 and 5 differ in alpha only).
 // jt[g]: jump from the seed to the first sub-column of group g; jsub: jump by one sub-column.
+// (waves per SIMD pinned to what the kernel needs without spilling: left to itself the allocator took 79 / 97 / 95 registers for rules
+// 1 / 2 / 4 after an unrelated change of the argument struct - four waves instead of six, 3.7 -> 4.5 ms per 1e6 columns)
+__host__ __device__ constexpr int kiss_waves(int rule) { return rule == 3 ? 5 : 6; }
 template <int RULE>
-__global__ __launch_bounds__(KJ_BLOCK) void k_subcol_kiss(Workspace W, SubcolIn in, const KissJump *jt, KissJump jsub, int ncol, int col0, int nb, int nlay)
+__global__ __launch_bounds__(KJ_BLOCK, kiss_waves(RULE)) void k_subcol_kiss(Workspace W, SubcolIn in, const KissJump *jt, KissJump jsub, int ncol, int col0, int nb, int nlay)
 {
 #pragma clang fp contract(off)
     extern __shared__ int4 kj_thr[];                             // [nlay][KJ_COLS]
