@@ -258,7 +258,7 @@ int rrtmg_lw_hip_set_one_sweep_max(int ncol);
  * price.  on = 1 / off = 0; results do not depend on it (bit for bit).  Returns the previous `on`. */
 int rrtmg_lw_hip_set_column_sort(int on, int min_gain);
 /* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (it holds what the call shapes seen so far need and only
- * grows: per column of the batch at 72 layers 62 KB for cloud-free calls, 144 KB for rtrnmr, 149 KB for rtrn, 163 KB with idrv = 1; 303 KB at
+ * grows: per column of the batch at 72 layers 62 KB for cloud-free calls, 148 KB for rtrnmr, 152 KB for rtrn, 166 KB with idrv = 1; 310 KB at
  * 137 layers with idrv = 1: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer
  * (<= 512 MB, or one slab) and the cached chunk states (<= 2 x 180 MB) of the Mersenne-Twister stream. */
 long long rrtmg_lw_hip_workspace_bytes(void);

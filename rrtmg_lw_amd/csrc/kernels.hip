@@ -3853,6 +3853,7 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
 //           its last layer, as in k_flux (rtrn :583-604: the same expressions, operands in the same order).
 // ------------------------------------------------------------------------------------------------
 constexpr int FLUXW_LV = 4, FLUXW_TY = 2;
+static_assert((FLUXW_LV + 1) * 6 * COLSORT_WIN * 8 <= 64 * 1024 && COLSORT_WIN * FLUXW_TY <= 1024, "k_fluxw holds a window x (FLUXW_LV + 1) levels x 6 values in static LDS");
 template <bool IDRV>
 __global__ __launch_bounds__(COLSORT_WIN * FLUXW_TY) void k_fluxw(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct, int ngroups)
 {
