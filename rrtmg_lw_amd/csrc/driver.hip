@@ -53,7 +53,7 @@ struct State {
     int ws_groups = 0;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *inv, *wsort; double *tlayc, *tlevc, *cldfc; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *wsort; double *tlayc, *tlevc, *cldfc; } prep[2] = {};
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -279,6 +279,8 @@ int ensure_sweep_attrs()
     if (int rc = sweepc_attr_one<2>()) return rc;
     if (int rc = sweepc_attr_one<3>()) return rc;
     if (int rc = sweepc_attr_one<4>()) return rc;
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fluxw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fluxw_lds_bytes(false)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fluxw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fluxw_lds_bytes(true)));
     G.sweep_attrs = true;
     return 0;
 }
@@ -360,7 +362,6 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
         items.push_back({(void **)&ps.bbot, nblk * 4});
         items.push_back({(void **)&ps.hbot, (nslot / SORT_GROUP) * 4});
         items.push_back({(void **)&ps.perm, align_up(n, COLSORT_WIN) * 4});
-        items.push_back({(void **)&ps.inv, align_up(n, COLSORT_WIN) * 4});
         items.push_back({(void **)&ps.wsort, (align_up(n, COLSORT_WIN) / COLSORT_WIN) * 4});
         if (cloud) {        // (reordered windows: the temperature and cloud-fraction rows of the caller once more, in position order)
             items.push_back({(void **)&ps.tlayc, L * n * 8});
@@ -430,7 +431,6 @@ Workspace ws_for(int k, bool sorted)
     Workspace w = G.W;
     const State::PrepSet &ps = G.prep[k];
     w.perm = sorted ? ps.perm : nullptr;
-    w.inv = sorted ? ps.inv : nullptr;
     w.wsort = sorted ? ps.wsort : nullptr;
     w.tlayc = ps.tlayc; w.tlevc = ps.tlevc; w.cldfc = ps.cldfc;
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
@@ -497,8 +497,7 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
     const dim3 cgrid1((nb + 63) / 64), cblock1(64);
     if (Wk.perm) {
         const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN);
-        LAUNCH("k_colsort", (k_colsort<GCM>), wgrid, dim3(COLSORT_WIN), s, Wk, g, c, nb, col0, nct, g_colsort_min);
-        if constexpr (GCM) LAUNCH("k_rowcopy", k_rowcopy, dim3(wgrid.x, 4), dim3(COLSORT_WIN), s, Wk, g.tlay, g.tlev, g.cldfr, nb, col0, nct);
+        LAUNCH("k_colsort", (k_colsort<GCM>), wgrid, dim3(COLSORT_WIN, COLSORT_TY), s, Wk, g, c, nb, col0, nct, g_colsort_min);
     }
     LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, idrv, istart);
     if (mode == 1 || mode == 2) {
@@ -676,11 +675,12 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     }
     {
         const dim3 fgrid2((nb + 63) / 64, (nlay + 1 + FLUX_LV - 1) / FLUX_LV), fblock(64, FLUX_LV + 1);
-        LAUNCH("k_flux", k_flux, fgrid2, fblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
-        if (Wk.perm) {      // the windows whose columns were taken in another order (k_colsort)
-            const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, std::min(5, (nlay + 1 + FLUXW_LV - 1) / FLUXW_LV)), wblock(COLSORT_WIN, FLUXW_TY);
-            if (idrv == 1) LAUNCH("k_fluxw", (k_fluxw<true>), wgrid, wblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
-            else LAUNCH("k_fluxw", (k_fluxw<false>), wgrid, wblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
+        if (Wk.perm) {      // the columns are taken in k_colsort's order: the flux kernel that turns positions back into columns
+            const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, (nlay + 1 + FLUXW_LV - 1) / FLUXW_LV), wblock(COLSORT_WIN, FLUXW_TY);
+            if (idrv == 1) LAUNCH_LDS("k_flux", (k_fluxw<true>), wgrid, wblock, fluxw_lds_bytes(true), s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
+            else LAUNCH_LDS("k_flux", (k_fluxw<false>), wgrid, wblock, fluxw_lds_bytes(false), s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
+        } else {
+            LAUNCH("k_flux", k_flux, fgrid2, fblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
         }
     }
     hipError_t e = hipGetLastError();

@@ -118,10 +118,9 @@ struct Workspace {
     // The order in which the batch's columns are taken (k_colsort): position (slot) -> column of the batch, or null = as they come.  Every
     // workspace array above is indexed by SLOT, the caller's arrays by COLUMN (pcol).
     int *perm;          // [ncolb rounded up to whole windows]
-    int *inv;           // ... and column -> position (k_flux writes the caller's arrays column by column)
     int *wsort;         // [windows] 1: the window's columns are taken in another order than they lie
     // ... and for such windows the rows the sweeps read of the caller's arrays at EVERY level - layer and interface temperatures, cloud
-    // fraction - once more in position order (k_rowcopy): [nlay | nlay+1 | nlay][ncolb]
+    // fraction - once more in position order (k_colsort): [nlay | nlay+1 | nlay][ncolb]
     double *tlayc, *tlevc, *cldfc;
 };
 #ifndef RRLW_COLSORT_WIN
@@ -210,57 +209,69 @@ __device__ __forceinline__ double fdiv(double a, double b)
 // spread over the window's cache lines instead of consecutive ones), so the order is taken when it removes at least `min_gain` block-levels
 // from the cloud zone - the sum over the window's four 64-column blocks of the block's highest cloudy layer, as the columns lie against
 // sorted - and the window keeps its order otherwise (a homogeneous deck, a tower system that fills whole blocks).
+constexpr int COLSORT_TY = 4;       // threads per column: the walk over the layers and the copy of the rows in four parts
 template <bool GCM>
-__global__ __launch_bounds__(COLSORT_WIN) void k_colsort(Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int min_gain)
+__global__ __launch_bounds__(COLSORT_WIN * COLSORT_TY) void k_colsort(Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int min_gain)
 {
     constexpr int NB = COLSORT_WIN / 64;
-    __shared__ int s_key[COLSORT_WIN];
+    __shared__ int s_key[COLSORT_WIN], s_perm[COLSORT_WIN], s_top[COLSORT_TY][COLSORT_WIN];
     __shared__ int s_nat[NB], s_srt[NB];
-    const int t = threadIdx.x, w0 = blockIdx.x * COLSORT_WIN, col = w0 + t;
+    const int t = threadIdx.x, ty = threadIdx.y, w0 = blockIdx.x * COLSORT_WIN, col = w0 + t;
     const int nlay = W.nlay;
     int top = -1;                                   // a position past the last column: after everything
     if (col < ncol) {
         const double *cf = (GCM ? g.cldfr : c.cldfrac) + (size_t)col0 + col;
+        const int per = (nlay + COLSORT_TY - 1) / COLSORT_TY, l0 = ty * per + 1, l1 = min(nlay, l0 + per - 1);
         top = 0;
 #pragma unroll 8
-        for (int lay = 1; lay <= nlay; lay++) { if (cf[(size_t)nct * (lay - 1)] >= 1.e-6) top = lay; }      // (k_cloudscan's `cloudy`)
+        for (int lay = l0; lay <= l1; lay++) { if (cf[(size_t)nct * (lay - 1)] >= 1.e-6) top = lay; }      // (k_cloudscan's `cloudy`)
     }
-    const int key = (nlay - top) * COLSORT_WIN + t; // deepest first, then column order
-    s_key[t] = key;
-    int mx = max(top, 0);                           // the block's top as the columns lie: a wave = 64 consecutive columns
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-    if ((t & 63) == 0) s_nat[t >> 6] = mx;
+    s_top[ty][t] = top;
     __syncthreads();
     int rank = 0;
+    if (ty == 0) {
+#pragma unroll
+        for (int k = 1; k < COLSORT_TY; k++) top = max(top, s_top[k][t]);
+        s_key[t] = (nlay - top) * COLSORT_WIN + t;  // deepest first, then column order
+        int mx = max(top, 0);                       // the block's top as the columns lie: a wave = 64 consecutive columns
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        if ((t & 63) == 0) s_nat[t >> 6] = mx;
+    }
+    __syncthreads();
+    if (ty == 0) {
+        const int key = s_key[t];
 #pragma unroll 8
-    for (int i = 0; i < COLSORT_WIN; i++) rank += s_key[i] < key ? 1 : 0;
-    if ((rank & 63) == 0) s_srt[rank >> 6] = max(top, 0);      // ... and sorted: the first of every 64 is the deepest
+        for (int i = 0; i < COLSORT_WIN; i++) rank += s_key[i] < key ? 1 : 0;
+        if ((rank & 63) == 0) s_srt[rank >> 6] = max(top, 0);      // ... and sorted: the first of every 64 is the deepest
+    }
     __syncthreads();
     int gain = 0;
 #pragma unroll
     for (int b = 0; b < NB; b++) gain += s_nat[b] - s_srt[b];
     const bool keep = gain * 4 < min_gain * NB;     // (uniform over the workgroup; min_gain is quoted for four blocks)
-    if (keep) rank = t;
-    if (t == 0) W.wsort[blockIdx.x] = keep ? 0 : 1;
-    W.perm[w0 + rank] = col;
-    W.inv[col] = w0 + rank;
-}
-
-// k_rowcopy : for the windows k_colsort reordered, the rows of the caller's arrays that the sweeps read at every level - layer and
-//             interface temperatures, cloud fraction - once more in position order (Workspace::tlayc ..): one thread per (position,
-//             level), reads through `perm`, writes consecutive.  The other windows leave at once.
-__global__ __launch_bounds__(COLSORT_WIN) void k_rowcopy(Workspace W, const double *tlay, const double *tlev, const double *cldfr, int ncol, int col0, int nct)
-{
-    if (W.wsort[blockIdx.x] == 0) return;                   // (uniform; few workgroups per window: one that leaves costs its dispatch)
-    const int slot = blockIdx.x * COLSORT_WIN + threadIdx.x;
-    if (slot >= ncol) return;
-    const size_t g0 = (size_t)col0 + W.perm[slot];
+    if (ty == 0) {
+        if (keep) rank = t;
+        if (t == 0) W.wsort[blockIdx.x] = keep ? 0 : 1;
+        W.perm[w0 + rank] = col;
+        s_perm[rank] = col;
+    }
+    if (keep) return;
+    // A reordered window: the rows of the caller's arrays that the sweeps read at EVERY level - layer and interface temperatures, cloud
+    // fraction - once more in position order (Workspace::tlayc ..), read through the new order, written consecutively.  (Out-of-order
+    // eight-byte reads cost the sweeps 5 ms per 1e6 deep-cloud columns where they recurred per level and band.)
+    if constexpr (GCM) {
+        __syncthreads();
+        const int slot = w0 + t;
+        if (slot < ncol) {
+            const size_t g0 = (size_t)col0 + s_perm[t];
 #pragma unroll 4
-    for (int lev = blockIdx.y; lev <= W.nlay; lev += gridDim.y) {       // level 0 .. nlay; layer lev + 1 for the two layer arrays
-        const size_t gi = g0 + (size_t)nct * lev, o = (size_t)lev * W.ncolb + slot;
-        W.tlevc[o] = tlev[gi];
-        if (lev < W.nlay) { W.tlayc[o] = tlay[gi]; W.cldfc[o] = cldfr ? cldfr[gi] : 0.0; }
+            for (int lev = ty; lev <= nlay; lev += COLSORT_TY) {         // level 0 .. nlay; layer lev + 1 for the two layer arrays
+                const size_t gi = g0 + (size_t)nct * lev, o = (size_t)lev * W.ncolb + slot;
+                W.tlevc[o] = g.tlev[gi];
+                if (lev < nlay) { W.tlayc[o] = g.tlay[gi]; W.cldfc[o] = g.cldfr[gi]; }
+            }
+        }
     }
 }
 
@@ -3793,27 +3804,20 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
 {
     __shared__ double s_net[FLUX_LV + 1][64], s_netc[FLUX_LV + 1][64];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * 64 + tx;                   // a COLUMN of the batch: the caller's arrays are written 64 consecutive columns at a time ...
+    const int col = blockIdx.x * 64 + tx;
     const int nlay = W.nlay;
     const int lev = blockIdx.y * FLUX_LV + ty;              // ty = FLUX_LV: the first level of the next workgroup (sums only)
     const bool on = col < ncol && lev <= nlay;
     const size_t gc = (size_t)col0 + col;
-    // ... and the partials read at the position the column was swept at (k_colsort); a window that kept its order - one scalar flag says so -
-    // takes the position for the column and its block's hand-off level from a scalar register, as without an order
-    const bool moved = W.inv && W.wsort[blockIdx.x / (COLSORT_WIN / 64)] != 0;      // (uniform)
-#ifndef RRLW_FLUX_GATHER
-    if (moved) return;                                      // k_fluxw's window (before any barrier: the whole workgroup leaves)
-#endif
-    const int slot = (on && moved) ? W.inv[col] : col;
     const size_t ncb = W.ncolb;
     double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
     if (on) {
         // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
         // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
-        const int ltop = clear_from_total ? 0 : (moved ? W.hblk[slot >> 6] : W.hblk[blockIdx.x]);     // hand-off level of the position's 64-column block
-        const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // (uniform over the wave unless the window was reordered)
+        const int ltop = clear_from_total ? 0 : W.hblk[blockIdx.x];                          // hand-off level of this 64-column block
+        const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // uniform over the wave
         for (int g = 0; g < ngroups; g++) {
-            const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + slot;
+            const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;
             Part2 su, sd, sq{0.0, 0.0};
             if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
             if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
@@ -3845,30 +3849,30 @@ __global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Worksp
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fluxw : k_flux for the windows whose columns were taken in another order (k_colsort; the others leave at once, as these leave k_flux).
-//           Read at the column's position, eight bytes per lane, the partial slabs cost k_flux a third more (sixteen cache lines per
-//           access instead of four).  Here a workgroup covers a WINDOW and FLUXW_LV levels: thread (t, .) sums the groups at POSITION
-//           w0 + t exactly as k_flux does (coalesced), the values change places in LDS - position -> column - and thread (t, .) writes
-//           COLUMN w0 + t of the caller's arrays (coalesced); the level above the workgroup's is summed once more for the heating rate of
+// k_fluxw : k_flux for batches whose columns are taken in k_colsort's order.  The partials lie by POSITION, the caller's arrays by
+//           COLUMN; gathered at the column's position, eight bytes per lane, the partial slabs cost k_flux a third more (sixteen cache
+//           lines per access instead of four), scattered to the position's column the outputs cost it 60 %.  Here a workgroup covers a
+//           WINDOW and FLUXW_LV levels: thread (t, .) sums the groups at position w0 + t exactly as k_flux does (coalesced), the values
+//           change places in LDS - position -> column; a window that kept its order: the same place - and thread (t, .) writes column
+//           w0 + t of the caller's arrays (coalesced); the level above the workgroup's is summed once more for the heating rate of
 //           its last layer, as in k_flux (rtrn :583-604: the same expressions, operands in the same order).
 // ------------------------------------------------------------------------------------------------
-constexpr int FLUXW_LV = 4, FLUXW_TY = 2;
-static_assert((FLUXW_LV + 1) * 6 * COLSORT_WIN * 8 <= 64 * 1024 && COLSORT_WIN * FLUXW_TY <= 1024, "k_fluxw holds a window x (FLUXW_LV + 1) levels x 6 values in static LDS");
+constexpr int FLUXW_LV = 8, FLUXW_TY = 4;
+static_assert(COLSORT_WIN * FLUXW_TY <= 1024, "k_fluxw: a window x FLUXW_TY threads");
+__host__ __device__ constexpr int fluxw_lds_bytes(bool idrv) { return (FLUXW_LV + 1) * (idrv ? 6 : 4) * COLSORT_WIN * 8; }
 template <bool IDRV>
 __global__ __launch_bounds__(COLSORT_WIN * FLUXW_TY) void k_fluxw(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct, int ngroups)
 {
     constexpr int NV = IDRV ? 6 : 4;
-    __shared__ double s_v[FLUXW_LV + 1][NV][COLSORT_WIN];
-    if (W.wsort[blockIdx.x] == 0) return;                   // (uniform) the window kept its order: k_flux's
+    extern __shared__ __align__(16) unsigned char smem_f[];
+    double (*s_v)[NV][COLSORT_WIN] = reinterpret_cast<double (*)[NV][COLSORT_WIN]>(smem_f);      // [FLUXW_LV + 1]
     const int t = threadIdx.x, ty = threadIdx.y, w0 = blockIdx.x * COLSORT_WIN;
     const int slot = w0 + t, col = w0 + t;                  // the position whose partials this thread sums, the column it writes
     const bool son = slot < ncol, con = col < ncol;
-    const int nlay = W.nlay;
+    const int nlay = W.nlay, lev0 = blockIdx.y * FLUXW_LV;
     const size_t ncb = W.ncolb, gc = (size_t)col0 + col;
-    const int dst = son ? W.perm[slot] - w0 : t;            // where the position's column lies in the window
+    const int dst = son ? pcol(W, slot) - w0 : t;           // where the position's column lies in the window
     const int ltop = son ? W.hblk[slot >> 6] : 0;           // hand-off level of the position's block (uniform over the wave)
-    // (a workgroup takes every gridDim.y-th chunk of levels: few workgroups per window - one that leaves costs its dispatch)
-    for (int lev0 = blockIdx.y * FLUXW_LV; lev0 <= nlay; lev0 += gridDim.y * FLUXW_LV) {
     for (int lc = ty; lc <= FLUXW_LV; lc += FLUXW_TY) {
         const int lev = lev0 + lc;
         if (son && lev <= nlay) {
@@ -3907,8 +3911,6 @@ __global__ __launch_bounds__(COLSORT_WIN * FLUXW_TY) void k_fluxw(DevTables T, W
                 out.hrc[o] = T.heatfac * (netc - abovec) / dp;
             }
         }
-    }
-    __syncthreads();                                        // (the next chunk writes the buffer again)
     }
 }
 
