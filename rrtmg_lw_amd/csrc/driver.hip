@@ -279,8 +279,8 @@ int ensure_sweep_attrs()
     if (int rc = sweepc_attr_one<2>()) return rc;
     if (int rc = sweepc_attr_one<3>()) return rc;
     if (int rc = sweepc_attr_one<4>()) return rc;
-    HIP_TRY(hipFuncSetAttribute((const void *)k_fluxw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fluxw_lds_bytes(false)));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_fluxw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fluxw_lds_bytes(true)));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_flux<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FLUX_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_flux<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FLUX_LDS_BYTES));
     G.sweep_attrs = true;
     return 0;
 }
@@ -674,14 +674,10 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
         }
     }
     {
-        const dim3 fgrid2((nb + 63) / 64, (nlay + 1 + FLUX_LV - 1) / FLUX_LV), fblock(64, FLUX_LV + 1);
-        if (Wk.perm) {      // the columns are taken in k_colsort's order: the flux kernel that turns positions back into columns
-            const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, (nlay + 1 + FLUXW_LV - 1) / FLUXW_LV), wblock(COLSORT_WIN, FLUXW_TY);
-            if (idrv == 1) LAUNCH_LDS("k_flux", (k_fluxw<true>), wgrid, wblock, fluxw_lds_bytes(true), s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
-            else LAUNCH_LDS("k_flux", (k_fluxw<false>), wgrid, wblock, fluxw_lds_bytes(false), s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, fg.n);
-        } else {
-            LAUNCH("k_flux", k_flux, fgrid2, fblock, s, G.D, Wk, out, GCM ? g.plev : c.pz, nb, col0, nct, idrv, mode == 0 ? 1 : 0, fg.n);
-        }
+        const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, (nlay + 1 + FLUX_LV - 1) / FLUX_LV), wblock(COLSORT_WIN, FLUX_TY);
+        const double *pz = GCM ? g.plev : c.pz;
+        if (idrv == 1) LAUNCH_LDS("k_flux", (k_flux<true>), wgrid, wblock, FLUX_LDS_BYTES, s, G.D, Wk, out, pz, nb, col0, nct, mode == 0 ? 1 : 0, fg.n);
+        else LAUNCH_LDS("k_flux", (k_flux<false>), wgrid, wblock, FLUX_LDS_BYTES, s, G.D, Wk, out, pz, nb, col0, nct, mode == 0 ? 1 : 0, fg.n);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));

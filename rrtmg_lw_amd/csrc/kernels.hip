@@ -3791,124 +3791,93 @@ __global__ __launch_bounds__(64 * N1_WAVES) void k_n1(DevTables T, Workspace W, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_flux  : sum of the group partials (rtrn :549-574), flux scaling (rtrn :580-594), net flux and heating rate
-//           (rtrn :583-604), one thread per (column, level); a workgroup covers 8 levels of 64 columns and sums
-//           the level above them once more, so that no second pass over the flux arrays is needed.
-//           clear_from_total: a cloud-free call, the clear-sky stream equals the total-sky stream.  Only bands in
-//           [istart, iend] were swept: the groups hold exactly those.
+// k_flux  : sum of the group partials (rtrn :549-574), flux scaling (rtrn :580-594), net flux and heating rate (rtrn :583-604; output
+//           copies src/rrtmg_lw_rad.nomcica.f90:563-583).  A workgroup covers a WINDOW of 256 columns and FLUX_LV levels and sums the
+//           level above them once more, so that no second pass over the flux arrays is needed for the heating rate of its last layer.
+//           The partials lie by POSITION, the caller's arrays by COLUMN (k_colsort): thread (t, .) sums the groups at position w0 + t
+//           (coalesced), the values change places in LDS - position -> column; the same place where the columns are taken as they
+//           lie - and thread (t, .) writes column w0 + t of the caller's arrays (coalesced).  (Gathered at the column's position,
+//           eight bytes per lane, the slabs cost a third more - sixteen cache lines per access instead of four -, scattered to the
+//           position's column the outputs 60 %; and the 256-column rows make this kernel 7 % faster than its 64-column predecessor
+//           where no column moves at all.)
+//           clear_from_total: a cloud-free call, the clear-sky stream equals the total-sky stream.  Only bands in [istart, iend] were
+//           swept: the groups hold exactly those.
 // ------------------------------------------------------------------------------------------------
-constexpr int FLUX_LV = 8;          // levels of a k_flux workgroup (+ 1: the level above, summed again for the heating rate of the last layer)
-
-__global__ __launch_bounds__(64 * (FLUX_LV + 1)) void k_flux(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct,
-                                                             int idrv, int clear_from_total, int ngroups)
-{
-    __shared__ double s_net[FLUX_LV + 1][64], s_netc[FLUX_LV + 1][64];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int col = blockIdx.x * 64 + tx;
-    const int nlay = W.nlay;
-    const int lev = blockIdx.y * FLUX_LV + ty;              // ty = FLUX_LV: the first level of the next workgroup (sums only)
-    const bool on = col < ncol && lev <= nlay;
-    const size_t gc = (size_t)col0 + col;
-    const size_t ncb = W.ncolb;
-    double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
-    if (on) {
-        // Partials arrive summed per group of bands.  Downward at and above the batch's highest cloud, and everywhere in a cloud-free
-        // call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two (k_sweepz / k_sweepc).
-        const int ltop = clear_from_total ? 0 : W.hblk[blockIdx.x];                          // hand-off level of this 64-column block
-        const bool dn1 = clear_from_total || lev >= ltop, up1 = clear_from_total != 0;       // uniform over the wave
-        for (int g = 0; g < ngroups; g++) {
-            const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + col;
-            Part2 su, sd, sq{0.0, 0.0};
-            if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
-            if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
-            if (idrv == 1) sq = W.gdp[go];
-            u = u + su.a; uc = uc + su.b;
-            d = d + sd.a; dc = dc + sd.b;
-            du = du + sq.a; duc = duc + sq.b;
-        }
-        u = u * T.fluxfac; d = d * T.fluxfac;
-        if (clear_from_total) { uc = u; dc = d; duc = du; }
-        else { uc = uc * T.fluxfac; dc = dc * T.fluxfac; }
-        if (ty < FLUX_LV) {
-            const size_t o = gc + (size_t)nct * lev;
-            out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = uc; out.dflxc[o] = dc;
-            if (idrv == 1) { out.duflx_dt[o] = du; out.duflxc_dt[o] = duc; }
-            if (out.fnet) { out.fnet[o] = u - d; out.fnetc[o] = uc - dc; }
-        }
-    }
-    // net flux and heating rate of the layer above each level (rtrn :583-604; output copies src/rrtmg_lw_rad.nomcica.f90:563-583)
-    s_net[ty][tx] = u - d;
-    s_netc[ty][tx] = uc - dc;
-    __syncthreads();
-    if (on && ty < FLUX_LV && lev < nlay) {
-        const size_t lo = gc + (size_t)nct * lev, hi = lo + (size_t)nct;
-        const double dp = pz[lo] - pz[hi];
-        out.hr[lo] = T.heatfac * (s_net[ty][tx] - s_net[ty + 1][tx]) / dp;
-        out.hrc[lo] = T.heatfac * (s_netc[ty][tx] - s_netc[ty + 1][tx]) / dp;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_fluxw : k_flux for batches whose columns are taken in k_colsort's order.  The partials lie by POSITION, the caller's arrays by
-//           COLUMN; gathered at the column's position, eight bytes per lane, the partial slabs cost k_flux a third more (sixteen cache
-//           lines per access instead of four), scattered to the position's column the outputs cost it 60 %.  Here a workgroup covers a
-//           WINDOW and FLUXW_LV levels: thread (t, .) sums the groups at position w0 + t exactly as k_flux does (coalesced), the values
-//           change places in LDS - position -> column; a window that kept its order: the same place - and thread (t, .) writes column
-//           w0 + t of the caller's arrays (coalesced); the level above the workgroup's is summed once more for the heating rate of
-//           its last layer, as in k_flux (rtrn :583-604: the same expressions, operands in the same order).
-// ------------------------------------------------------------------------------------------------
-constexpr int FLUXW_LV = 8, FLUXW_TY = 4;
-static_assert(COLSORT_WIN * FLUXW_TY <= 1024, "k_fluxw: a window x FLUXW_TY threads");
-__host__ __device__ constexpr int fluxw_lds_bytes(bool idrv) { return (FLUXW_LV + 1) * (idrv ? 6 : 4) * COLSORT_WIN * 8; }
+constexpr int FLUX_LV = 8, FLUX_TY = 4;         // levels of a workgroup (+ 1: the level above, summed again), threads per column
+static_assert(COLSORT_WIN * FLUX_TY <= 1024, "k_flux: a window x FLUX_TY threads");
+constexpr int FLUX_LDS_BYTES = (FLUX_LV + 1) * 4 * COLSORT_WIN * 8;       // 72 KB: two workgroups per CU
 template <bool IDRV>
-__global__ __launch_bounds__(COLSORT_WIN * FLUXW_TY) void k_fluxw(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct, int ngroups)
+__global__ __launch_bounds__(COLSORT_WIN * FLUX_TY) void k_flux(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct,
+                                                                int clear_from_total, int ngroups)
 {
-    constexpr int NV = IDRV ? 6 : 4;
+    constexpr int NV = 4, NL = (FLUX_LV + FLUX_TY) / FLUX_TY;      // values that change places at a time; levels per thread
     extern __shared__ __align__(16) unsigned char smem_f[];
-    double (*s_v)[NV][COLSORT_WIN] = reinterpret_cast<double (*)[NV][COLSORT_WIN]>(smem_f);      // [FLUXW_LV + 1]
+    double (*s_v)[NV][COLSORT_WIN] = reinterpret_cast<double (*)[NV][COLSORT_WIN]>(smem_f);      // [FLUX_LV + 1]
+    double kdu[IDRV ? NL : 1], kduc[IDRV ? NL : 1];         // d(flux)/dT of this thread's levels: they change places after the fluxes, in the same buffer
     const int t = threadIdx.x, ty = threadIdx.y, w0 = blockIdx.x * COLSORT_WIN;
     const int slot = w0 + t, col = w0 + t;                  // the position whose partials this thread sums, the column it writes
     const bool son = slot < ncol, con = col < ncol;
-    const int nlay = W.nlay, lev0 = blockIdx.y * FLUXW_LV;
+    const int nlay = W.nlay, lev0 = blockIdx.y * FLUX_LV;
     const size_t ncb = W.ncolb, gc = (size_t)col0 + col;
     const int dst = son ? pcol(W, slot) - w0 : t;           // where the position's column lies in the window
-    const int ltop = son ? W.hblk[slot >> 6] : 0;           // hand-off level of the position's block (uniform over the wave)
-    for (int lc = ty; lc <= FLUXW_LV; lc += FLUXW_TY) {
-        const int lev = lev0 + lc;
-        if (son && lev <= nlay) {
-            const bool dn1 = lev >= ltop;
+    // Partials arrive summed per group of bands.  Downward at and above the hand-off level of the position's 64-column block, and everywhere
+    // in a cloud-free call, the clear-sky stream equals the total one and one value was written (k_sweepc); below, and upward, two.
+    const int ltop = (son && !clear_from_total) ? W.hblk[slot >> 6] : 0;       // (uniform over the wave)
+    const bool up1 = clear_from_total != 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {          // (unrolled: kdu / kduc stay in registers)
+        const int lc = ty + k * FLUX_TY, lev = lev0 + lc;
+        if constexpr (IDRV) { kdu[k] = 0.0; kduc[k] = 0.0; }
+        if (lc <= FLUX_LV && son && lev <= nlay) {
+            const bool dn1 = clear_from_total || lev >= ltop;
             double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
             for (int g = 0; g < ngroups; g++) {
                 const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + slot;
                 Part2 su, sd, sq{0.0, 0.0};
                 if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
-                su = W.gup[go];
+                if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
                 if constexpr (IDRV) sq = W.gdp[go];
                 u = u + su.a; uc = uc + su.b;
                 d = d + sd.a; dc = dc + sd.b;
                 du = du + sq.a; duc = duc + sq.b;
             }
             u = u * T.fluxfac; d = d * T.fluxfac;
-            uc = uc * T.fluxfac; dc = dc * T.fluxfac;
+            if (clear_from_total) { uc = u; dc = d; duc = du; }
+            else { uc = uc * T.fluxfac; dc = dc * T.fluxfac; }
             s_v[lc][0][dst] = u; s_v[lc][1][dst] = d; s_v[lc][2][dst] = uc; s_v[lc][3][dst] = dc;
-            if constexpr (IDRV) { s_v[lc][4][dst] = du; s_v[lc][5][dst] = duc; }
+            if constexpr (IDRV) { kdu[k] = du; kduc[k] = duc; }
         }
     }
     __syncthreads();
-    for (int lc = ty; lc < FLUXW_LV; lc += FLUXW_TY) {
+    for (int lc = ty; lc < FLUX_LV; lc += FLUX_TY) {
         const int lev = lev0 + lc;
         if (con && lev <= nlay) {
             const double u = s_v[lc][0][t], d = s_v[lc][1][t], uc = s_v[lc][2][t], dc = s_v[lc][3][t];
             const size_t o = gc + (size_t)nct * lev;
             out.uflx[o] = u; out.dflx[o] = d; out.uflxc[o] = uc; out.dflxc[o] = dc;
-            if constexpr (IDRV) { out.duflx_dt[o] = s_v[lc][4][t]; out.duflxc_dt[o] = s_v[lc][5][t]; }
             if (out.fnet) { out.fnet[o] = u - d; out.fnetc[o] = uc - dc; }
-            if (lev < nlay) {
+            if (lev < nlay) {       // net flux and heating rate of the layer above the level
                 const double net = u - d, netc = uc - dc;
                 const double above = s_v[lc + 1][0][t] - s_v[lc + 1][1][t], abovec = s_v[lc + 1][2][t] - s_v[lc + 1][3][t];
                 const double dp = pz[o] - pz[o + (size_t)nct];
                 out.hr[o] = T.heatfac * (net - above) / dp;
                 out.hrc[o] = T.heatfac * (netc - abovec) / dp;
+            }
+        }
+    }
+    if constexpr (IDRV) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int lc = ty + k * FLUX_TY, lev = lev0 + lc;
+            if (lc < FLUX_LV && son && lev <= nlay) { s_v[lc][0][dst] = kdu[k]; s_v[lc][1][dst] = kduc[k]; }
+        }
+        __syncthreads();
+        for (int lc = ty; lc < FLUX_LV; lc += FLUX_TY) {
+            const int lev = lev0 + lc;
+            if (con && lev <= nlay) {
+                const size_t o = gc + (size_t)nct * lev;
+                out.duflx_dt[o] = s_v[lc][0][t]; out.duflxc_dt[o] = s_v[lc][1][t];
             }
         }
     }
