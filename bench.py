@@ -43,6 +43,15 @@ def algo_bytes_per_col(nlay, idrv):
     return 8.0 * (n_in + n_out)
 
 
+def kernels_sha16():
+    """first 16 hex digits of the sha256 of the kernel sources: what the committed PMC files (profiles/pmc_traffic.json) are tied to"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "driver.hip"):
+        h.update(open(os.path.join(ROOT, "rrtmg_lw_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,7 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncol", type=int, default=1_000_000, help="total columns over all GPUs")
     ap.add_argument("--nlay", type=int, default=72)
-    ap.add_argument("--config", default="cloudy", choices=["clear", "cloudy", "aer_idrv", "cloudy_deep", "cloudy_towers", "cloudy_scatter"])
+    ap.add_argument("--config", default="cloudy", choices=["clear", "cloudy", "aer_idrv", "cloudy_deep", "cloudy_towers", "cloudy_scatter", "cloudy_orography"])
     ap.add_argument("--mcica", type=int, default=0, metavar="ICLD",
                     help="McICA flavour (BASELINE configs[3]): sub-column generator with overlap ICLD (5 = exponential-random) "
                          "+ cldprmc + rtrnmc through the fused device entry; 0 = non-McICA rtrn/rtrnmr")
@@ -239,6 +248,7 @@ def main():
             hout = api._out_arrays(nh, nlay, hidrv)                      # persistent arrays in both legs (a host model's live for the whole run)
             th = timed(out=hout)
             r = dict(value=round(nh / th, 1), unit="columns/s", columns=nh, ms=round(1e3 * th, 2), host_GBps=round(hbytes / th / 1e9, 2))
+            pinned = []
             try:
                 pinned = [v for v in list(dh.values()) + list(hout.values()) if isinstance(v, np.ndarray) and v.flags.f_contiguous and v.dtype == np.float64]
                 for v in pinned:
@@ -246,19 +256,31 @@ def main():
                 tp = timed(out=hout)
                 r["pinned"] = dict(value=round(nh / tp, 1), ms=round(1e3 * tp, 2), host_GBps=round(hbytes / tp / 1e9, 2))
                 # ... and with the arrays a host model sets once declared static (rrtmg_lw_hip_host_static: well-mixed gases, halocarbons,
-                # aerosol optical depths, emissivities): their rows are scanned by the first call only
+                # aerosol optical depths, emissivities): their rows are scanned by the first call only.  (A leg of its own: whatever
+                # happens in it, the pinned figure stands and the declarations are withdrawn.)
                 static = [dh[k] for k in ("co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr", "cfc22vmr", "ccl4vmr", "tauaer", "emis")]
-                for v in static:
-                    api.host_static(v)
-                ts = timed(out=hout)
-                for v in static:
-                    api.host_changed(v, keep=False)
-                r["pinned_static"] = dict(value=round(nh / ts, 1), ms=round(1e3 * ts, 2), host_GBps=round(hbytes / ts / 1e9, 2),
-                                          static="co2, ch4, n2o, o2, cfc11, cfc12, cfc22, ccl4 mixing ratios, tauaer, emis")
-                for v in pinned:
-                    api.host_unregister(v)
+                try:
+                    for v in static:
+                        api.host_static(v)
+                    ts = timed(out=hout)
+                    r["pinned_static"] = dict(value=round(nh / ts, 1), ms=round(1e3 * ts, 2), host_GBps=round(hbytes / ts / 1e9, 2),
+                                              static="co2, ch4, n2o, o2, cfc11, cfc12, cfc22, ccl4 mixing ratios, tauaer, emis")
+                except Exception as ex:
+                    r["pinned_static"] = dict(error=str(ex)[:120])
+                finally:
+                    for v in static:
+                        try:
+                            api.host_changed(v, keep=False)
+                        except Exception:
+                            pass
             except Exception as ex:          # registration is optional
                 r["pinned"] = dict(error=str(ex)[:120])
+            finally:
+                for v in pinned:
+                    try:
+                        api.host_unregister(v)
+                    except Exception:
+                        pass
             return r
 
         e2e = host_rate(args.config)
@@ -315,11 +337,17 @@ def main():
             # configuration): the PATH's bytes per column x this rank's columns per step, and the dominant kernel's per launch
             key = f"{args.config}_L{nlay}" + (f"_mcica{args.mcica}" if args.mcica else "")
             path_traffic = None
+            traffic_stale = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
                     ent = json.load(open(pmc)).get(key)
                     if ent:
+                        # the PMC pass is a committed file, not part of this run: say so when the kernels have changed since it was taken
+                        if ent.get("kernels_sha16") != kernels_sha16():
+                            traffic_stale = (f"profiles/pmc_traffic.json[{key}] was collected for kernels {ent.get('kernels_sha16', 'of an unrecorded version')}, "
+                                             f"this tree has {kernels_sha16()}: re-run tools/pmc_collect.sh")
+                            print("# WARNING: " + traffic_stale, file=sys.stderr)
                         path_traffic = ent["bytes_per_column"] * ncol
                         kb = ent["kernels"].get(dom) or ent["kernels"].get(dom.replace(">", ",false>"))
                         if kb:
@@ -332,7 +360,7 @@ def main():
                         achieved=round(pach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(pach / HBM_PEAK_GBS, 5),
                         algorithmic_bytes_per_column=bpc, kernels_ms_per_step=round(ktot / args.steps, 3), path_ms_per_step=round(tpath / args.steps, 3),
                         traffic=path_traffic, traffic_scope="HBM bytes of ALL kernels of one step on this rank (PMC, per-column figure of the same configuration x columns)" if path_traffic else None,
-                        traffic_over_algorithmic=round(path_traffic / (bpc * ncol), 3) if path_traffic else None, dominant=dom_d)
+                        traffic_over_algorithmic=round(path_traffic / (bpc * ncol), 3) if path_traffic else None, traffic_stale=traffic_stale, dominant=dom_d)
             path = dict(kernels_ms_per_step=round(ktot / args.steps, 3),
                         note="HIP-event time per kernel; the sweeps of the four band groups and the per-column kernels run on their own streams, so the sum exceeds the step",
                         kernels={k: round(v[1] / args.steps, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])},

@@ -232,7 +232,12 @@ int rrtmg_lw_hip_queue_flush(void);
 /* columns queued since the last flush */
 int rrtmg_lw_hip_queue_columns(void);
 
-/* Columns processed per internal batch (bounds the device workspace); default 262144 (0.06-0.16 MB of device workspace per column at 72 layers, by call shape: see rrtmg_lw_hip_workspace_bytes). */
+/* What the library was built with: 0 for the shipped library, 8 for the 256-g-point one.  Bit 0: tuning build (-DRRLW_TUNE: only the
+ * benchmark's kernels), bit 1: knock-out switch (WRONG results, timing only), bit 2: numerics variant (other code width / decode /
+ * division than the product's), bit 3: -DRRLW_G256, bit 4: kernel-geometry switches (same results, other speed).
+ * rrtmg_lw_hip_init[_devices] refuses a library with bit 1 or 2 unless RRTMG_LW_ALLOW_TUNE_BUILD=1 is set. */
+unsigned rrtmg_lw_hip_build_flags(void);
+/* Columns processed per internal batch (bounds the device workspace); 0 = back to the default; default 262144 (0.06-0.16 MB of device workspace per column at 72 layers, by call shape: see rrtmg_lw_hip_workspace_bytes). */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
 /* on = 1: device-pointer entries run the sweeps / k_flux of column batch i on a second stream while k_layer of batch i+1 runs on the
  * caller's stream (second scratch set, +0.1 MB of workspace per column).  Default 0: a sweep workgroup owns a CU (transmittance table in
@@ -249,14 +254,25 @@ int rrtmg_lw_hip_cu_partition(void);
  * above the clouds).  Batches of up to `ncol` columns (default 4096; RRTMG_LW_ONE_SWEEP_MAX) take ONE sweep launch per band group instead:
  * the cloud-zone kernel walks all levels.  0 = never.  Results do not depend on it (bit for bit).  Returns the previous value. */
 int rrtmg_lw_hip_set_one_sweep_max(int ncol);
+/* k_layer stages, per workgroup of 256 columns of one layer, the reference-pressure planes of the absorption tables those columns
+ * need.  Where the columns of a model level lie within one plane of each other (a grid that is nearly the same in every column) three
+ * planes do; on a terrain-following grid (surface pressures of 550 .. 1040 hPa side by side: up to three planes apart,
+ * reference src/rrtmg_lw_setcoef.f90:276-284) such workgroups are taken by a second launch that stages five planes and ten minor-gas
+ * temperature slices (GCM entries; default on, RRTMG_LW_WIDE_WINDOW=0 to switch off: every workgroup then keeps the narrow window and
+ * the cells outside it read the tables through the vector L1 - 1.6x the kernel's time on such a grid).  Results do not depend on it
+ * (bit for bit).  Returns the previous value. */
+int rrtmg_lw_hip_set_wide_window(int on);
 /* The sweeps decide per wavefront - 64 consecutive columns of a batch - where the clouds end; one deep tower among 64 shallow columns sends
- * all of them through the cloud-zone sweep up to its top.  By default (RRTMG_LW_COLSORT=0 to switch off) the columns of a cloudy non-McICA
- * batch are therefore TAKEN in another order than they lie: within each window of 256 consecutive columns by their highest cloudy layer,
+ * all of them through the cloud-zone sweep up to its top.  By default (RRTMG_LW_COLSORT=0 to switch off) the columns of a cloudy batch
+ * - rtrn, rtrnmr and the McICA entries, where the key is the grid-mean cloud fraction the sub-columns are drawn from - are therefore
+ * TAKEN in another order than they lie: within each window of 256 consecutive columns by their highest cloudy layer,
  * deepest first (k_colsort); the caller's arrays stay as they are and are read / written through that order.  A window is reordered only
  * where that takes at least `min_gain` block-levels out of the cloud zone (sum over its four 64-column blocks of the highest cloudy layer,
  * as the columns lie against sorted; default 24, RRTMG_LW_COLSORT_MIN; < 0 keeps the value): reading the caller's arrays out of order has a
  * price.  on = 1 / off = 0; results do not depend on it (bit for bit).  Returns the previous `on`. */
 int rrtmg_lw_hip_set_column_sort(int on, int min_gain);
+/* the threshold in force (min_gain above; values beyond 2^24 are taken as 2^24 = never) */
+int rrtmg_lw_hip_column_sort_min(void);
 /* Bytes of device memory the library holds right now, over all its devices: per-batch workspace (it holds what the call shapes seen so far need and only
  * grows: per column of the batch at 72 layers 62 KB for cloud-free calls, 148 KB for rtrnmr, 152 KB for rtrn, 166 KB with idrv = 1; 310 KB at
  * 137 layers with idrv = 1: rrtmg_lw_hip_set_batch trades it against launch count), host-entry staging, McICA masks, the slab buffer

@@ -177,10 +177,21 @@ def set_one_sweep_max(ncol):
     return int(lib().rrtmg_lw_hip_set_one_sweep_max(C.c_int(int(ncol))))
 
 
+def set_wide_window(on):
+    """k_layer's second pass with the wide staging window for workgroups whose columns lie more than one reference-pressure plane apart
+    (rrtmg_lw_hip_set_wide_window); returns the previous on / off"""
+    return int(lib().rrtmg_lw_hip_set_wide_window(C.c_int(1 if on else 0)))
+
+
 def set_column_sort(on, min_gain=-1):
-    """columns of a cloudy non-McICA batch are taken by cloud top within windows of 256 where that removes >= min_gain block-levels from the
+    """columns of a cloudy batch (rtrn, rtrnmr, McICA) are taken by cloud top within windows of 256 where that removes >= min_gain block-levels from the
     cloud zone (rrtmg_lw_hip_set_column_sort; min_gain < 0 keeps the threshold); returns the previous on / off"""
     return int(lib().rrtmg_lw_hip_set_column_sort(C.c_int(1 if on else 0), C.c_int(int(min_gain))))
+
+
+def column_sort_min():
+    """the threshold of set_column_sort in force"""
+    return int(lib().rrtmg_lw_hip_column_sort_min())
 
 
 def cu_partition():

@@ -38,6 +38,7 @@ constexpr int HOST_SETS = 4;
 
 struct KissTable { unsigned long long stride = 0; long long seed = -1; KissJump host[KJ_NGROUP + 1]; KissJump *dev = nullptr; };
 
+constexpr int DEFAULT_BATCH = 262144;        // rrtmg_lw_hip_set_batch(0) restores it
 struct State {
     bool init = false;
     int device = -1;
@@ -53,7 +54,8 @@ struct State {
     int ws_groups = 0;
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
-    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *wsort; double *tlayc, *tlevc, *cldfc; } prep[2] = {};
+    struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *wsort; double *tlayc, *tlevc, *cldfc; int *wide; } prep[2] = {};
+    int wide_par[2] = {0, 0};    // k_layer's wide-window list: the count (0 / 1) the next launch pair on prep set k uses
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -75,7 +77,7 @@ struct State {
     size_t mask_bytes = 0;
     double *d_rnd = nullptr;   // one slab of Mersenne-Twister deviates (irng = 1)
     size_t rnd_bytes = 0;
-    int batch = 262144;     // columns per internal batch: 0.06-0.16 MB of workspace per column at 72 layers by call shape (38 GB of the 288 for the benchmark's); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
+    int batch = DEFAULT_BATCH;     // columns per internal batch: 0.06-0.16 MB of workspace per column at 72 layers by call shape (38 GB of the 288 for the benchmark's); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
     bool split_sweep = false;    // run the sweeps / k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: a sweep
                                  // workgroup owns a CU (transmittance table in LDS), so the two do not share a CU (measured: 1-2 % gain for twice the code scratch)
     bool sweep_attrs = false;    // the sweeps' dynamic-LDS limit has been raised on this device
@@ -139,6 +141,10 @@ struct DeviceGuard {
 // The text of an error belongs to the THREAD whose call failed (concurrent callers: another thread's failure a moment later must not
 // replace it before the caller has read it); the state keeps a copy for threads that have had no error of their own.
 thread_local std::string tl_err;
+// the library's latest error text whatever the thread, for a thread that has none of its own (rrtmg_lw_hip_last_error): under its own
+// small lock, never the entry lock - a caller polling for errors must not wait out another thread's solve
+std::mutex g_lasterr_mu;
+std::string g_lasterr;
 
 int fail(int code, const char *fmt, ...)
 {
@@ -149,6 +155,7 @@ int fail(int code, const char *fmt, ...)
     va_end(ap);
     G.err = buf;
     tl_err = buf;
+    { std::lock_guard<std::mutex> lk(g_lasterr_mu); g_lasterr = buf; }
     return code;
 }
 
@@ -363,6 +370,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
         items.push_back({(void **)&ps.hbot, (nslot / SORT_GROUP) * 4});
         items.push_back({(void **)&ps.perm, align_up(n, COLSORT_WIN) * 4});
         items.push_back({(void **)&ps.wsort, (align_up(n, COLSORT_WIN) / COLSORT_WIN) * 4});
+        items.push_back({(void **)&ps.wide, (2 + ((n + LAYER_BLOCK - 1) / LAYER_BLOCK) * L) * 4});
         if (cloud) {        // (reordered windows: the temperature and cloud-fraction rows of the caller once more, in position order)
             items.push_back({(void **)&ps.tlayc, L * n * 8});
             items.push_back({(void **)&ps.tlevc, (L + 1) * n * 8});
@@ -386,6 +394,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
     HIP_TRY(hipMalloc(&G.ws_base, total));
     size_t off = 0;
     for (auto &it : items) { *it.p = (char *)G.ws_base + off; off += align_up(it.bytes, 256); }
+    for (auto &ps : G.prep) HIP_TRY(hipMemset(ps.wide, 0, 8));         // the two counts of k_layer's wide-window list (kernels.hip: k_layer)
     W.ncolb = ncolb;
     W.nlay = nlay;
     W.err = G.d_err;
@@ -423,7 +432,8 @@ int ensure_mask(int nlay, size_t ncol)
 bool g_colsort = []() { const char *e = getenv("RRTMG_LW_COLSORT"); return !e || atoi(e) != 0; }();
 bool use_colsort(bool gcm, int mode, int nb);
 // block-levels a window's reordering must take out of the cloud zone (k_colsort; measured break-even on an MI355X, profiles/round4_column_order.md)
-int g_colsort_min = []() { const char *e = getenv("RRTMG_LW_COLSORT_MIN"); return e ? atoi(e) : 24; }();
+constexpr int COLSORT_NEVER = 1 << 24;     // no window gains this many block-levels (4 blocks x 603 layers at most): "never reorder"
+int g_colsort_min = []() { const char *e = getenv("RRTMG_LW_COLSORT_MIN"); return e ? std::max(0, std::min(atoi(e), COLSORT_NEVER)) : 24; }();
 
 // the workspace view of prep set k (see State::prep); sorted: the batch's columns go through k_colsort's order
 Workspace ws_for(int k, bool sorted)
@@ -433,6 +443,7 @@ Workspace ws_for(int k, bool sorted)
     w.perm = sorted ? ps.perm : nullptr;
     w.wsort = sorted ? ps.wsort : nullptr;
     w.tlayc = ps.tlayc; w.tlevc = ps.tlevc; w.cldfc = ps.cldfc;
+    w.wide = ps.wide;
     w.percol = ps.percol; w.laytrop = ps.laytrop; w.ncbands = ps.ncbands; w.cflag = ps.cflag;
     w.odcld = ps.odcld; w.efcl = ps.efcl; w.ovl = ps.ovl;
     w.btop = ps.btop; w.order = ps.order; w.hgrp = ps.hgrp; w.hblk = ps.hblk; w.bbot = ps.bbot; w.hbot = ps.hbot;
@@ -482,6 +493,9 @@ void drop_sweep_set(int k)
 // clouds k_sweepc costs a third of k_sweepz's clear-sky body per level.
 int g_one_sweep_max = []() { const char *e = getenv("RRTMG_LW_ONE_SWEEP_MAX"); return e ? atoi(e) : 4096; }();       // rrtmg_lw_hip_set_one_sweep_max
 bool one_sweep(int nb, int mode) { return mode != 0 && nb <= g_one_sweep_max; }
+// k_layer's second pass with the wide staging window (terrain-following pressure grids; kernels.hip: StageWin).  rrtmg_lw_hip_set_wide_window /
+// RRTMG_LW_WIDE_WINDOW=0 switch it off (measurement: every workgroup then keeps the narrow window, as before round 5); same results either way.
+bool g_wide_window = []() { const char *e = getenv("RRTMG_LW_WIDE_WINDOW"); return !e || atoi(e) != 0; }();
 // (a batch that takes one sweep launch walks every level in the cloud-zone kernel whatever its blocks hold: nothing to gain from an order)
 // (McICA, mode 3: with the generator's mask - the grid-mean cloud fraction gives the key; the sub-column ARRAYS of the reference's McICA
 // argument list come without one and keep their order: the call sites pass `!mc`)
@@ -530,19 +544,36 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     la.tauaer = GCM ? g.tauaer : c.taua;
     const unsigned gx = (nb + LAYER_BLOCK - 1) / LAYER_BLOCK;
     const dim3 lgrid(gx, nlay), lblock(LAYER_BLOCK);
+    // the wide-window pass over the (window, layer) pairs the narrow launch could not take (GCM entry; kernels.hip: StageWin): as many
+    // workgroups as fit the chip at once, which leave at once when the list is empty
+    Workspace Wn = Wk;
+    if (!GCM || !HAVE_WIDE || !g_wide_window) Wn.wide = nullptr;
+    const dim3 wgrid(gx * nlay);
+    // (the pair's count alternates per workspace set; the narrow launch clears the one the set's next pair will use)
+    la.wpar = 0;
+    if (Wn.wide) { int &par = G.wide_par[Wn.wide == G.prep[1].wide ? 1 : 0]; la.wpar = par; par ^= 1; }
 #ifdef RRLW_TUNE
     // tuning builds (tools/build_variant.sh name -DRRLW_TUNE ...): only the kernels of the benchmark's default workload - GCM entry,
     // rtrn / rtrnmr, idrv = 0 - are instantiated (a quarter of the compile time); every other call shape is refused
 #define LAYER_GROUP(GR)                                                                                              \
-    if constexpr (GCM) { if (mode == 1 || mode == 2) LAUNCH("k_layer<cloud," #GR ">", (k_layer<true, 1, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); \
+    if constexpr (GCM) { if (mode == 1 || mode == 2) { LAUNCH("k_layer<cloud," #GR ">", (k_layer<true, 1, GR>), lgrid, lblock, s, G.D, Wn, g, c, la); \
+                                                       if (Wn.wide) LAUNCH("k_layer<cloud,1>", (k_layer<true, 1, 1>), wgrid, lblock, s, G.D, Wn, g, c, la); } \
                          else return fail(RRTMG_LW_HIP_EARG, "tuning build: cloudy non-McICA calls only"); }          \
     else return fail(RRTMG_LW_HIP_EARG, "tuning build: GCM entry only");
 #else
 #define LAYER_GROUP(GR)                                                                                              \
-    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, lblock, s, G.D, Wk, g, c, la);         \
-    else if (mode == 3) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<GCM, 2, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); \
-                          else if constexpr (GCM) LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, lblock, s, G.D, Wk, g, c, la); } \
-    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, lblock, s, G.D, Wk, g, c, la);
+    if (mode == 0) LAUNCH("k_layer<clear," #GR ">", (k_layer<GCM, 0, GR>), lgrid, lblock, s, G.D, Wn, g, c, la);         \
+    else if (mode == 3) { if (mc) LAUNCH("k_layer<mcica," #GR ">", (k_layer<GCM, 2, GR>), lgrid, lblock, s, G.D, Wn, g, c, la); \
+                          else if constexpr (GCM) LAUNCH("k_layer<mcmask," #GR ">", (k_layer<true, 3, GR>), lgrid, lblock, s, G.D, Wn, g, c, la); } \
+    else LAUNCH("k_layer<cloud," #GR ">", (k_layer<GCM, 1, GR>), lgrid, lblock, s, G.D, Wn, g, c, la);             \
+    if constexpr (GCM) {                                                                                             \
+        if (Wn.wide) {                                                                                               \
+            if (mode == 0) LAUNCH("k_layer<clear,1>", (k_layer<true, 0, 1>), wgrid, lblock, s, G.D, Wn, g, c, la);        \
+            else if (mode == 3) { if (mc) LAUNCH("k_layer<mcica,1>", (k_layer<true, 2, 1>), wgrid, lblock, s, G.D, Wn, g, c, la); \
+                                  else LAUNCH("k_layer<mcmask,1>", (k_layer<true, 3, 1>), wgrid, lblock, s, G.D, Wn, g, c, la); } \
+            else LAUNCH("k_layer<cloud,1>", (k_layer<true, 1, 1>), wgrid, lblock, s, G.D, Wn, g, c, la);                  \
+        }                                                                                                            \
+    }
 #endif
     LAYER_GROUP(0)
 #undef LAYER_GROUP
@@ -1652,7 +1683,7 @@ extern "C" {
 
 const char *rrtmg_lw_hip_last_error(void)
 {
-    if (tl_err.empty()) { std::lock_guard<std::mutex> lk(g_mu); tl_err = g_states[0].err; }
+    if (tl_err.empty()) { std::lock_guard<std::mutex> lk(g_lasterr_mu); tl_err = g_lasterr; }
     return tl_err.c_str();
 }
 
@@ -1703,6 +1734,10 @@ static int init_state(const char *static_tables_path, const char *kdata_path, do
 
 static void finalize_state();
 
+// What this library was built with (kernels.hip, "Tuning switches"): bit 0 tuning build (the benchmark's kernels only), 1 knock-out (wrong
+// results), 2 numerics variant, 3 the 256-g-point configuration, 4 kernel-geometry switches.  The shipped libraries: 0 and 8.
+unsigned rrtmg_lw_hip_build_flags(void) { return BUILD_FLAGS; }
+
 int rrtmg_lw_hip_init(const char *static_tables_path, const char *kdata_path, double cpdair, int device)
 {
     return rrtmg_lw_hip_init_devices(static_tables_path, kdata_path, cpdair, 1, &device);
@@ -1715,6 +1750,12 @@ int rrtmg_lw_hip_init_devices(const char *static_tables_path, const char *kdata_
 {
     std::lock_guard<std::mutex> lk(g_mu);
     g_cur = &g_states[0];
+    if (BUILD_FLAGS & (RRLW_BF_KNOCKOUT | RRLW_BF_NUMERICS)) {      // a measurement build whose results are not the product's
+        const char *e = getenv("RRTMG_LW_ALLOW_TUNE_BUILD");
+        if (!e || atoi(e) == 0)
+            return fail(RRTMG_LW_HIP_EARG, "this library is a measurement build (build flags 0x%x: knock-out or numerics variant); set RRTMG_LW_ALLOW_TUNE_BUILD=1 to use it",
+                        BUILD_FLAGS);
+    }
     if (ndev < 1 || ndev > MAXDEV || !devices) return fail(RRTMG_LW_HIP_EARG, "ndev must be 1..%d", MAXDEV);
     int rc = 0, done = 0;
     std::string err;
@@ -1803,6 +1844,7 @@ static void finalize_state()
 
 int rrtmg_lw_hip_set_batch(int ncol_batch)
 {
+    if (ncol_batch == 0) ncol_batch = DEFAULT_BATCH;
     if (ncol_batch < 64) return fail(RRTMG_LW_HIP_EARG, "batch must be >= 64 columns");
     if (ncol_batch > 64 * SORT_MAXBLK) return fail(RRTMG_LW_HIP_EARG, "batch must be <= %d columns", 64 * SORT_MAXBLK);      // k_blocksort orders a batch's 64-column blocks in LDS
     for (int d = 0; d < MAXDEV; d++) g_states[d].batch = ncol_batch;
@@ -1841,6 +1883,16 @@ int rrtmg_lw_hip_set_one_sweep_max(int ncol)
     return prev;
 }
 
+// k_layer's second pass with the wide staging window for (window, layer) pairs whose columns lie more than one reference-pressure plane
+// apart (terrain-following grids): on = 1 (default) / off = 0.  Results do not depend on it.  Returns the previous value.
+int rrtmg_lw_hip_set_wide_window(int on)
+{
+    ENTRY_LOCK;
+    const int prev = g_wide_window ? 1 : 0;
+    g_wide_window = on != 0;
+    return prev;
+}
+
 // The columns of a cloudy non-McICA batch are taken in k_colsort's order (by cloud top within windows of 256 columns): on = 1 / off = 0.
 // min_gain >= 0: the block-levels a window's reordering must take out of the cloud zone (k_colsort; < 0 keeps the value).
 // Results do not depend on it.  Returns the previous value.
@@ -1849,8 +1901,15 @@ int rrtmg_lw_hip_set_column_sort(int on, int min_gain)
     ENTRY_LOCK;
     const int prev = g_colsort ? 1 : 0;
     g_colsort = on != 0;
-    if (min_gain >= 0) g_colsort_min = min_gain;
+    if (min_gain >= 0) g_colsort_min = std::min(min_gain, COLSORT_NEVER);      // (k_colsort compares gain x 4 with min_gain x 4 in 32 bits)
     return prev;
+}
+
+// the threshold in force (rrtmg_lw_hip_set_column_sort's min_gain): what a caller that changes it for a while puts back
+int rrtmg_lw_hip_column_sort_min(void)
+{
+    ENTRY_LOCK;
+    return g_colsort_min;
 }
 
 // CU partition of the overlapped pipeline (device-pointer entries): k_layer of batch i + 1 on `layer_cus` CUs (rounded to a multiple of 8:
@@ -2588,7 +2647,11 @@ int comb_call(CallReq &me)
         batch.swap(g_comb_pending);
         g_comb_last = batch.size();
         lk.unlock();
-        comb_serve(batch);
+        {   // (the chunks of other callers go through fail() on this thread: their texts are theirs - CallReq::err - not this thread's)
+            const std::string mine = tl_err;
+            comb_serve(batch);
+            tl_err = mine;
+        }
         lk.lock();
         for (CallReq *r : batch) { r->done = true; if (r != &me) r->cv.notify_one(); }
     }

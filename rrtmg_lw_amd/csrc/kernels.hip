@@ -29,6 +29,48 @@
 #include <hip/hip_runtime.h>
 #include "kissjump.hpp"
 
+// ------------------------------------------------------------------------------------------------
+// Tuning switches.  This translation unit carries one-source measurement switches (-DRRLW_...: geometry of the kernels, numerics variants,
+// two knock-outs that give WRONG results); the shipped libraries are built with none of them (only -DRRLW_G256 for the 256-g-point
+// library).  What a library was built with is recorded in its build-flags word (rrtmg_lw_hip_build_flags): rrtmg_lw_hip_init refuses a
+// library whose results differ from the product's (knock-out or numerics variant) unless RRTMG_LW_ALLOW_TUNE_BUILD=1, and a knock-out
+// does not compile outside a tuning build (-DRRLW_TUNE: the benchmark's kernels only).
+// ------------------------------------------------------------------------------------------------
+#if (defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG)) && !defined(RRLW_TUNE)
+#error "RRLW_KO_* knock-outs give wrong results: tuning builds (-DRRLW_TUNE) only"
+#endif
+#ifdef RRLW_TUNE
+#define RRLW_BF_TUNE 1u
+#else
+#define RRLW_BF_TUNE 0u
+#endif
+#if defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG)
+#define RRLW_BF_KNOCKOUT 2u
+#else
+#define RRLW_BF_KNOCKOUT 0u
+#endif
+#if (defined(RRLW_CODE_BITS) && RRLW_CODE_BITS != 32) || defined(RRLW_DECODE_F64) || defined(RRLW_SWEEP_EXPF) || defined(RRLW_EXACT_DIV) || defined(RRLW_FDIV_TWO_NEWTON)
+#define RRLW_BF_NUMERICS 4u
+#else
+#define RRLW_BF_NUMERICS 0u
+#endif
+#ifdef RRLW_G256
+#define RRLW_BF_G256 8u
+#else
+#define RRLW_BF_G256 0u
+#endif
+// kernel-geometry switches given on the command line (same results, other speed)
+#if defined(RRLW_LAYER_BLOCK) || defined(RRLW_STAGE_DOUBLES) || defined(RRLW_LAYER_WAVES) || defined(RRLW_LOAD_CHUNK) || defined(RRLW_CLOUD_QUADS) || \
+    defined(RRLW_MINOR_WIN) || defined(RRLW_COLSORT_WIN) || defined(RRLW_LAYER_PASS_PER_BAND) || defined(RRLW_LAYER_PASSES_3) || defined(RRLW_LAYER_PASSES_1) || \
+    defined(RRLW_LAYER_SYNCTHREADS) || defined(RRLW_LAYER_STAMPS) || defined(RRLW_NO_NT) || defined(RRLW_SWEEPC_P0) || defined(RRLW_SWEEPC_P2D) || \
+    defined(RRLW_SWEEPC_WAVES_CAP) || defined(RRLW_SWEEPC_QUAD_BARRIER) || defined(RRLW_SWEEPC_CODES) || defined(RRLW_SWEEPC_SPLIT) || defined(RRLW_SWEEPC_SPLIT3) || \
+    defined(RRLW_SWEEPC_SPLIT_P1) || defined(RRLW_SWEEPZ_CT_SLOTS) || defined(RRLW_SWEEPZ_G2) || defined(RRLW_SWEEPZ_WAVES_G2) || defined(RRLW_SWEEPZ_WAVES_G1) || \
+    defined(RRLW_SWEEPZ_WAVES_IDRV) || defined(RRLW_GEN_BESIDE_SWEEP) || defined(RRLW_FANOUT_MAX)
+#define RRLW_BF_GEOMETRY 16u
+#else
+#define RRLW_BF_GEOMETRY 0u
+#endif
+
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -36,6 +78,8 @@
 #include "tables.hpp"
 
 namespace rrlw {
+
+constexpr unsigned BUILD_FLAGS = RRLW_BF_TUNE | RRLW_BF_KNOCKOUT | RRLW_BF_NUMERICS | RRLW_BF_G256 | RRLW_BF_GEOMETRY;
 
 // ------------------------------------------------------------------------------------------------
 // device-side views
@@ -117,6 +161,9 @@ struct Workspace {
     size_t mask_col0;
     // The order in which the batch's columns are taken (k_colsort): position (slot) -> column of the batch, or null = as they come.  Every
     // workspace array above is indexed by SLOT, the caller's arrays by COLUMN (pcol).
+    // k_layer's (window, layer) pairs whose cells do not fit the narrow staging window, left by the narrow launch for the wide one:
+    // {count (parity 0), count (parity 1), pair ..}; null: no wide launch follows (every workgroup keeps the narrow window)
+    int *wide;          // [2 + windows * nlay]
     int *perm;          // [ncolb rounded up to whole windows]
     int *wsort;         // [windows] 1: the window's columns are taken in another order than they lie
     // ... and for such windows the rows the sweeps read of the caller's arrays at EVERY level - layer and interface temperatures, cloud
@@ -1122,17 +1169,32 @@ enum Role { RL_MAJOR, RL_SELF, RL_FOR, RL_MINOR0, RL_MINOR1, RL_MINOR2, RL_CFC0,
 #endif
 constexpr int MINOR_WIN = RRLW_MINOR_WIN;
 static_assert(MINOR_WIN >= 2 && MINOR_WIN <= 19, "minor-gas tables have 19 temperature slices");
+// The staging window of a workgroup comes in two sizes (round 5, profiles/round5_orography.md).  NARROW - three pressure planes (cells
+// with jp0 <= jp <= jp0 + 1), MINOR_WIN minor-gas slices - where the 256 columns of the layer lie that close together: a pressure grid
+// that is (nearly) the same in every column.  WIDE - five planes (jp0 .. jp0 + 3), ten slices, the bands in more passes - where they do
+// not: a terrain-following grid puts the columns of one model level at surface-pressure factors of 0.55 .. 1.03 (three reference planes
+// apart, setcoef :276-284) and at temperatures 30 K apart.  Chosen per workgroup from the spread of its cells; with the narrow window
+// alone half of such a grid's waves fell to the global-memory evaluation and k_layer took 37.7 ms instead of 23 per 1e6 columns.
+template <int NPL_, int MW_> struct StageWin { static constexpr int NPL = NPL_, MW = MW_; };
+using WinNarrow = StageWin<3, MINOR_WIN>;
+#ifdef RRLW_G256
+using WinWide = WinNarrow;               // (the 256-g-point build keeps the narrow window: its tables are twice the size)
+constexpr bool HAVE_WIDE = false;
+#else
+using WinWide = StageWin<5, 10>;
+constexpr bool HAVE_WIDE = true;
+#endif
 
-template <int B, bool LOWER>
+template <int B, bool LOWER, class WN>
 struct Stage {
     static constexpr Region R = LOWER ? BT<B>::lo : BT<B>::up;
     static constexpr int ng = BT<B>::ng;
     static constexpr int nsp = R.key == K_BINARY ? (LOWER ? 9 : 5) : 1;          // mixture points per (P, T) node
-    static constexpr int NPL = 3;                                                // pressure planes staged
+    static constexpr int NPL = WN::NPL;                                          // pressure planes staged
     static constexpr bool has_major = R.key == K_SINGLE || R.key == K_BINARY;
     static constexpr int major_rows = has_major ? NPL * 5 * nsp + 3 : 0;         // + 3: zero-weight stencil rows may lie past the last plane
     static constexpr int nj(int k) { return R.m[k].two_d ? (LOWER ? 9 : 5) : 1; }   // rows per temperature slice of minor gas k
-    static constexpr int mrows(int k) { return k < R.nm ? MINOR_WIN * nj(k) : 0; }
+    static constexpr int mrows(int k) { return k < R.nm ? WN::MW * nj(k) : 0; }
     // doubles of the segment with role `r`, and its start within the band's part of the staging buffer (segments follow each other)
     static constexpr int n(int r)
     {
@@ -1156,18 +1218,18 @@ constexpr int STAGE_DOUBLES = RRLW_STAGE_DOUBLES;
 // the bands of one staging pass, in evaluation order
 template <int... Bs> struct BandList { static constexpr int b[sizeof...(Bs)] = {Bs...}; static constexpr int n = sizeof...(Bs); };
 // start of band number I of the pass within the staging buffer, in doubles
-template <class PL, bool LOWER, int I> constexpr int pass_base()
+template <class PL, bool LOWER, class WN, int I> constexpr int pass_base()
 {
     if constexpr (I == 0) return 0;
-    else return pass_base<PL, LOWER, I - 1>() + Stage<PL::b[I - 1], LOWER>::total;
+    else return pass_base<PL, LOWER, WN, I - 1>() + Stage<PL::b[I - 1], LOWER, WN>::total;
 }
-template <class PL, bool LOWER> constexpr int pass_total() { return pass_base<PL, LOWER, PL::n>(); }
+template <class PL, bool LOWER, class WN> constexpr int pass_total() { return pass_base<PL, LOWER, WN, PL::n>(); }
 
 // where each segment of band B comes from: element offsets into the packed table buffer (wave-uniform: scalar registers)
-template <int B, bool LOWER>
+template <int B, bool LOWER, class WN>
 __device__ __forceinline__ void stage_sources(const DevTables &T, int jp0, int im0, unsigned (&g)[NROLE])
 {
-    using S = Stage<B, LOWER>;
+    using S = Stage<B, LOWER, WN>;
     constexpr Region R = S::R;
     constexpr int ng = S::ng;
     const BandLayout &L = T.band[B - 1];
@@ -1189,14 +1251,14 @@ __device__ __forceinline__ void stage_sources(const DevTables &T, int jp0, int i
 // The staging buffer of a pass is the bands' segments one after the other; a thread copies the 16-byte pieces tid, tid + 256, ...
 // Per-lane source offsets of those pieces: of the segments, whose bounds are compile-time constants, only the few that meet the 256
 // pieces of round k contribute a compare and a select.
-template <class PL, bool LOWER, int I, int IT>
+template <class PL, bool LOWER, class WN, int I, int IT>
 __device__ __forceinline__ void pass_offsets(const DevTables &T, int jp0, int im0, int tid, unsigned (&off)[IT])
 {
     if constexpr (I < PL::n) {
-        using S = Stage<PL::b[I], LOWER>;
-        constexpr int base = pass_base<PL, LOWER, I>();
+        using S = Stage<PL::b[I], LOWER, WN>;
+        constexpr int base = pass_base<PL, LOWER, WN, I>();
         unsigned g[NROLE];
-        stage_sources<PL::b[I], LOWER>(T, jp0, im0, g);
+        stage_sources<PL::b[I], LOWER, WN>(T, jp0, im0, g);
 #pragma unroll
         for (int r = 0; r < NROLE; r++) {
             const int n = S::n(r), lo = (base + S::l(r)) / 2, hi = lo + n / 2;         // constants once the loops are unrolled
@@ -1211,23 +1273,23 @@ __device__ __forceinline__ void pass_offsets(const DevTables &T, int jp0, int im
                 }
             }
         }
-        pass_offsets<PL, LOWER, I + 1, IT>(T, jp0, im0, tid, off);
+        pass_offsets<PL, LOWER, WN, I + 1, IT>(T, jp0, im0, tid, off);
     }
 }
 
 // two-phase copy: every thread first issues ALL its 16-byte loads (at most 12, independent), then writes them to LDS - a pass costs one
 // memory round trip
-template <class PL, bool LOWER>
+template <class PL, bool LOWER, class WN>
 __device__ __forceinline__ void stage_pass(const DevTables &T, __amdgpu_buffer_rsrc_t kt, double2 *lds, int jp0, int im0, int tid)
 {
-    constexpr int NCH = pass_total<PL, LOWER>() / 2;
+    constexpr int NCH = pass_total<PL, LOWER, WN>() / 2;
     constexpr int IT = (NCH + LAYER_BLOCK - 1) / LAYER_BLOCK;
-    static_assert(pass_total<PL, LOWER>() <= STAGE_DOUBLES, "the pass does not fit the staging buffer");
+    static_assert(pass_total<PL, LOWER, WN>() <= STAGE_DOUBLES, "the pass does not fit the staging buffer");
     if constexpr (IT > 0) {
         unsigned off[IT];
 #pragma unroll
         for (int k = 0; k < IT; k++) off[k] = 0u;
-        pass_offsets<PL, LOWER, 0, IT>(T, jp0, im0, tid, off);
+        pass_offsets<PL, LOWER, WN, 0, IT>(T, jp0, im0, tid, off);
         double2 v[IT];
 #pragma unroll
         for (int k = 0; k < IT; k++) v[k] = ld2(kt, off[k]);          // (past the last piece: some table data or, past the buffer, zeros; not stored)
@@ -1240,13 +1302,13 @@ __device__ __forceinline__ void stage_pass(const DevTables &T, __amdgpu_buffer_r
 }
 
 // packed-table offset -> staging-buffer offset, per role, for band B whose part of the buffer starts at BASE
-template <int B, bool LOWER, int BASE>
+template <int B, bool LOWER, class WN, int BASE>
 __device__ __forceinline__ void band_delta(const DevTables &T, int jp0, int im0, unsigned (&delta)[NROLE])
 {
     unsigned g[NROLE];
-    stage_sources<B, LOWER>(T, jp0, im0, g);
+    stage_sources<B, LOWER, WN>(T, jp0, im0, g);
 #pragma unroll
-    for (int r = 0; r < NROLE; r++) delta[r] = (unsigned)(BASE + Stage<B, LOWER>::l(r)) - g[r];
+    for (int r = 0; r < NROLE; r++) delta[r] = (unsigned)(BASE + Stage<B, LOWER, WN>::l(r)) - g[r];
 }
 
 // row offsets of the packed table buffer -> offsets into the staging buffer (rows_prep's row order: key species, self, foreign, minors, halocarbons)
@@ -1276,7 +1338,7 @@ __device__ __forceinline__ void rows_to_lds(Rows<N> &rw, const unsigned (&delta)
 #define RRLW_LOAD_CHUNK 2       // loads in flight per pipeline stage.  From LDS two suffice (8 were needed through the vector L1) and the
 #endif                          // registers saved allow three waves per SIMD: 36.4 vs 40.9 ms per 1e6 cloudy columns
 #ifndef RRLW_CLOUD_QUADS
-#define RRLW_CLOUD_QUADS 2      // quads of a band whose cloudy-layer look-ups are in flight together
+#define RRLW_CLOUD_QUADS 1      // quads of a band whose cloudy-layer look-ups are in flight together (2 until round 5: with the quad-wise table indices two spill ten registers)
 #endif
 
 template <int B, bool LOWER, int N>
@@ -1331,21 +1393,27 @@ struct BandLoads {
     }
 };
 
+// tau0: what the sum starts from - the layer's aerosol optical depth of the band (taut = taug + taua, src/rrtmg_lw_rad.nomcica.f90:527-539),
+// so that the sum arrives complete (one addition per cell less; with taua = 0, the usual case, bit for bit what it was).  The two regions
+// whose gas optical depth is scaled per g-point afterwards (bands 4 and 7 above the tropopause) start from 0 and add taua behind the factor.
 template <int B, bool LOWER, int N, bool LDS>
-__device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const double2 *lds, const Rows<N> &rw, double (&tau)[4 * band_nquad(B)])
+__device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const double2 *lds, const Rows<N> &rw, double tau0, double (&tau)[4 * band_nquad(B)])
 {
     using BL = BandLoads<B, LOWER, N>;
     constexpr int NP = 4 * band_nquad(B);
+    constexpr bool SCALED = BL::R.mult != 0;
 #pragma unroll
-    for (int j = 0; j < NP; j++) tau[j] = 0.0;
+    for (int j = 0; j < NP; j++) tau[j] = (SCALED || j >= BL::ng) ? 0.0 : tau0;
     if constexpr (BL::NL > 0) {
         double2 b0[BL::CH], b1[BL::CH];
         BL::template issue<0, LDS>(kt, lds, rw, b0);
         BL::template step<0, LDS>(kt, lds, rw, b0, b1, tau);
+    }
+    if constexpr (SCALED) {
 #pragma unroll
         for (int j = 0; j < BL::ng; j++) {
-            if constexpr (BL::R.mult == 4) tau[j] = tau[j] * kMult4[j];
-            else if constexpr (BL::R.mult == 7) tau[j] = tau[j] * kMult7[j];
+            if constexpr (BL::R.mult == 4) tau[j] = fma(tau[j], kMult4[j], tau0);
+            else if constexpr (BL::R.mult == 7) tau[j] = fma(tau[j], kMult7[j], tau0);
         }
     }
 }
@@ -1360,6 +1428,7 @@ __device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const 
 struct LayerArgs {
     int ncol, col0, nct, idrv, istart, iend;
     int ktab_bytes;            // size of the packed k-table buffer (buffer descriptor range)
+    int wpar;                  // which of W.wide's two counts this launch pair uses (0 / 1)
     const double *tauaer;      // (nct,nlay,16)
 };
 
@@ -1445,6 +1514,23 @@ __device__ __forceinline__ void scr_store(unsigned *base, size_t cell, const scr
 // transmittance-table index of an optical depth: rtrn :445 (tblint = 10000, Pade constant bpade)
 __device__ __forceinline__ int lut_index(double od, double bpade) { return (int)(10000.0 * fdiv(od, bpade + od) + 0.5); }
 
+// code of a series-branch cell: its optical depth as a float, negative values (and NaN) to zero - the clamp modifier of the conversion
+// ([0, 1]; a thin cell is <= 0.06)
+__device__ __forceinline__ scr_t thin_code(double od) { return __builtin_amdgcn_fmed3f((scr_t)od, 0.0f, 1.0f); }
+
+// table indices of the four cells of a quad, formed together when any of them is thick (see gas_codes); a thin cell's index is not used
+__device__ __forceinline__ void quad_indices(double o0, double o1, double o2, double o3, bool t0, bool t1, bool t2, bool t3, double bpade, int *ig)
+{
+    ig[0] = ig[1] = ig[2] = ig[3] = 0;
+    if (t0 || t1 || t2 || t3) {
+        ig[0] = lut_index(o0, bpade); ig[1] = lut_index(o1, bpade); ig[2] = lut_index(o2, bpade); ig[3] = lut_index(o3, bpade);
+    }
+}
+__device__ __forceinline__ void quad_indices(double o0, double o1, double o2, double o3, double bpade, int *ig)
+{
+    quad_indices(o0, o1, o2, o3, !(o0 <= 0.06), !(o1 <= 0.06), !(o2 <= 0.06), !(o3 <= 0.06), bpade, ig);
+}
+
 // What k_layer hands to the sweeps for one cell is the DECISION the reference takes on its optical depth (rtrn :372-451), in 4 bytes:
 //   code >= 0 : the optical depth itself (<= 0.06, or odtot < 0.06) - the series branch: atrans = od - od^2/2, tfac = od/6
 //   code <  0 : -(index into the 1e-4-quantised transmittance / tfn tables), formed here in float64 exactly as the reference forms it
@@ -1468,7 +1554,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     const int nlay = W.nlay;
     const size_t ncb = W.ncolb;
     double od[NP];
-    rows_eval_band<B, LOWER, N, LDS>(kt, lds, rw, od);
+    rows_eval_band<B, LOWER, N, LDS>(kt, lds, rw, taua, od);
     const double *S = T.stat;
     const double *__restrict__ tau_tbl = S + T.sl.tau_tbl;
     const double bpade = T.bpade;
@@ -1476,10 +1562,12 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
     // below the next branch and keep every loaded row alive until then)
 #pragma unroll
     for (int j = 0; j < NP; j++) {        // optical depth along the diffusivity angle: rtrn :368-369
-        // (as a compare and a select: with fmax(o, 0) - one v_max_f64 - the scheduler overlaps more of the band and spills 29 registers:
-        // 24.3 -> 36.0 ms; this kernel sits at its 168-register budget)
-        double o = secdiff * (od[j] + taua);
-        if (!(o >= 0.0) || j >= ng) o = 0.0;
+        // The reference's `if (odepth < 0) odepth = 0` is NOT applied here: a negative value is a thin cell, and its code is formed with
+        // the conversion's clamp modifier (thin_code: one instruction, where a float64 compare and two selects per cell stood until round
+        // 5; fmax(o, 0) - one v_max_f64 - makes the scheduler overlap more of the band and spills 29 registers: this kernel sits at its
+        // 168-register budget).  The cloudy branch, which adds the cloud optical depth to this value, clamps it first (below).
+        double o = secdiff * od[j];          // (od: gas + aerosol, rows_eval_band)
+        if (j >= ng) o = 0.0;
         od[j] = o;
     }
 #pragma unroll
@@ -1495,11 +1583,21 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             scr4 c;
-            // the table index costs a float64 division (~14 instructions per cell, a third of k_layer's arithmetic); the compiler runs it
-            // under the exec mask of the thick cells and skips it for a wave whose cells are all thin (upper atmosphere, band wings)
+            // the table index costs a float64 division (~14 instructions per cell, a third of k_layer's arithmetic): formed for the four
+            // cells of a QUAD together when any of them is thick (the g-points of a band are ordered by absorption: thick cells are
+            // neighbours) and skipped for a wave whose quad is all thin (upper atmosphere, band wings).  One exec-mask bracket per quad
+            // instead of one per cell - a quarter of the scalar instructions - and four independent division chains in flight instead
+            // of one after the other (round 5: profiles/round5_instruction_diet.md).
+            const bool t0 = !(od[4 * q] <= 0.06), t1 = !(od[4 * q + 1] <= 0.06), t2 = !(od[4 * q + 2] <= 0.06), t3 = !(od[4 * q + 3] <= 0.06);
 #pragma unroll
-            for (int k = 0; k < 4; k++) c.v[k] = cell_code(od[4 * q + k], od[4 * q + k] <= 0.06, bpade);
+            for (int k = 0; k < 4; k++) c.v[k] = thin_code(od[4 * q + k]);
+            if (t0 || t1 || t2 || t3) {
+                const scr_t i0 = -(scr_t)lut_index(od[4 * q], bpade), i1 = -(scr_t)lut_index(od[4 * q + 1], bpade);
+                const scr_t i2 = -(scr_t)lut_index(od[4 * q + 2], bpade), i3 = -(scr_t)lut_index(od[4 * q + 3], bpade);
+                c.v[0] = t0 ? i0 : c.v[0]; c.v[1] = t1 ? i1 : c.v[1]; c.v[2] = t2 ? i2 : c.v[2]; c.v[3] = t3 ? i3 : c.v[3];
+            }
             if (incol) scr_store(W.scr[S_CODE], so0 + q * qstride, c);
+            __builtin_amdgcn_sched_barrier(0);      // (one quad's chains at a time: all of a band's at once cost registers this kernel does not have)
         }
     };
     if constexpr (CLOUD == 0) {
@@ -1518,6 +1616,8 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
         const bool wave_cloudy = __builtin_amdgcn_ballot_w64(cloudy != 0) != 0ull;
         if (!REUSE || !wave_cloudy) gas_codes();
         if (wave_cloudy) {
+#pragma unroll
+            for (int j = 0; j < ng; j++) { if (!(od[j] >= 0.0)) od[j] = 0.0; }       // rtrn :369 (see above)
             constexpr int QCW = CLOUD >= 2 ? 1 : RRLW_CLOUD_QUADS;
             constexpr int QC = QCW < NQ ? QCW : NQ;
 #pragma unroll
@@ -1526,10 +1626,10 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
                 int ig[REUSE ? GC : 1];     // table index of the gas optical depth, 0 for a series cell
                 if constexpr (REUSE) {
 #pragma unroll
-                    for (int k = 0; k < GC; k++) {
-                        const int j = 4 * q0 + k;
-                        ig[k] = 0;
-                        if (j < ng) { if (!(od[j] <= 0.06)) ig[k] = lut_index(od[j], bpade); }
+                    for (int q = 0; q < QC; q++) {
+                        const int j = 4 * (q0 + q);         // (padded cells hold od = 0: thin)
+                        if (q0 + q < NQ) quad_indices(od[j < NP ? j : 0], od[j + 1 < NP ? j + 1 : 0], od[j + 2 < NP ? j + 2 : 0], od[j + 3 < NP ? j + 3 : 0], bpade, ig + 4 * q);
+                        else ig[4 * q] = ig[4 * q + 1] = ig[4 * q + 2] = ig[4 * q + 3] = 0;
                     }
 #pragma unroll
                     for (int q = 0; q < QC; q++) {
@@ -1577,15 +1677,25 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
                     for (int q = 0; q < QC; q++) {
                         if (q0 + q < NQ) {
                             scr4 c;
+                            double odtot[4];
+                            bool tk[4];             // the total optical depth takes the table (a padded cell never does)
+                            int it[4];
 #pragma unroll
                             for (int kk = 0; kk < 4; kk++) {
                                 const int k = 4 * q + kk, j = 4 * (q0 + q) + kk;
                                 const bool p1 = od[j] + odc[k] < 0.06;
                                 const bool p3 = !p1 && !(od[j] <= 0.06);
-                                const double odtot = (p3 ? tg[k] : od[j]) + odc[k];
-                                c.v[kk] = j < ng ? cell_code(odtot, p1, bpade) : (scr_t)0;
+                                odtot[kk] = (p3 ? tg[k] : od[j]) + odc[k];
+                                tk[kk] = j < ng && !p1;
+                            }
+                            quad_indices(odtot[0], odtot[1], odtot[2], odtot[3], tk[0], tk[1], tk[2], tk[3], bpade, it);
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) {
+                                const int j = 4 * (q0 + q) + kk;
+                                c.v[kk] = j < ng ? (tk[kk] ? -(scr_t)it[kk] : (scr_t)odtot[kk]) : (scr_t)0;
                             }
                             if (incol) scr_store(W.scr[S_CODET], so0 + (q0 + q) * qstride, c);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
@@ -1603,7 +1713,7 @@ __device__ __forceinline__ void band_cells(const DevTables &T, const Workspace &
 struct LayerWg { double2 *lds; int jp0, im0, tid, nth, pc; bool lower, ok; };      // pc: the thread's column of the batch (caller arrays; `col` is its position)
 
 // all cells of band B for one (layer, column); BASE_LO / BASE_UP: where the band's tables start in the staging buffer of its pass
-template <int B, int CLOUD, int BASE_LO, int BASE_UP>
+template <int B, int CLOUD, class WN, int BASE_LO, int BASE_UP>
 __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &W, const LayerArgs &a, const LayerCoef &C,
                                            __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol, int cloudy,
                                            const unsigned (&mw)[MASK_WORDS])
@@ -1636,7 +1746,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         Rows<N> rw;
         rows_prep<B, true, N>(T, C, rw);
         if (use_lds) {
-            band_delta<B, true, BASE_LO>(T, wg.jp0, wg.im0, delta);
+            band_delta<B, true, WN, BASE_LO>(T, wg.jp0, wg.im0, delta);
             rows_to_lds<B, true, N>(rw, delta);
             STAMP(2);
             band_cells<B, CLOUD, true, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
@@ -1648,7 +1758,7 @@ __device__ __forceinline__ void layer_band(const DevTables &T, const Workspace &
         Rows<N> rw;
         rows_prep<B, false, N>(T, C, rw);
         if (use_lds) {
-            band_delta<B, false, BASE_UP>(T, wg.jp0, wg.im0, delta);
+            band_delta<B, false, WN, BASE_UP>(T, wg.jp0, wg.im0, delta);
             rows_to_lds<B, false, N>(rw, delta);
             STAMP(2);
             band_cells<B, CLOUD, false, N, true>(T, W, kt, wg.lds, rw, lay, col, incol, secdiff, taua, cloudy, odcld, gbits);
@@ -1673,8 +1783,14 @@ using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13, 
 #else
 using LayerPasses = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 12, 13>, BandList<4, 9>, BandList<7, 3>, BandList<5>>;
 #endif
+// ... and with the wide window (five planes, ten minor-gas slices: the tables of the binary-key bands take 5/3 of the space)
+#ifdef RRLW_G256
+using LayerPassesWide = LayerPasses;
+#else
+using LayerPassesWide = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 13>, BandList<12, 4>, BandList<9>, BandList<7>, BandList<3>, BandList<5>>;
+#endif
 
-template <class PL, int CLOUD, int... I>
+template <class PL, class WN, int CLOUD, int... I>
 __device__ __forceinline__ void pass_run(std::integer_sequence<int, I...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
                                          int cloudy, const unsigned (&mw)[MASK_WORDS])
@@ -1683,31 +1799,33 @@ __device__ __forceinline__ void pass_run(std::integer_sequence<int, I...>, const
     STAMP(4);
     lds_barrier();                      // the previous pass's readers are done with the staging buffer
     STAMP(0);
-    if (wg.lower) stage_pass<PL, true>(T, kt, wg.lds, wg.jp0, wg.im0, wg.tid);
-    else stage_pass<PL, false>(T, kt, wg.lds, wg.jp0, wg.im0, wg.tid);
+    if (wg.lower) stage_pass<PL, true, WN>(T, kt, wg.lds, wg.jp0, wg.im0, wg.tid);
+    else stage_pass<PL, false, WN>(T, kt, wg.lds, wg.jp0, wg.im0, wg.tid);
     lds_barrier();
     STAMP(1);
     ((PL::b[I] >= a.istart && PL::b[I] <= a.iend
-          ? layer_band<PL::b[I], CLOUD, pass_base<PL, true, I>(), pass_base<PL, false, I>()>(T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw)
+          ? layer_band<PL::b[I], CLOUD, WN, pass_base<PL, true, WN, I>(), pass_base<PL, false, WN, I>()>(T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw)
           : (void)0), ...);
 }
-template <int CLOUD, class... PLs>
+template <int CLOUD, class WN, class... PLs>
 __device__ __forceinline__ void passes_run(std::tuple<PLs...> *, const DevTables &T, const Workspace &W, const LayerArgs &a,
                                            const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
                                            int cloudy, const unsigned (&mw)[MASK_WORDS])
 {
-    (pass_run<PLs, CLOUD>(std::make_integer_sequence<int, PLs::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw), ...);
+    (pass_run<PLs, WN, CLOUD>(std::make_integer_sequence<int, PLs::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw), ...);
 }
 
-template <bool GCM, int CLOUD, int GROUP>
-__global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
+// One workgroup's work: the cells of window `bx` (256 consecutive positions) in layer `by` + 1.  WIDE = 0: the narrow staging window; a
+// workgroup whose cells do not fit it leaves its (window, layer) in W.wide and returns.  WIDE = 1: the wide window (k_layer<.., 1> walks
+// that list).
+template <bool GCM, int CLOUD, int WIDE>
+__device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace &W, const GcmIn &g, const ColIn &c, const LayerArgs &a, double2 *s_tab, int *s_wg,
+                                            int bx, int by)
 {
-    __shared__ double2 s_tab[STAGE_DOUBLES / 2];
-    __shared__ int s_wg[3];
-    const int colr = blockIdx.x * blockDim.x + threadIdx.x;
+    const int colr = bx * LAYER_BLOCK + threadIdx.x;
     const bool incol = colr < a.ncol;
     const int col = incol ? colr : a.ncol - 1;      // threads past the end shadow the last column (they take part in the staging and the barriers)
-    const int lay = blockIdx.y + 1;
+    const int lay = by + 1;
     const int pc = pcol(W, col);                    // the column this position holds (k_colsort)
     const size_t gc = (size_t)a.col0 + pc;
     const int nct = a.nct;
@@ -1823,18 +1941,37 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
 #endif
     // staging window of the workgroup: the region of its first thread, the smallest jp and the smallest indminor among the cells of that region
     for (int i = threadIdx.x; i < NRATCHI; i += LAYER_BLOCK) s_ratchi[i] = S[T.sl.rat + i];
-    if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; s_wg[2] = 99; }
+    if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; s_wg[2] = 99; s_wg[3] = 0; s_wg[4] = 0; }
     __syncthreads();
     LayerWg wg;
     wg.lds = s_tab; wg.tid = threadIdx.x; wg.nth = blockDim.x; wg.pc = pc;
     wg.lower = s_wg[0] != 0;
-    if (lower == wg.lower) { atomicMin(&s_wg[1], jp); atomicMin(&s_wg[2], indminor); }
+    // (one wave-level reduction per quantity, then one LDS atomic per wave: 256 atomics on one address serialise)
+    {
+        const bool in = lower == wg.lower;
+        int jlo = in ? jp : 99, ilo = in ? indminor : 99, jhi = in ? jp : 0, ihi = in ? indminor : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            jlo = min(jlo, __shfl_xor(jlo, o, 64)); ilo = min(ilo, __shfl_xor(ilo, o, 64));
+            jhi = max(jhi, __shfl_xor(jhi, o, 64)); ihi = max(ihi, __shfl_xor(ihi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_wg[1], jlo); atomicMin(&s_wg[2], ilo); atomicMax(&s_wg[3], jhi); atomicMax(&s_wg[4], ihi); }
+    }
     __syncthreads();
     wg.jp0 = s_wg[1];
-    wg.im0 = min(s_wg[2], 20 - MINOR_WIN);           // (the window ends with the table's last slice at the latest)
-    wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= 1u && (unsigned)(indminor - wg.im0) <= (unsigned)(MINOR_WIN - 2);
+    using WN = std::conditional_t<WIDE != 0, WinWide, WinNarrow>;
+    wg.im0 = min(s_wg[2], 20 - WN::MW);                     // (the window ends with the table's last slice at the latest)
+    if constexpr (WIDE == 0 && HAVE_WIDE) {
+        // where the workgroup's cells do not fit the narrow window (uniform over the workgroup) and a wide pass follows (W.wide; GCM
+        // entry): the (window, layer) goes to its list
+        if (W.wide && (s_wg[3] - wg.jp0 > WN::NPL - 2 || s_wg[4] - wg.im0 > WN::MW - 2)) {
+            if (threadIdx.x == 0) W.wide[2 + atomicAdd(&W.wide[a.wpar], 1)] = by * ((a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK) + bx;
+            return;
+        }
+    }
+    wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= (unsigned)(WN::NPL - 2) && (unsigned)(indminor - wg.im0) <= (unsigned)(WN::MW - 2);
     STAMP(5);                       // set-up of the workgroup's staging window
-    passes_run<CLOUD>(static_cast<LayerPasses *>(nullptr), T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
+    passes_run<CLOUD, WN>(static_cast<std::conditional_t<WIDE != 0, LayerPassesWide, LayerPasses> *>(nullptr), T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
 #ifdef RRLW_LAYER_STAMPS
     STAMP(4);
     if ((threadIdx.x & 63) == 0) {
@@ -1842,6 +1979,28 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
         atomicAdd(&g_stamps[NSTAMP], 1ull);
     }
 #endif
+}
+
+// WIDE = 0: grid (windows, layers), one workgroup per (window, layer).  WIDE = 1: grid (windows x layers); workgroup i takes pair i of the
+// list the narrow launch left in W.wide = {count of parity 0, of parity 1, pair ..} and leaves at once when there is none (a (window,
+// layer) grid of workgroups that read one word and leave costs ~15 us per 250 000 columns; a fixed grid of workgroups that LOOP over the
+// list spills 151 registers: everything derived from the kernel's arguments stays live round the loop).  The count a launch pair uses
+// is a.wpar's; the narrow launch clears the other one, which the next pair on this workspace set will use (driver.hip: run_layer) - no
+// clearing launch, no ticket.
+template <bool GCM, int CLOUD, int WIDE>
+__global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
+{
+    __shared__ double2 s_tab[STAGE_DOUBLES / 2];
+    __shared__ int s_wg[5];
+    if constexpr (WIDE == 0) {
+        if (W.wide && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) W.wide[a.wpar ^ 1] = 0;
+        layer_cells<GCM, CLOUD, 0>(T, W, g, c, a, s_tab, s_wg, blockIdx.x, blockIdx.y);
+    } else {
+        const int n = __builtin_amdgcn_readfirstlane(W.wide[a.wpar]), gx = (a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK;
+        if ((int)blockIdx.x >= n) return;
+        const int item = __builtin_amdgcn_readfirstlane(W.wide[2 + blockIdx.x]);
+        layer_cells<GCM, CLOUD, 1>(T, W, g, c, a, s_tab, s_wg, item % gx, item / gx);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -70,13 +70,19 @@ class ShardedStep:
     """
 
     def __init__(self, nlay, idrv, per, world, device=None, gather=True):
+        """gather: True - the collective runs on the blocks where they are (RCCL on device blocks, gloo on host blocks); "host" - the
+        blocks live on `device`, a host copy of each is gathered (a process group without a device backend: the two-rank test on one GPU);
+        False - no collective (one rank, or the caller gathers)."""
         import torch
         self.nlay, self.idrv, self.per, self.world = nlay, idrv, per, world
         self.rows = output_rows(nlay, idrv)
         self.outbufs = [torch.zeros((self.rows, per), dtype=torch.float64, device=device) for _ in range(2)]
         self.outs = [output_views(b, nlay, idrv) for b in self.outbufs]
         self.do_gather = bool(gather) and world >= 1
-        self.gathered = [torch.empty((world * self.rows, per), dtype=torch.float64, device=device) if self.do_gather else None for _ in range(2)]
+        self.via_host = gather == "host"
+        gdev = None if self.via_host else device
+        self.hostbufs = [torch.empty((self.rows, per), dtype=torch.float64) for _ in range(2)] if self.via_host else None
+        self.gathered = [torch.empty((world * self.rows, per), dtype=torch.float64, device=gdev) if self.do_gather else None for _ in range(2)]
         self.pending = [None, None]
         self.count = 0
 
@@ -89,7 +95,11 @@ class ShardedStep:
             self.pending[k] = None
         solve(self.outs[k])
         if self.do_gather:
-            self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], self.outbufs[k], async_op=True)
+            src = self.outbufs[k]
+            if self.via_host:                    # (a blocking copy on the current stream: `solve` enqueued its kernels there)
+                self.hostbufs[k].copy_(src)
+                src = self.hostbufs[k]
+            self.pending[k] = dist.all_gather_into_tensor(self.gathered[k], src, async_op=True)
         return k
 
     def drain(self):

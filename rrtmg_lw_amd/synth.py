@@ -18,6 +18,13 @@ the clouds are - the sweeps treat the layers above a column block's highest clou
                     a 0.25-degree grid whose columns are stored longitude-fastest); the rest as "cloudy" (layers 6-14)
   "cloudy_scatter"  the same 2 %, each tower column on its own (no spatial coherence at all: the worst case for any
                     per-block treatment)
+Pressure-grid variant of "cloudy" (same clouds; it measures what k_layer's staging window - the two reference-pressure planes of a
+256-column workgroup's layer - costs on a terrain-following grid, where neighbouring columns of one model level sit at
+different pressures, reference src/rrtmg_lw_setcoef.f90:276-284: `jp` per layer):
+  "cloudy_orography"  surface-pressure factor 0.97-1.03 for 70 % of the columns; the rest lie in mountain ranges - runs of 8-64
+                    consecutive columns (run length fixed per block of 64 columns) with a factor between 0.55 and 0.95 that
+                    is common to the run up to +-0.03 - and the layer temperatures follow the terrain (the profile is read at
+                    the column's own pressures)
 """
 from __future__ import annotations
 
@@ -29,7 +36,7 @@ from .blob import read_blob
 
 NBND = 16
 SEED = 20240607
-CLOUDY_CONFIGS = ("cloudy", "aer_idrv", "cloudy_deep", "cloudy_towers", "cloudy_scatter")
+CLOUDY_CONFIGS = ("cloudy", "aer_idrv", "cloudy_deep", "cloudy_towers", "cloudy_scatter", "cloudy_orography")
 TOWER_TOP = 45          # highest cloud layer (1-based) of the deep / tower variants
 TOWER_RUN = 32          # consecutive columns of one tower system ("cloudy_towers")
 _BASE = None
@@ -91,6 +98,13 @@ class _NP:
     def floor(self, a):
         return np.floor(a)
 
+    def log(self, a):
+        return np.log(a)
+
+    def interp_rows(self, x, xp_, fp_):
+        """piecewise-linear fp(xp) (xp increasing, 1-D) at every element of x"""
+        return np.interp(x, xp_, fp_)
+
     def col_major(self, a):
         """(ncol, ...) logical array -> Fortran-contiguous storage"""
         return np.asfortranarray(a)
@@ -134,6 +148,19 @@ class _Torch:
     def floor(self, a):
         return self.t.floor(a)
 
+    def log(self, a):
+        return self.t.log(a)
+
+    def interp_rows(self, x, xp_, fp_):
+        """piecewise-linear fp(xp) (xp increasing, 1-D numpy) at every element of the tensor x - np.interp's arithmetic, clamped ends"""
+        t = self.t
+        xs = t.as_tensor(np.asarray(xp_, dtype=np.float64), device=self.device)
+        fs = t.as_tensor(np.asarray(fp_, dtype=np.float64), device=self.device)
+        i = t.clamp(t.searchsorted(xs, x.contiguous(), right=True) - 1, 0, xs.numel() - 2)
+        x0, x1, f0, f1 = xs[i], xs[i + 1], fs[i], fs[i + 1]
+        w = t.clamp((x - x0) / (x1 - x0), 0.0, 1.0)
+        return f0 + w * (f1 - f0)
+
     def col_major(self, a):
         # store so that the first logical index is fastest in memory: permute-reverse, make contiguous
         nd = a.dim()
@@ -173,8 +200,25 @@ def make_gcm_inputs(ncol, nlay, config="clear", col0=0, backend="numpy", device=
         q = q * (0.3 + 1.2 * u(3))[:, None]
         tsfc = tlay[:, 0] + (u(4) * 7.0 - 2.0)
         psf = (0.95 + 0.08 * u(14))[:, None]                # surface-pressure factor (sigma-like grid)
+        if config == "cloudy_orography":
+            # mountain ranges: the block of 64 columns fixes the run length (8, 16, 32 or 64), the run decides whether it is a range (30 %)
+            # and how high (factor 0.55-0.95); the columns of a run differ by +-0.03.  Elsewhere 0.97-1.03.
+            blk = col // 64
+            run_len = 8 * (1 << (xp.floor(xp.uniform(blk * 65536 + 17) * 4.0)).astype(col.dtype) if backend == "numpy" else
+                           1 << xp.floor(xp.uniform(blk * 65536 + 17) * 4.0).to(col.dtype))
+            run = col // run_len
+            ur = xp.uniform(run * 65536 + 18)
+            high = 0.55 + 0.40 * xp.uniform(run * 65536 + 19) + 0.06 * (u(14) - 0.5)
+            flat = 0.97 + 0.06 * u(14)
+            psf = xp.where(ur < 0.30, high, flat)[:, None]
         d["play"] = d["play"] * psf
         d["plev"] = d["plev"] * psf
+        if config == "cloudy_orography":
+            # temperatures follow the terrain: the base profile read at the column's own pressures (not at the model level's nominal one)
+            nlnp = -np.log(bp["play"])
+            tlay = xp.interp_rows(-xp.log(d["play"]), nlnp, bp["tlay"]) + dT + (u(2, nlay) * 2.0 - 1.0)
+            tlev = xp.interp_rows(-xp.log(d["plev"]), -np.log(bp["plev"]), bp["tlev"]) + dT
+            tsfc = tlay[:, 0] + (u(4) * 7.0 - 2.0)
     d["tlay"], d["tlev"], d["tsfc"], d["h2ovmr"] = tlay, tlev, tsfc, q
     d["co2vmr"] = ones * xp.asarray(bp["vmr"][1])[None, :]
     d["o3vmr"] = ones * xp.asarray(bp["vmr"][2])[None, :]

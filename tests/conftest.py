@@ -39,7 +39,8 @@ def sweeps(request, hip):
     window of 256 columns reordered by cloud top (rrtmg_lw_hip_set_column_sort with threshold 0; by default only windows where that pays
     are, which small test inputs rarely reach), three launches."""
     prev = hip.set_one_sweep_max(1 << 30 if request.param.startswith("one") else 0)
-    prev_sort = hip.set_column_sort(True, 0 if request.param.startswith("columns") else 1 << 20)
+    prev_min = hip.column_sort_min()
+    prev_sort = hip.set_column_sort(True, 0 if request.param.startswith("columns") else 1 << 24)
     yield request.param
     hip.set_one_sweep_max(prev)
-    hip.set_column_sort(prev_sort, 24)
+    hip.set_column_sort(prev_sort, prev_min)

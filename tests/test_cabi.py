@@ -35,6 +35,34 @@ def test_g256_library_exports_the_same_symbols():
     assert api.lib().rrtmg_lw_hip_gpoints() == 140
 
 
+def test_shipped_libraries_are_built_without_tuning_switches():
+    """kernels.hip carries one-source measurement switches (-DRRLW_...: kernel geometry, numerics variants, two knock-outs that give wrong
+    results).  The shipped libraries are built with none of them: the build-flags word says 0 (8 = the 256-g-point configuration) and the
+    recorded compile command (<lib>.buildinfo, second line) holds no -DRRLW_ but -DRRLW_G256; a knock-out does not even compile outside a
+    tuning build, and rrtmg_lw_hip_init refuses a library whose results are not the product's (checked on the source text: building one
+    takes minutes)."""
+    from rrtmg_lw_amd import api
+    for path, want, allowed in ((api.LIB_PATH, 0, set()), (api.LIB_PATH_G256, 8, {"-DRRLW_G256"})):
+        lib = ctypes.CDLL(path)
+        lib.rrtmg_lw_hip_build_flags.restype = ctypes.c_uint
+        assert lib.rrtmg_lw_hip_build_flags() == want, path
+        info = path + ".buildinfo"
+        if os.path.exists(info):
+            lines = open(info).read().split("\n")
+            if len(lines) > 1 and lines[1].strip():
+                assert set(re.findall(r"-DRRLW_\w+", lines[1])) == allowed, lines[1]
+    k = open(os.path.join(ROOT, "rrtmg_lw_amd", "csrc", "kernels.hip")).read()
+    assert re.search(r"#if \(defined\(RRLW_KO_LDS_UNIFORM\) \|\| defined\(RRLW_KO_HALFG\)\) && !defined\(RRLW_TUNE\)\s*\n#error", k)
+    d = open(os.path.join(ROOT, "rrtmg_lw_amd", "csrc", "driver.hip")).read()
+    assert "RRTMG_LW_ALLOW_TUNE_BUILD" in d and "RRLW_BF_KNOCKOUT | RRLW_BF_NUMERICS" in d
+    # every -D switch the sources test for is either a product configuration or named in the build-flags section
+    used = set(re.findall(r"\bRRLW_[A-Z0-9_]+\b", re.sub(r"//.*", "", k) + re.sub(r"//.*", "", d)))
+    used = {u for u in used if not u.startswith("RRLW_BF_")} - set(re.findall(r"#define (RRLW_\w+)\(", k + d))     # (function-like macros are not switches)
+    head = k[:k.index("namespace rrlw {")]
+    missing = sorted(u for u in used if u not in head)
+    assert not missing, f"switches not covered by the build-flags word: {missing}"
+
+
 def test_no_device_is_a_loud_error():
     import torch
     if torch.cuda.is_available():

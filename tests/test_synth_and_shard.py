@@ -34,6 +34,29 @@ def test_numpy_and_torch_backends_agree(config):
     assert (a["icld"], a["idrv"]) == (b["icld"], b["idrv"])
 
 
+def test_orography_variant():
+    """"cloudy_orography": the same clouds as "cloudy" on a terrain-following pressure grid - 30 % of the columns in mountain ranges (runs
+    of 8-64 columns, surface-pressure factor 0.55-0.95), temperatures read at the column's own pressures.  The reference-pressure index jp
+    of setcoef (src/rrtmg_lw_setcoef.f90:276-284) then spans three values and more inside 256 consecutive columns of a layer; the torch
+    backend agrees with numpy up to the last bits of log / interpolation; shards are reproducible."""
+    import torch
+    a = make_gcm_inputs(1024, 72, "cloudy_orography", col0=5000)
+    b = make_gcm_inputs(1024, 72, "cloudy_orography", col0=5000, backend="torch", device=torch.device("cpu"))
+    for k, v in a.items():
+        if isinstance(v, np.ndarray):
+            assert np.allclose(b[k].numpy(), v, rtol=1e-12, atol=1e-12), k
+    c = make_gcm_inputs(1024, 72, "cloudy", col0=5000)
+    assert np.array_equal(a["cldfr"], c["cldfr"]) and np.array_equal(a["cliqwp"], c["cliqwp"])
+    psf = a["plev"][:, 0] / 1013.0
+    assert 0.2 < (psf < 0.96).mean() < 0.4 and psf.min() < 0.6 and psf.max() > 1.02
+    assert np.all(np.diff(a["plev"], axis=1) < 0) and np.all(a["tlay"] > 150) and np.all(a["tlay"] < 330)
+    jp = np.floor(36.0 - 5.0 * (np.log(a["play"]) + 0.04)).astype(int).reshape(4, 256, 72)
+    assert ((jp.max(axis=1) - jp.min(axis=1)) >= 2).mean() > 0.5
+    part = make_gcm_inputs(100, 72, "cloudy_orography", col0=5300)
+    for k in ("play", "plev", "tlay", "tlev", "tsfc", "cldfr"):
+        assert np.array_equal(a[k][300:400], part[k]), k
+
+
 def test_shards_are_reproducible():
     full = make_gcm_inputs(100, 40, "cloudy", col0=0)
     part = make_gcm_inputs(30, 40, "cloudy", col0=50)

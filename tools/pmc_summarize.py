@@ -151,8 +151,13 @@ def main():
             data = {}                         # (the round-2 layout: one flat dictionary of the cloudy configuration)
         per_call = {k: launches.get(k, 1) for k in traffic}
         path = sum(traffic[k] * max(per_call[k], 1) for k in traffic)
+        import hashlib
+        h = hashlib.sha256()                  # (what bench.py compares: the kernel sources these counters were collected for)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for f in ("kernels.hip", "driver.hip"):
+            h.update(open(os.path.join(root, "rrtmg_lw_amd", "csrc", f), "rb").read())
         data[args.key] = dict(columns=args.columns, kernels={k: round(v, 1) for k, v in traffic.items()}, launches_per_call=per_call,
-                              path_bytes_per_call=round(path, 1), bytes_per_column=round(path / args.columns, 1))
+                              path_bytes_per_call=round(path, 1), bytes_per_column=round(path / args.columns, 1), kernels_sha16=h.hexdigest()[:16])
         json.dump(data, open(args.json, "w"), indent=1, sort_keys=True)
 
 
