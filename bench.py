@@ -394,6 +394,7 @@ def main():
                                gather="rccl all_gather_into_tensor of the packed outputs, overlapped with the next step's kernels" if do_gather else "none",
                                kdata="stand-in (real k-data absent from the reference mount)" if api.kdata_is_standin() else "real",
                                sweeps="k_n1 prototype (measurement)" if args.n1_prototype else "production"),
+                   workspace_GB=round(api.workspace_bytes() / 1e9, 3),
                    roofline=roof, compute=compute, path=path, cpu_baseline=cpu, end_to_end=e2e)
         print(json.dumps(res))
     if use_dist:

@@ -75,6 +75,12 @@ int rrtmg_lw_hip_run_nomcica(
     double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
     double *duflx_dt, double *duflxc_dt);
 
+/* The device-pointer entries below run on the state of the device their arrays live on (hipPointerGetAttributes on `play`): after
+ * rrtmg_lw_hip_init_devices a one-process host with device-resident data on several GPUs uses all of them through the same entries;
+ * arrays on a device the library was not initialised for are an error.  (The Mersenne-Twister generator, irng = 1 - one stream over all
+ * columns of a call - lives on the first device.)  rrtmg_lw_hip_last_device_state: the index of the state this thread's last such call
+ * ran on.  rrtmg_lw_hip_check(stream) waits for the stream and reports the first physics error of any state. */
+int rrtmg_lw_hip_last_device_state(void);
 /* Same contract with DEVICE pointers (a GPU-resident host model, and the benchmark's timed region).
  * Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and the call
  * returns without synchronising; physics errors are reported by rrtmg_lw_hip_check(stream). */
@@ -237,7 +243,10 @@ int rrtmg_lw_hip_queue_columns(void);
  * division than the product's), bit 3: -DRRLW_G256, bit 4: kernel-geometry switches (same results, other speed).
  * rrtmg_lw_hip_init[_devices] refuses a library with bit 1 or 2 unless RRTMG_LW_ALLOW_TUNE_BUILD=1 is set. */
 unsigned rrtmg_lw_hip_build_flags(void);
-/* Columns processed per internal batch (bounds the device workspace); 0 = back to the default; default 262144 (0.06-0.16 MB of device workspace per column at 72 layers, by call shape: see rrtmg_lw_hip_workspace_bytes). */
+/* Columns processed per internal batch (bounds the device workspace); 0 = back to the default, which follows the call's layers: 262144 at up
+ * to 96 layers, 131072 at 137 (the next lower power of two of 262144 x 72 / nlay) - the benchmark's call (1e6 x 72 layers, rtrnmr) then holds
+ * 36.9 GB of workspace, the 137-layer call with aerosol and d/dT 38.7 GB; set_batch(65536) brings the 72-layer call to 9.3 GB at 4 % of its
+ * speed (profiles/round5_batch_sweep.md) (0.06-0.16 MB of device workspace per column at 72 layers, by call shape: see rrtmg_lw_hip_workspace_bytes). */
 int rrtmg_lw_hip_set_batch(int ncol_batch);
 /* on = 1: device-pointer entries run the sweeps / k_flux of column batch i on a second stream while k_layer of batch i+1 runs on the
  * caller's stream (second scratch set, +0.1 MB of workspace per column).  Default 0: a sweep workgroup owns a CU (transmittance table in
@@ -254,6 +263,13 @@ int rrtmg_lw_hip_cu_partition(void);
  * above the clouds).  Batches of up to `ncol` columns (default 4096; RRTMG_LW_ONE_SWEEP_MAX) take ONE sweep launch per band group instead:
  * the cloud-zone kernel walks all levels.  0 = never.  Results do not depend on it (bit for bit).  Returns the previous value. */
 int rrtmg_lw_hip_set_one_sweep_max(int ncol);
+/* A device-resident call of one batch that does not fill the chip is a chain of a dozen dependent launches on four streams.  The second
+ * call with the same arguments (shape, flags, every array pointer - a host model hands over the same arrays step after step) is
+ * captured as a graph, later ones are ONE hipGraphLaunch on the caller's stream (up to 8 graphs are kept).  Calls of up to `ncol`
+ * columns are taken this way (default 16384; RRTMG_LW_GRAPH_MAX; 0 = never).  Results do not depend on it (bit for bit).  Returns the
+ * previous value.  rrtmg_lw_hip_graph_stats: graphs captured / calls replayed since initialisation. */
+int rrtmg_lw_hip_set_graph_max(int ncol);
+void rrtmg_lw_hip_graph_stats(long long *captures, long long *replays);
 /* k_layer stages, per workgroup of 256 columns of one layer, the reference-pressure planes of the absorption tables those columns
  * need.  Where the columns of a model level lie within one plane of each other (a grid that is nearly the same in every column) three
  * planes do; on a terrain-following grid (surface pressures of 550 .. 1040 hPa side by side: up to three planes apart,

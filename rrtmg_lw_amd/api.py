@@ -153,6 +153,11 @@ def init_devices(devices, cpdair=1004.0, kdata=None, static=STATIC_BLOB):
     _initialised = True
 
 
+def last_device_state():
+    """index of the library state (rrtmg_lw_hip_init_devices) this thread's last device-pointer entry ran on"""
+    return int(lib().rrtmg_lw_hip_last_device_state())
+
+
 def num_devices():
     return int(lib().rrtmg_lw_hip_num_devices())
 
@@ -175,6 +180,18 @@ def workspace_bytes():
 def set_one_sweep_max(ncol):
     """cloudy batches of up to `ncol` columns take one sweep launch per band group instead of three (0 = never); returns the previous value"""
     return int(lib().rrtmg_lw_hip_set_one_sweep_max(C.c_int(int(ncol))))
+
+
+def set_graph_max(ncol):
+    """device-resident one-batch calls of up to `ncol` columns are replayed as one graph (rrtmg_lw_hip_set_graph_max; 0 = never); returns the previous value"""
+    return int(lib().rrtmg_lw_hip_set_graph_max(C.c_int(int(ncol))))
+
+
+def graph_stats():
+    """(graphs captured, calls replayed from a graph) since initialisation"""
+    a, b = C.c_longlong(0), C.c_longlong(0)
+    lib().rrtmg_lw_hip_graph_stats(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def set_wide_window(on):

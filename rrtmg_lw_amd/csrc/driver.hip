@@ -38,7 +38,12 @@ constexpr int HOST_SETS = 4;
 
 struct KissTable { unsigned long long stride = 0; long long seed = -1; KissJump host[KJ_NGROUP + 1]; KissJump *dev = nullptr; };
 
-constexpr int DEFAULT_BATCH = 262144;        // rrtmg_lw_hip_set_batch(0) restores it
+// Columns per internal batch when the caller has not chosen (rrtmg_lw_hip_set_batch(0) comes back to this): 262 144 at up to 96 layers,
+// the next lower power of two of 262 144 x 72 / nlay above (131 072 at 137 layers) - the workspace grows with the layers, the step
+// time does not need it.  Measured (profiles/round5_batch_sweep.md, 1e6 columns, 32 768 / 65 536 / 131 072 / 262 144 per batch): cloudy
+// 66.1 / 61.3 / 59.3 / 58.9 ms, clear 46.4 / 43.6 / 42.1 / 39.7, deep clouds 83.5 / 77.8 / 76.0 / 74.4; 137 layers with aerosol and
+// d/dT (5e5 columns) 68.5 / 65.9 / 65.0 / 65.2.
+constexpr int DEFAULT_BATCH = 262144;
 struct State {
     bool init = false;
     int device = -1;
@@ -55,7 +60,6 @@ struct State {
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
     struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *wsort; double *tlayc, *tlevc, *cldfc; int *wide; } prep[2] = {};
-    int wide_par[2] = {0, 0};    // k_layer's wide-window list: the count (0 / 1) the next launch pair on prep set k uses
     // the per-cell scratch written by k_layer and read by the sweeps exists twice as well: sweeps / k_flux of batch i (HBM-bound)
     // run on `sw` while k_layer of batch i+1 (latency-bound) runs on the caller's stream
     struct ScrSet { unsigned *scr[NSCR]; unsigned *fw; } scrset[2] = {};
@@ -77,6 +81,7 @@ struct State {
     size_t mask_bytes = 0;
     double *d_rnd = nullptr;   // one slab of Mersenne-Twister deviates (irng = 1)
     size_t rnd_bytes = 0;
+    bool batch_set = false; // rrtmg_lw_hip_set_batch has named a size (otherwise: auto_batch(nlay))
     int batch = DEFAULT_BATCH;     // columns per internal batch: 0.06-0.16 MB of workspace per column at 72 layers by call shape (38 GB of the 288 for the benchmark's); measured per 1e6 cloudy columns (end of round 2): 131072: 63.1 ms, 262144: 62.7, 524288: 61.7-62.3, 1048576: 61.2 - within the run-to-run spread, not worth the memory
     bool split_sweep = false;    // run the sweeps / k_flux of batch i concurrently with k_layer of batch i+1 (device entries).  Off by default: a sweep
                                  // workgroup owns a CU (transmittance table in LDS), so the two do not share a CU (measured: 1-2 % gain for twice the code scratch)
@@ -99,6 +104,12 @@ struct State {
     std::string err;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool profile = false;
+    // small device-resident calls replayed as ONE graph (run_pipelined): what a call's launches depend on -> the instantiated graph
+    struct GraphEnt { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; unsigned long long used = 0; };
+    std::vector<GraphEnt> graphs;
+    unsigned long long graph_clock = 0;
+    hipStream_t cap = nullptr;         // the stream the launches of such a call are captured on (the caller's may be the null stream)
+    long long graph_replays = 0, graph_captures = 0;
     struct ProfRec { const char *name; hipEvent_t a, b; };
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> evpool;
@@ -115,7 +126,7 @@ thread_local State *g_cur = &g_states[0];
 std::mutex g_mu;
 
 // aggregation of small calls (rrtmg_lw_hip_queue_*): recorded chunks and the pinned staging set they are packed into
-struct QueuedChunk { int ncol; int *icld; const double *in[23]; double *out[8]; };
+struct QueuedChunk { int ncol; int *icld; const double *in[24]; double *out[8]; };       // in[23]: alpha of the generator (fused McICA calls; optional)
 struct ChunkQueue {
     bool open = false;
     int nlay = 0, icld = 0, idrv = 0, inflg = 0, iceflg = 0, liqflg = 0;
@@ -137,6 +148,39 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 #define ENTRY_LOCK std::lock_guard<std::mutex> lk(g_mu); DeviceGuard dg_
+
+// Device-pointer entries: the state (rrtmg_lw_hip_init_devices) of the device the caller's arrays live on, found from the first array
+// (hipPointerGetAttributes) - a one-process host with device-resident data on several GPUs uses all of them through the same entries.
+// Several states on ONE device (the virtual devices of the tests) take such calls in turn.  A pointer the runtime does not know keeps
+// the first state (the behaviour until round 5); arrays on a device the library was not initialised for are an error.  g_cur is
+// thread-local: put back when the entry returns.
+thread_local int tl_dev_state = 0;          // the state this thread's last device-pointer entry ran on (rrtmg_lw_hip_last_device_state)
+struct StateSelect {
+    State *keep;
+    bool bad = false;
+    int dev = -1;
+    // first_only: work that lives on the first state whatever the arrays' device (the Mersenne-Twister generator: ONE stream over all columns
+    // of a call, its jump-ahead tables on the first device) - arrays elsewhere are an error
+    explicit StateSelect(const void *p, bool first_only = false) : keep(g_cur)
+    {
+        static unsigned turn = 0;
+        tl_dev_state = 0;
+        g_cur = &g_states[0];
+        if (!p || g_ndev <= 1) return;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return; }
+        dev = at.device;
+        if (first_only) { bad = g_states[0].device != dev; return; }
+        int match[16], n = 0;
+        for (int d = 0; d < g_ndev && n < 16; d++) if (g_states[d].init && g_states[d].device == dev) match[n++] = d;
+        if (n == 0) { bad = true; return; }
+        tl_dev_state = match[turn++ % (unsigned)n];
+        g_cur = &g_states[tl_dev_state];
+    }
+    ~StateSelect() { g_cur = keep; }
+};
+#define ENTRY_LOCK_FOR(ptr, ...) std::lock_guard<std::mutex> lk(g_mu); StateSelect ss_(ptr, ##__VA_ARGS__); DeviceGuard dg_; \
+    if (ss_.bad) return fail(RRTMG_LW_HIP_EARG, "the arrays live on device %d, which the library was not initialised for (rrtmg_lw_hip_init_devices)", ss_.dev)
 
 // The text of an error belongs to the THREAD whose call failed (concurrent callers: another thread's failure a moment later must not
 // replace it before the caller has read it); the state keeps a copy for threads that have had no error of their own.
@@ -181,6 +225,23 @@ const char *physics_message(int code)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// the batch size in force for a call of nlay layers
+int auto_batch(int nlay)
+{
+    if (nlay <= 96) return DEFAULT_BATCH;
+    int b = DEFAULT_BATCH;
+    while (b > 16384 && (long long)b * nlay > (long long)DEFAULT_BATCH * 72) b >>= 1;
+    return b;
+}
+int eff_batch(int nlay)
+{
+    int b = G.batch_set ? G.batch : auto_batch(nlay);
+    // the sweeps address the rows of a workspace array by 32-bit byte offsets (kernels.hip: bload_*'s soff); the largest is that of
+    // rtrnmr's overlap factors, (nlay + 1) x 3 rows of 16 bytes per column: a batch that would carry it past 2^32 is halved (262 144
+    // columns: beyond 170 layers)
+    while (b > 64 && (unsigned long long)(nlay + 2) * 3ull * 16ull * (unsigned long long)b >= (1ull << 32)) b >>= 1;
+    return b;
+}
 // columns per batch: the fewest batches that respect G.batch, of (nearly) equal size - a short last batch would leave the
 // pipelines (prep / layer / sweep of neighbouring batches) unbalanced, e.g. 125000 columns -> 2 x 62720 rather than 65536 + 59464
 int balanced_batch(int ncol, int cap)
@@ -320,6 +381,7 @@ bool make_groups(int mode, int idrv, int istart, int iend, SweepGroups &fg)
 // (re)allocate the per-batch workspace.  It holds what the call shapes seen so far need and grows with them: the partial slabs of as many
 // band groups as the sweeps form (4 without d/dT, up to NGROUP_MAX with), the d/dT slab only for idrv = 1, rtrn's / rtrnmc's emissivity
 // term only for modes 1 and 3, rtrnmr's overlap factors only for mode 2.  mode: 0 clear, 1 rtrn, 2 rtrnmr, 3 rtrnmc; -1 = everything.
+void graphs_clear();      // (the graphs of small calls hold workspace addresses)
 int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv = 1, int mode = -1)
 {
     SweepGroups fgw;
@@ -328,7 +390,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
     const bool gdp = idrv == 1, efcl = cloud && (mode < 0 || mode == 1 || mode == 3), ovl = cloud && (mode < 0 || mode == 2);
     if (G.ws_base && G.ws_nlay == nlay && G.ws_ncolb >= ncolb && (G.ws_cloud || !cloud) && (G.ws_mc || !mc) && (G.ws_two_scr || !G.split_sweep) &&
         G.ws_groups >= groups && (G.ws_gdp || !gdp) && (G.ws_efcl || !efcl) && (G.ws_ovl || !ovl)) return 0;
-    if (G.ws_base) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(G.ws_base)); G.ws_base = nullptr; }
+    if (G.ws_base) { HIP_TRY(hipDeviceSynchronize()); graphs_clear(); HIP_TRY(hipFree(G.ws_base)); G.ws_base = nullptr; }
     const bool same = G.ws_nlay == nlay;
     ncolb = std::max(ncolb, same ? G.ws_ncolb : 0);
     cloud = cloud || G.ws_cloud || mc;
@@ -394,7 +456,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
     HIP_TRY(hipMalloc(&G.ws_base, total));
     size_t off = 0;
     for (auto &it : items) { *it.p = (char *)G.ws_base + off; off += align_up(it.bytes, 256); }
-    for (auto &ps : G.prep) HIP_TRY(hipMemset(ps.wide, 0, 8));         // the two counts of k_layer's wide-window list (kernels.hip: k_layer)
+    for (auto &ps : G.prep) HIP_TRY(hipMemset(ps.wide, 0, 8));         // the count of k_layer's wide-window list (kernels.hip: k_layer)
     W.ncolb = ncolb;
     W.nlay = nlay;
     W.err = G.d_err;
@@ -549,9 +611,8 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     Workspace Wn = Wk;
     if (!GCM || !HAVE_WIDE || !g_wide_window) Wn.wide = nullptr;
     const dim3 wgrid(gx * nlay);
-    // (the pair's count alternates per workspace set; the narrow launch clears the one the set's next pair will use)
-    la.wpar = 0;
-    if (Wn.wide) { int &par = G.wide_par[Wn.wide == G.prep[1].wide ? 1 : 0]; la.wpar = par; par ^= 1; }
+    // (the list's count: cleared on the stream in front of the narrow launch - a memset node when the call is captured as a graph)
+    if (Wn.wide) HIP_TRY(hipMemsetAsync(Wn.wide, 0, sizeof(int), s));
 #ifdef RRLW_TUNE
     // tuning builds (tools/build_variant.sh name -DRRLW_TUNE ...): only the kernels of the benchmark's default workload - GCM entry,
     // rtrn / rtrnmr, idrv = 0 - are instantiated (a quarter of the compile time); every other call shape is refused
@@ -753,13 +814,32 @@ int ensure_pipeline()
 #endif
 int launch_kiss(hipStream_t s, const Workspace &Wk, int ncol, int col0, int nb, int nlay, int icld, int permuteseed, const SubcolIn &in);
 
+// A device-resident call of ONE batch that does not fill the chip is a chain of a dozen dependent launches on up to four streams: the
+// kernels themselves take two thirds of its time, launch gaps and cross-stream event hops the rest (profiles/round4_small_calls.md).  The
+// second call with the same arguments - shape, flags, every array pointer: a host model hands over the same arrays time step after time
+// step - is captured (hipStreamBeginCapture on a stream of the library's own) and every later one replays the instantiated graph with one
+// hipGraphLaunch on the caller's stream.  rrtmg_lw_hip_set_graph_max / RRTMG_LW_GRAPH_MAX: the largest call (columns) taken this way;
+// 0 = never.  Same kernels, same arguments: same results.
+int g_graph_max = []() { const char *e = getenv("RRTMG_LW_GRAPH_MAX"); return e ? std::max(0, atoi(e)) : 16384; }();
+constexpr size_t GRAPH_CACHE = 8;
+void graphs_clear()
+{
+    for (auto &e : G.graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    G.graphs.clear();
+}
+template <class T> void key_put(std::vector<unsigned char> &k, const T &v)
+{
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&v);
+    k.insert(k.end(), p, p + sizeof(T));
+}
+
 struct KissGen { bool on; int icld, permuteseed; const double *alpha; };      // kissvec generator folded into the per-batch prep
 
 int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const GcmIn &g, int inflag, int iceflag, int liqflag,
                   const FluxOut &out, const McIn *mc, KissGen gen = KissGen{false, 0, 0, nullptr})
 {
     if (int rc = ensure_pipeline()) return rc;
-    const int nbmax = balanced_batch(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, eff_batch(nlay));
     // a call that is ONE batch has nothing for its per-column kernels to run beside: they go on the caller's stream, one cross-stream
     // event hop (~20 us of a 0.6 ms call) less
     const bool single = ncol <= nbmax && !(G.split_sweep && G.cu_layer > 0);
@@ -773,11 +853,56 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         if (int rc = make_stream(&G.lay_m, 0, G.cu_layer)) return rc;
     }
     if (G.ev_last_valid) HIP_TRY(hipStreamWaitEvent(s, G.ev_last, 0));      // an earlier call, possibly on another stream, still owns the workspace
+    // a small one-batch call as a graph (above): replay, capture (second call with this key), or the plain launches
+    State::GraphEnt *gent = nullptr;
+    bool capture = false;
+    if (single && !split && !gen.on && !mc && !G.profile && !G.n1 && ncol <= g_graph_max) {
+        std::vector<unsigned char> key;
+        key_put(key, ncol); key_put(key, nlay); key_put(key, mode); key_put(key, idrv); key_put(key, inflag); key_put(key, iceflag); key_put(key, liqflag);
+        const double *gp[] = {g.play, g.plev, g.tlay, g.tlev, g.tsfc, g.h2ovmr, g.o3vmr, g.co2vmr, g.ch4vmr, g.n2ovmr, g.o2vmr, g.cfc11vmr, g.cfc12vmr,
+                              g.cfc22vmr, g.ccl4vmr, g.emis, g.cldfr, g.taucld, g.cicewp, g.cliqwp, g.reice, g.reliq, g.tauaer, g.tauctot,
+                              out.uflx, out.dflx, out.hr, out.uflxc, out.dflxc, out.hrc, out.duflx_dt, out.duflxc_dt, out.fnet, out.fnetc};
+        key_put(key, gp);
+        // (what else decides which kernels run with which arguments: the workspace, the tuning switches)
+        key_put(key, G.ws_base); key_put(key, G.ws_bytes); key_put(key, g_colsort); key_put(key, g_colsort_min); key_put(key, g_one_sweep_max);
+        key_put(key, g_wide_window); key_put(key, G.sweep_fanout); key_put(key, eff_batch(nlay));
+        for (auto &e : G.graphs) if (e.key == key) { gent = &e; break; }
+        if (!gent) {
+            if (G.graphs.size() >= GRAPH_CACHE) {           // the entry used longest ago makes room
+                size_t old = 0;
+                for (size_t j = 1; j < G.graphs.size(); j++) if (G.graphs[j].used < G.graphs[old].used) old = j;
+                if (G.graphs[old].exec) (void)hipGraphExecDestroy(G.graphs[old].exec);
+                G.graphs.erase(G.graphs.begin() + (long)old);
+            }
+            G.graphs.emplace_back();
+            gent = &G.graphs.back();
+            gent->key = key;
+        }
+        gent->used = ++G.graph_clock;
+        if (gent->exec) {
+            HIP_TRY(hipGraphLaunch(gent->exec, s));
+            G.graph_replays++;
+            HIP_TRY(hipEventRecord(G.ev_last, s));
+            G.ev_last_valid = true;
+            return 0;
+        }
+        // the first call with a key takes the plain launches (whatever is set up lazily - streams, kernel attributes - then exists), the
+        // second is captured
+        capture = gent->seen >= 1 && !gent->failed;
+        gent->seen++;
+        if (capture && !G.cap) HIP_TRY(hipStreamCreateWithFlags(&G.cap, hipStreamNonBlocking));
+    }
+    const hipStream_t s_call = s;
+    if (capture) {
+        if (hipStreamBeginCapture(G.cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); capture = false; gent->failed = true; }
+        else s = G.cap;
+    }
+    const hipStream_t aux_ = capture ? s : aux;
     if (!single) {
         HIP_TRY(hipEventRecord(G.ev_in, s));             // inputs are ready when the caller's stream gets here
         HIP_TRY(hipStreamWaitEvent(aux, G.ev_in, 0));
     }
-    int i = 0;
+    int i = 0, rc_cap = 0;
     for (int col0 = 0; col0 < ncol; col0 += nbmax, i++) {
         const int nb = std::min(nbmax, ncol - col0), k = i & 1;
         const Workspace Wk = ws_for(k, use_colsort(true, mode, nb) && !mc);
@@ -785,6 +910,14 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         // (The per-column kernels of batch i thus run beside k_layer of batch i-1.  Their few long-lived waves cost whatever runs beside
         // them about what the overlap saves - measured per 1e6 columns: k_layer 32.7 ms beside them, 28.3 alone, step 93.9 vs 96.0 on one
         // stream; held back until k_layer is done they slow the sweep instead, 94.4, and the McICA generator then costs 7 ms more.)
+        if (capture) {
+            // (one batch, one stream: the batch's launches, the fork to the sweep streams and their join become the graph; an error ends
+            // the capture before it is reported)
+            rc_cap = run_prep<true>(s, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag);
+            if (rc_cap == 0) rc_cap = run_layer<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc);
+            if (rc_cap == 0) rc_cap = run_sweep<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc);
+            continue;
+        }
         if (int rc = run_prep<true>(aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
         if (gen.on) {
 #if RRLW_GEN_BESIDE_SWEEP
@@ -828,6 +961,25 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
             if (int rc = run_sweep<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc)) return rc;
             HIP_TRY(hipEventRecord(G.ev_done[k], s));
         }
+    }
+    if (capture) {
+        (void)aux_;
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(G.cap, &graph);
+        s = s_call;
+        if (rc_cap != 0) { if (graph) (void)hipGraphDestroy(graph); gent->failed = true; return rc_cap; }
+        hipGraphExec_t exec = nullptr;
+        if (ce != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            // no graph on this runtime for this call shape: the plain launches, now and from here on
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            gent->failed = true;
+            return run_pipelined(s, ncol, nlay, mode, idrv, g, inflag, iceflag, liqflag, out, mc, gen);
+        }
+        (void)hipGraphDestroy(graph);
+        gent->exec = exec;
+        G.graph_captures++;
+        HIP_TRY(hipGraphLaunch(exec, s));
     }
     if (split) {                                  // the caller's stream sees the results of every batch
         for (int k = 0; k < std::min(i, 2); k++) HIP_TRY(hipStreamWaitEvent(s, G.ev_done[k], 0));
@@ -1798,6 +1950,8 @@ static void finalize_state()
     const bool first = g_cur == &g_states[0];
     (void)hipSetDevice(G.device);
     (void)hipDeviceSynchronize();
+    graphs_clear();
+    if (G.cap) { (void)hipStreamDestroy(G.cap); G.cap = nullptr; }
     if (G.ws_base) (void)hipFree(G.ws_base);
     if (G.stage_base) (void)hipFree(G.stage_base);
     if (first) {            // the queue and the generator's caches live on the first device
@@ -1844,10 +1998,13 @@ static void finalize_state()
 
 int rrtmg_lw_hip_set_batch(int ncol_batch)
 {
-    if (ncol_batch == 0) ncol_batch = DEFAULT_BATCH;
+    if (ncol_batch == 0) {              // back to the default: by the call's layers (auto_batch)
+        for (int d = 0; d < MAXDEV; d++) { g_states[d].batch = DEFAULT_BATCH; g_states[d].batch_set = false; }
+        return 0;
+    }
     if (ncol_batch < 64) return fail(RRTMG_LW_HIP_EARG, "batch must be >= 64 columns");
     if (ncol_batch > 64 * SORT_MAXBLK) return fail(RRTMG_LW_HIP_EARG, "batch must be <= %d columns", 64 * SORT_MAXBLK);      // k_blocksort orders a batch's 64-column blocks in LDS
-    for (int d = 0; d < MAXDEV; d++) g_states[d].batch = ncol_batch;
+    for (int d = 0; d < MAXDEV; d++) { g_states[d].batch = ncol_batch; g_states[d].batch_set = true; }
     return 0;
 }
 
@@ -1881,6 +2038,23 @@ int rrtmg_lw_hip_set_one_sweep_max(int ncol)
     const int prev = g_one_sweep_max;
     g_one_sweep_max = ncol < 0 ? 0 : ncol;
     return prev;
+}
+
+// Device-resident one-batch calls of up to `ncol` columns are replayed as one graph from their third occurrence on (run_pipelined);
+// 0 = never.  Results do not depend on it.  Returns the previous value.
+int rrtmg_lw_hip_set_graph_max(int ncol)
+{
+    ENTRY_LOCK;
+    const int prev = g_graph_max;
+    g_graph_max = ncol < 0 ? 0 : ncol;
+    return prev;
+}
+// graphs captured / calls replayed from a graph since the library was initialised (first device)
+void rrtmg_lw_hip_graph_stats(long long *captures, long long *replays)
+{
+    ENTRY_LOCK;
+    if (captures) *captures = g_states[0].graph_captures;
+    if (replays) *replays = g_states[0].graph_replays;
 }
 
 // k_layer's second pass with the wide staging window for (window, layer) pairs whose columns lie more than one reference-pressure plane
@@ -2019,8 +2193,24 @@ int rrtmg_lw_hip_check(void *stream)
 {
     ENTRY_LOCK;
     if (!G.init) return fail(RRTMG_LW_HIP_ENOTINIT, "rrtmg_lw_hip_init has not been called");
-    return read_physics_error((hipStream_t)stream);
+    if (g_ndev <= 1) return read_physics_error((hipStream_t)stream);
+    // several states (rrtmg_lw_hip_init_devices): the device-pointer entries run on the state of the arrays' device - wait for the stream,
+    // then look at every state's error word (the first error found is reported)
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    State *const keep = g_cur;
+    int rc = 0;
+    for (int d = 0; d < g_ndev && rc == 0; d++) {
+        g_cur = &g_states[d];
+        if (!G.init) continue;
+        DeviceGuard dg2;
+        rc = read_physics_error(nullptr);
+        if (rc != 0 && d > 0) { const std::string e = G.err; g_cur = keep; G.err = e; }
+    }
+    g_cur = keep;
+    return rc;
 }
+// the state (index into the devices of rrtmg_lw_hip_init_devices) this thread's last device-pointer entry ran on
+int rrtmg_lw_hip_last_device_state(void) { return tl_dev_state; }
 
 int rrtmg_lw_hip_run_nomcica_device(
     int ncol, int nlay, int *icld, int idrv,
@@ -2033,13 +2223,13 @@ int rrtmg_lw_hip_run_nomcica_device(
     double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc,
     double *duflx_dt, double *duflxc_dt, void *stream)
 {
-    ENTRY_LOCK;
+    ENTRY_LOCK_FOR(play);
     if (int rc = check_common(ncol, nlay)) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.nomcica.f90:456
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : (*icld == 1 ? 1 : 2);      // :546-560 (icld=0 -> rtrnmr clear branch)
-    const int nbmax = balanced_batch(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, eff_batch(nlay));
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false, idrv, mode)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer};
@@ -2067,7 +2257,7 @@ int nomcica_host_range(int ncol, int c0, int c1, int nlay, int icld, int idrv,
     const bool cloud = icld >= 1;           // inatm copies the cloud arrays only when icld >= 1 (:893-910)
     // host arrays: the copies bound the rate (PCIe), and they overlap with the kernels only across batches - smaller batches than
     // the device-resident default
-    const int nbmax = balanced_batch(c1 - c0, std::min(G.batch, HOST_BATCH));
+    const int nbmax = balanced_batch(c1 - c0, std::min(eff_batch(nlay), HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false, idrv, mode)) return rc;
     const size_t L = (size_t)nlay;
     // What the copies need not carry (62 % of a column's bytes are taucld and tauaer, 2 x 16 nlay values):
@@ -2240,7 +2430,7 @@ int rrtmg_lw_hip_run_columns(
     if (int rc = check_common(ncol, nlayers)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
-    if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns handles at most one batch (%d columns)", G.batch);
+    if (ncol > eff_batch(nlayers)) return fail(RRTMG_LW_HIP_EARG, "run_columns handles at most one batch (%d columns)", eff_batch(nlayers));
     const int mode = icld == 0 ? 0 : (icld == 1 ? 1 : 2);
     if (int rc = ensure_workspace(nlayers, ncol, true, false, idrv, mode)) return rc;
     const size_t n = (size_t)ncol, L = (size_t)nlayers;
@@ -2292,7 +2482,7 @@ int rrtmg_lw_hip_run_columns_mcica(
     if (int rc = check_common(ncol, nlayers)) return rc;
     if (G.init) HIP_TRY(hipDeviceSynchronize());      // asynchronous device-entry work of earlier calls shares the workspace
     if (istart < 1 || iend > 16 || istart > iend) return fail(RRTMG_LW_HIP_EARG, "bad band range %d..%d", istart, iend);
-    if (ncol > G.batch) return fail(RRTMG_LW_HIP_EARG, "run_columns_mcica handles at most one batch (%d columns)", G.batch);
+    if (ncol > eff_batch(nlayers)) return fail(RRTMG_LW_HIP_EARG, "run_columns_mcica handles at most one batch (%d columns)", eff_batch(nlayers));
     const int mode = icld == 0 ? 0 : 3;
     if (int rc = ensure_workspace(nlayers, ncol, true, true, idrv, mode)) return rc;
     const size_t n = (size_t)ncol, L = (size_t)nlayers;
@@ -2488,7 +2678,18 @@ static void queue_parallel(size_t n, F f)
 
 // The chunks as ONE call: every array is [rows][columns][inner] - row r of a chunk goes to row r of the packed array at the chunk's column
 // offset (pinned set Q.pinned) - then nomcica_host on the packed arrays, then the outputs back to every chunk.  Caller holds the entry lock.
-static int solve_chunks(const std::vector<QueuedChunk> &chunks, long long N, int nlay, int icld_in, int idrv, int inflg, int iceflg, int liqflg)
+// kind 0: rrtmg_lw (non-McICA); kind 1: the fused sub-column generator + McICA solver with the kissvec generator (a stream per column:
+// the columns of a packed call draw what they draw on their own), permuteseed and - has_alpha - the generator's alpha array as input 23
+static int mcica_subcol_host(int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng,
+    const double *play, const double *plev, const double *tlay, const double *tlev, const double *tsfc,
+    const double *h2ovmr, const double *o3vmr, const double *co2vmr, const double *ch4vmr, const double *n2ovmr,
+    const double *o2vmr, const double *cfc11vmr, const double *cfc12vmr, const double *cfc22vmr,
+    const double *ccl4vmr, const double *emis, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
+    const double *reliq, const double *alpha, const double *tauaer,
+    double *uflx, double *dflx, double *hr, double *uflxc, double *dflxc, double *hrc, double *duflx_dt, double *duflxc_dt);
+static int solve_chunks(const std::vector<QueuedChunk> &chunks, long long N, int nlay, int icld_in, int idrv, int inflg, int iceflg, int liqflg,
+                        int kind = 0, int permuteseed = 0, bool has_alpha = false)
 {
     size_t in_inner[23], in_rows[23], out_rows[8];
     double *in_p[23], *out_p[8];
@@ -2496,6 +2697,7 @@ static int solve_chunks(const std::vector<QueuedChunk> &chunks, long long N, int
     size_t tot = 0;
     for (int k = 0; k < 23; k++) tot += in_inner[k] * in_rows[k] * (size_t)N;
     for (int k = 0; k < 8; k++) tot += out_rows[k] * (size_t)N;
+    if (has_alpha) tot += (size_t)nlay * (size_t)N;
     if (Q.pinned_doubles < tot) {
         if (Q.pinned) { forget_pinned(Q.pinned); (void)hipHostFree(Q.pinned); Q.pinned = nullptr; Q.pinned_doubles = 0; }
         HIP_TRY(hipHostMalloc((void **)&Q.pinned, tot * sizeof(double), hipHostMallocDefault));
@@ -2505,6 +2707,7 @@ static int solve_chunks(const std::vector<QueuedChunk> &chunks, long long N, int
     double *p = Q.pinned;
     for (int k = 0; k < 23; k++) { in_p[k] = p; p += in_inner[k] * in_rows[k] * (size_t)N; }
     for (int k = 0; k < 8; k++) { out_p[k] = p; p += out_rows[k] * (size_t)N; }
+    double *alpha_p = has_alpha ? p : nullptr;
     const bool cloud = !(icld_in == 0);
     std::vector<size_t> offs(chunks.size());
     { size_t off = 0; for (size_t i = 0; i < chunks.size(); i++) { offs[i] = off; off += (size_t)chunks[i].ncol; } }
@@ -2517,9 +2720,16 @@ static int solve_chunks(const std::vector<QueuedChunk> &chunks, long long N, int
             for (size_t r = 0; r < in_rows[k]; r++)
                 memcpy(in_p[k] + (r * (size_t)N + offs[i]) * in_inner[k], c.in[k] + r * w, w * sizeof(double));
         }
+        if (has_alpha && cloud)
+            for (size_t r = 0; r < (size_t)nlay; r++) memcpy(alpha_p + r * (size_t)N + offs[i], c.in[23] + r * (size_t)c.ncol, (size_t)c.ncol * sizeof(double));
     });
-    int icld = icld_in;
-    const int rc = nomcica_host((int)N, nlay, &icld, idrv, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
+    int icld = icld_in, irng = 0;
+    const int rc = kind == 1
+        ? mcica_subcol_host((int)N, nlay, &icld, idrv, permuteseed, &irng, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
+                            in_p[8], in_p[9], in_p[10], in_p[11], in_p[12], in_p[13], in_p[14], in_p[15], inflg, iceflg, liqflg,
+                            in_p[16], in_p[17], in_p[18], in_p[19], in_p[20], in_p[21], alpha_p, in_p[22],
+                            out_p[0], out_p[1], out_p[2], out_p[3], out_p[4], out_p[5], idrv == 1 ? out_p[6] : nullptr, idrv == 1 ? out_p[7] : nullptr)
+        : nomcica_host((int)N, nlay, &icld, idrv, in_p[0], in_p[1], in_p[2], in_p[3], in_p[4], in_p[5], in_p[6], in_p[7],
                                             in_p[8], in_p[9], in_p[10], in_p[11], in_p[12], in_p[13], in_p[14], in_p[15], inflg, iceflg, liqflg,
                                             cloud ? in_p[16] : nullptr, cloud ? in_p[17] : nullptr, cloud ? in_p[18] : nullptr, cloud ? in_p[19] : nullptr,
                                             cloud ? in_p[20] : nullptr, cloud ? in_p[21] : nullptr, in_p[22],
@@ -2562,6 +2772,7 @@ namespace {
 struct CallReq {
     QueuedChunk c;
     int nlay, icld, idrv, inflg, iceflg, liqflg;
+    int kind = 0, permuteseed = 0;             // kind 1: the fused generator + McICA entry (kissvec); see solve_chunks
     int rc = 0;
     bool done = false, lead = false;
     std::string err;                           // the text of rc != 0, handed to the owner's thread
@@ -2590,12 +2801,18 @@ void comb_serve(std::vector<CallReq *> &batch)
         for (size_t j = i; j < batch.size(); j++) {
             const CallReq &b = *batch[j];
             if (!served[j] && b.nlay == a.nlay && b.icld == a.icld && b.idrv == a.idrv && b.inflg == a.inflg && b.iceflg == a.iceflg && b.liqflg == a.liqflg &&
+                b.kind == a.kind && b.permuteseed == a.permuteseed && (b.c.in[23] != nullptr) == (a.c.in[23] != nullptr) &&
                 N + b.c.ncol <= 0x7fffffffLL) { grp.push_back(j); N += b.c.ncol; }
         }
         auto alone = [&](CallReq &r) {
             const QueuedChunk &c = r.c;
-            int icld = r.icld;
+            int icld = r.icld, irng = 0;
             g_comb_passes++;
+            if (r.kind == 1)
+                r.rc = mcica_subcol_host(c.ncol, r.nlay, &icld, r.idrv, r.permuteseed, &irng, c.in[0], c.in[1], c.in[2], c.in[3], c.in[4], c.in[5], c.in[6], c.in[7],
+                                         c.in[8], c.in[9], c.in[10], c.in[11], c.in[12], c.in[13], c.in[14], c.in[15], r.inflg, r.iceflg, r.liqflg, c.in[16], c.in[17],
+                                         c.in[18], c.in[19], c.in[20], c.in[21], c.in[23], c.in[22], c.out[0], c.out[1], c.out[2], c.out[3], c.out[4], c.out[5], c.out[6], c.out[7]);
+            else
             r.rc = nomcica_host(c.ncol, r.nlay, &icld, r.idrv, c.in[0], c.in[1], c.in[2], c.in[3], c.in[4], c.in[5], c.in[6], c.in[7], c.in[8], c.in[9], c.in[10],
                                 c.in[11], c.in[12], c.in[13], c.in[14], c.in[15], r.inflg, r.iceflg, r.liqflg, c.in[16], c.in[17], c.in[18], c.in[19], c.in[20], c.in[21],
                                 c.in[22], c.out[0], c.out[1], c.out[2], c.out[3], c.out[4], c.out[5], c.out[6], c.out[7]);
@@ -2607,7 +2824,7 @@ void comb_serve(std::vector<CallReq *> &batch)
             std::vector<QueuedChunk> chunks;
             for (size_t j : grp) chunks.push_back(batch[j]->c);
             g_comb_passes++;
-            const int rc = solve_chunks(chunks, N, a.nlay, a.icld, a.idrv, a.inflg, a.iceflg, a.liqflg);
+            const int rc = solve_chunks(chunks, N, a.nlay, a.icld, a.idrv, a.inflg, a.iceflg, a.liqflg, a.kind, a.permuteseed, a.c.in[23] != nullptr);
             if (rc == 0) { for (size_t j : grp) batch[j]->rc = 0; }
             else { for (size_t j : grp) alone(*batch[j]); }      // an error (one caller's bad particle size ...) belongs to the call that caused it: each chunk again, on its own
         }
@@ -2716,14 +2933,14 @@ int rrtmg_lw_hip_run_mcica_device(
     const double *cldfmcl, const double *taucmcl, const double *ciwpmcl, const double *clwpmcl,
     const double *reicmcl, const double *relqmcl, const double *tauaer, OUT_PARAMS, void *stream)
 {
-    ENTRY_LOCK;
+    ENTRY_LOCK_FOR(play);
     if (int rc = check_mcica_build()) return rc;
     if (int rc = check_common(ncol, nlay)) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (*icld < 0 || *icld > 3) *icld = 2;                       // src/rrtmg_lw_rad.f90:469
     if (idrv == 1 && (!duflx_dt || !duflxc_dt)) return fail(RRTMG_LW_HIP_EARG, "idrv=1 needs duflx_dt and duflxc_dt");
     const int mode = *icld == 0 ? 0 : 3;                         // inatm leaves the cloud arrays zero when icld = 0 (:899-911)
-    const int nbmax = balanced_batch(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, eff_batch(nlay));
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0, mode == 3, idrv, mode)) return rc;
     GcmIn g{play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr,
             ccl4vmr, emis, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tauaer};
@@ -2750,7 +2967,7 @@ int rrtmg_lw_hip_run_mcica(
     HIP_TRY(hipDeviceSynchronize());        // asynchronous device-entry work of earlier calls shares the workspace
     // the sub-column arrays are 4 x 140 x nlay doubles per column: bound the batch so that staging stays below ~4 GB
     const int mcmax = (int)std::max<size_t>(64, ((size_t)1 << 30) / ((size_t)4 * NGPT * nlay * 8));        // (HOST_SETS staging sets of 1 GiB)
-    const int nbmax = balanced_batch(c1 - c0, std::min(std::min(G.batch, HOST_BATCH), cloud ? mcmax : HOST_BATCH));
+    const int nbmax = balanced_batch(c1 - c0, std::min(std::min(eff_batch(nlay), HOST_BATCH), cloud ? mcmax : HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, cloud, cloud, idrv, mode)) return rc;
     const size_t L = (size_t)nlay;
     std::vector<HostIn> ins = {
@@ -2812,7 +3029,7 @@ int rrtmg_lw_hip_mcica_subcol_device(
     const double *clwp, const double *rei, const double *rel, const double *tauc, const double *alpha,
     double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl, double *taucmcl, void *stream)
 {
-    ENTRY_LOCK;
+    ENTRY_LOCK_FOR(play, irng && *irng != 0);
     if (int rc = check_mcica_build()) return rc;
     if (int rc = check_subcol_args(ncol, nlay, icld, irng)) return rc;
     if (icld == 0) return 0;                                      // src/mcica_subcol_gen_lw.f90:265
@@ -2905,7 +3122,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
     const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS, void *stream)
 {
-    ENTRY_LOCK;
+    ENTRY_LOCK_FOR(play, irng && *irng != 0);
     if (int rc = check_mcica_build()) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
@@ -2914,7 +3131,7 @@ int rrtmg_lw_hip_run_mcica_subcol_device(
     if (*icld > 3) *icld = 2;                                     // what rrtmg_lw does to the generator's icld (src/rrtmg_lw_rad.f90:469)
     const int mode = icld_gen == 0 ? 0 : 3;
     hipStream_t s = (hipStream_t)stream;
-    const int nbmax = balanced_batch(ncol, G.batch);
+    const int nbmax = balanced_batch(ncol, eff_batch(nlay));
     if (int rc = ensure_workspace(nlay, nbmax, mode != 0, false, idrv, mode)) return rc;      // mask path: no per-g-point cloud arrays
     KissGen gen{false, icld_gen, permuteseed, alpha};
     if (mode == 3) {
@@ -2942,7 +3159,7 @@ static int mcica_subcol_host_range(
     const int mode = icld_gen == 0 ? 0 : 3;
     const bool cloud = mode == 3, two = icld_gen == 4 || icld_gen == 5;
     const int nloc = c1 - c0;
-    const int nbmax = balanced_batch(nloc, std::min(G.batch, HOST_BATCH));
+    const int nbmax = balanced_batch(nloc, std::min(eff_batch(nlay), HOST_BATCH));
     if (int rc = ensure_workspace(nlay, nbmax, cloud, false, idrv, mode)) return rc;
     const size_t L = (size_t)nlay, n = (size_t)ncol, nl = (size_t)nloc;
     hipStream_t s = G.stream;
@@ -2988,12 +3205,12 @@ static int mcica_subcol_host_range(
     return read_physics_error(s);
 }
 
-int rrtmg_lw_hip_run_mcica_subcol(
-    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+}   // extern "C"
+// the fused entry behind the lock (the caller holds it): argument checks, the columns over the devices
+static int mcica_subcol_host(int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
     const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
     const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS)
 {
-    ENTRY_LOCK;
     if (int rc = check_mcica_build()) return rc;
     if (!icld) return fail(RRTMG_LW_HIP_EARG, "icld is null");
     if (int rc = check_subcol_args(ncol, nlay, *icld, irng)) return rc;
@@ -3009,6 +3226,34 @@ int rrtmg_lw_hip_run_mcica_subcol(
     // (src/mcica_subcol_gen_lw.f90:497-503): a column's deviates depend on every column before it, so the call stays on the first device
     if (rng != 0 && icld_gen != 0) return range(0, ncol);
     return fan_out(ncol, range);
+}
+extern "C" {
+int rrtmg_lw_hip_run_mcica_subcol(
+    int ncol, int nlay, int *icld, int idrv, int permuteseed, int *irng, GCM_PARAMS, int inflglw, int iceflglw, int liqflglw,
+    const double *cldfr, const double *taucld, const double *cicewp, const double *cliqwp, const double *reice,
+    const double *reliq, const double *alpha, const double *tauaer, OUT_PARAMS)
+{
+    // a small call with the kissvec generator (every column draws from its own stream: src/mcica_subcol_gen_lw.f90:463-474) that finds
+    // another in flight is solved together with it in one pass, like the non-McICA entry (comb_call); the Mersenne Twister - one stream
+    // over the columns of a call - and calls that are wrong on their face take the lock and say so themselves
+    const bool plain = ncol >= 1 && ncol <= comb_max() && comb_enabled() && icld && irng && *irng == 0 && *icld >= 0 && *icld <= 5 && nlay >= 1 && nlay <= 603 &&
+                       uflx && dflx && hr && uflxc && dflxc && hrc && (idrv != 1 || (duflx_dt && duflxc_dt)) &&
+                       play && plev && tlay && tlev && tsfc && h2ovmr && o3vmr && co2vmr && ch4vmr && n2ovmr && o2vmr && cfc11vmr && cfc12vmr && cfc22vmr && ccl4vmr &&
+                       emis && cldfr && taucld && cicewp && cliqwp && reice && reliq && tauaer;
+    if (plain) {
+        CallReq me;
+        me.c = QueuedChunk{ncol, icld,
+                           {play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr, cfc12vmr, cfc22vmr, ccl4vmr, emis,
+                            cldfr, taucld, cicewp, cliqwp, reice, reliq, tauaer, alpha},
+                           {uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt}};
+        me.nlay = nlay; me.icld = *icld; me.idrv = idrv; me.inflg = inflglw; me.iceflg = iceflglw; me.liqflg = liqflglw;
+        me.kind = 1; me.permuteseed = permuteseed;
+        return comb_call(me);
+    }
+    ENTRY_LOCK;
+    return mcica_subcol_host(ncol, nlay, icld, idrv, permuteseed, irng, play, plev, tlay, tlev, tsfc, h2ovmr, o3vmr, co2vmr, ch4vmr, n2ovmr, o2vmr, cfc11vmr,
+                             cfc12vmr, cfc22vmr, ccl4vmr, emis, inflglw, iceflglw, liqflglw, cldfr, taucld, cicewp, cliqwp, reice, reliq, alpha, tauaer,
+                             uflx, dflx, hr, uflxc, dflxc, hrc, duflx_dt, duflxc_dt);
 }
 
 }  // extern "C"

@@ -65,7 +65,7 @@
     defined(RRLW_LAYER_SYNCTHREADS) || defined(RRLW_LAYER_STAMPS) || defined(RRLW_NO_NT) || defined(RRLW_SWEEPC_P0) || defined(RRLW_SWEEPC_P2D) || \
     defined(RRLW_SWEEPC_WAVES_CAP) || defined(RRLW_SWEEPC_QUAD_BARRIER) || defined(RRLW_SWEEPC_CODES) || defined(RRLW_SWEEPC_SPLIT) || defined(RRLW_SWEEPC_SPLIT3) || \
     defined(RRLW_SWEEPC_SPLIT_P1) || defined(RRLW_SWEEPZ_CT_SLOTS) || defined(RRLW_SWEEPZ_G2) || defined(RRLW_SWEEPZ_WAVES_G2) || defined(RRLW_SWEEPZ_WAVES_G1) || \
-    defined(RRLW_SWEEPZ_WAVES_IDRV) || defined(RRLW_GEN_BESIDE_SWEEP) || defined(RRLW_FANOUT_MAX)
+    defined(RRLW_SWEEPZ_WAVES_IDRV) || defined(RRLW_GEN_BESIDE_SWEEP) || defined(RRLW_FANOUT_MAX) || defined(RRLW_KI_SALU)
 #define RRLW_BF_GEOMETRY 16u
 #else
 #define RRLW_BF_GEOMETRY 0u
@@ -162,7 +162,7 @@ struct Workspace {
     // The order in which the batch's columns are taken (k_colsort): position (slot) -> column of the batch, or null = as they come.  Every
     // workspace array above is indexed by SLOT, the caller's arrays by COLUMN (pcol).
     // k_layer's (window, layer) pairs whose cells do not fit the narrow staging window, left by the narrow launch for the wide one:
-    // {count (parity 0), count (parity 1), pair ..}; null: no wide launch follows (every workgroup keeps the narrow window)
+    // {count, unused, pair ..}; null: no wide launch follows (every workgroup keeps the narrow window)
     int *wide;          // [2 + windows * nlay]
     int *perm;          // [ncolb rounded up to whole windows]
     int *wsort;         // [windows] 1: the window's columns are taken in another order than they lie
@@ -1428,7 +1428,6 @@ __device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const 
 struct LayerArgs {
     int ncol, col0, nct, idrv, istart, iend;
     int ktab_bytes;            // size of the packed k-table buffer (buffer descriptor range)
-    int wpar;                  // which of W.wide's two counts this launch pair uses (0 / 1)
     const double *tauaer;      // (nct,nlay,16)
 };
 
@@ -1965,7 +1964,7 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
         // where the workgroup's cells do not fit the narrow window (uniform over the workgroup) and a wide pass follows (W.wide; GCM
         // entry): the (window, layer) goes to its list
         if (W.wide && (s_wg[3] - wg.jp0 > WN::NPL - 2 || s_wg[4] - wg.im0 > WN::MW - 2)) {
-            if (threadIdx.x == 0) W.wide[2 + atomicAdd(&W.wide[a.wpar], 1)] = by * ((a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK) + bx;
+            if (threadIdx.x == 0) W.wide[2 + atomicAdd(&W.wide[0], 1)] = by * ((a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK) + bx;
             return;
         }
     }
@@ -1982,21 +1981,19 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
 }
 
 // WIDE = 0: grid (windows, layers), one workgroup per (window, layer).  WIDE = 1: grid (windows x layers); workgroup i takes pair i of the
-// list the narrow launch left in W.wide = {count of parity 0, of parity 1, pair ..} and leaves at once when there is none (a (window,
-// layer) grid of workgroups that read one word and leave costs ~15 us per 250 000 columns; a fixed grid of workgroups that LOOP over the
-// list spills 151 registers: everything derived from the kernel's arguments stays live round the loop).  The count a launch pair uses
-// is a.wpar's; the narrow launch clears the other one, which the next pair on this workspace set will use (driver.hip: run_layer) - no
-// clearing launch, no ticket.
+// list the narrow launch left in W.wide = {count, -, pair ..} and leaves at once when there is none (a (window, layer) grid of
+// workgroups that read one word and leave costs ~25 us per 250 000 columns; a fixed grid of workgroups that LOOP over the list spills
+// 151 registers: everything derived from the kernel's arguments stays live round the loop).  The count is cleared on the stream in front
+// of the narrow launch (driver.hip: run_layer).
 template <bool GCM, int CLOUD, int WIDE>
 __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTables T, Workspace W, GcmIn g, ColIn c, LayerArgs a)
 {
     __shared__ double2 s_tab[STAGE_DOUBLES / 2];
     __shared__ int s_wg[5];
     if constexpr (WIDE == 0) {
-        if (W.wide && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) W.wide[a.wpar ^ 1] = 0;
         layer_cells<GCM, CLOUD, 0>(T, W, g, c, a, s_tab, s_wg, blockIdx.x, blockIdx.y);
     } else {
-        const int n = __builtin_amdgcn_readfirstlane(W.wide[a.wpar]), gx = (a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK;
+        const int n = __builtin_amdgcn_readfirstlane(W.wide[0]), gx = (a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK;
         if ((int)blockIdx.x >= n) return;
         const int item = __builtin_amdgcn_readfirstlane(W.wide[2 + blockIdx.x]);
         layer_cells<GCM, CLOUD, 1>(T, W, g, c, a, s_tab, s_wg, item % gx, item / gx);
@@ -2725,46 +2722,59 @@ constexpr int SWEEP_LUT_BYTES = 8 * (NTBL + 1) + 8;
 constexpr int SWEEP_PL_BYTES = 2 * 184 * 8, SWEEP_FR_BYTES = 16 * 16 * 8;
 // Loads of the sweeps: wave-uniform base pointer in a buffer descriptor (scalar registers), per-lane 32-bit byte offset that does not
 // change from level to level - no 64-bit vector address arithmetic per load.  nt = streaming (non-temporal) access.
+// soff (round 5): the ROW of the level as a wave-uniform 32-bit byte offset in the instruction's scalar-offset operand.  Until then every
+// load of a level formed its row's 64-bit address (clamp, a signed 64-bit multiply by the row stride, the add, the descriptor's second
+// word: ~14 scalar instructions, ~106 per level and thread in k_sweepz), and the scalar stream is NOT hidden behind the vector one at
+// three waves per SIMD: 100 scalar instructions more per level cost the sweeps 10 % (knock-in, profiles/round5_instruction_diet.md).
+// Now the descriptor is built from the array's start (the compiler keeps it across the level loop) and a level costs the workspace arrays
+// one multiply for the row and a shift per element size; the rows of the caller's arrays, whose column stride is the whole call's column
+// count, keep a 64-bit address, formed from an unsigned 32 x 32 -> 64 bit product (row_ptr).  The driver keeps every row offset below
+// 2^32 bytes (driver.hip: eff_batch).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_rsrc(const void *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
 }
 // a quad record of cell codes (voff = the lane's column x CODE_BYTES), streaming
-__device__ __forceinline__ pk4 bload_pk4_nt(const void *base, unsigned voff)
+__device__ __forceinline__ pk4 bload_pk4_nt(const void *base, unsigned voff, unsigned soff = 0u)
 {
     pk4 r;
     if constexpr (CODE_WORDS == 4) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, 0, 2);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, (int)soff, 2);
         __builtin_memcpy(&r, &v, 16);
     } else if constexpr (CODE_WORDS == 3) {
         typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
-        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(sweep_rsrc(base), (int)voff, 0, 2);
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(sweep_rsrc(base), (int)voff, (int)soff, 2);
         r.w[0] = v[0]; r.w[1] = v[1]; r.w[2] = v[2];
     } else {
         typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-        const u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(sweep_rsrc(base), (int)voff, 0, 2);
+        const u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(sweep_rsrc(base), (int)voff, (int)soff, 2);
         r.w[0] = v[0]; r.w[1] = v[1];
     }
     return r;
 }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double bload_f64(const void *base, unsigned voff)
+__device__ __forceinline__ double bload_f64(const void *base, unsigned voff, unsigned soff = 0u)
 {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(sweep_rsrc(base), (int)voff, 0, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(sweep_rsrc(base), (int)voff, (int)soff, 0);
     double r;
     __builtin_memcpy(&r, &v, 8);
     return r;
 }
-__device__ __forceinline__ double2 bload_f64x2(const void *base, unsigned voff)
+__device__ __forceinline__ double2 bload_f64x2(const void *base, unsigned voff, unsigned soff = 0u)
 {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(base), (int)voff, (int)soff, 0);
     double2 r;
     __builtin_memcpy(&r, &v, 16);
     return r;
 }
-__device__ __forceinline__ unsigned bload_u32(const void *base, unsigned voff)
+__device__ __forceinline__ unsigned bload_u32(const void *base, unsigned voff, unsigned soff = 0u)
 {
-    return __builtin_amdgcn_raw_buffer_load_b32(sweep_rsrc(base), (int)voff, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b32(sweep_rsrc(base), (int)voff, (int)soff, 0);
+}
+// row `r` of a caller's (column-fastest) array whose rows lie `stride` doubles apart: a 64-bit address from an unsigned 32 x 32 product
+__device__ __forceinline__ const double *row_ptr(const double *base, unsigned r, unsigned stride)
+{
+    return base + (unsigned long long)r * (unsigned long long)stride;
 }
 
 __device__ __forceinline__ void bstore_f64(void *base, unsigned voff, double v)
@@ -2779,6 +2789,18 @@ __device__ __forceinline__ void bstore_f64x2(void *base, unsigned voff, double v
     u32x4 x;
     __builtin_memcpy(&x, t, 16);
     __builtin_amdgcn_raw_buffer_store_b128(x, sweep_rsrc(base), (int)voff, 0, 0);
+}
+
+// Knock-IN (measurement, -DRRLW_KI_SALU=n): n more scalar instructions per level and thread in the sweeps, a dependent chain like the
+// address arithmetic of the level's loads - what the scalar stream costs is what adding to it costs (profiles/round5_instruction_diet.md).
+__device__ __forceinline__ void ki_salu(int &x)
+{
+#ifdef RRLW_KI_SALU
+#pragma unroll
+    for (int i = 0; i < RRLW_KI_SALU; i++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(x));
+#else
+    (void)x;
+#endif
 }
 
 // table index of a cell's code (0 for the series branch: entry 0 is {1 - exp = 0, tfn = 0})
@@ -3063,15 +3085,29 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
 
     // loads of layer `lev` (any integer: rows outside 1 .. nlay are clamped, their values never used); zoff selects the interface whose
     // temperature the sweep direction needs: 0 = level lev - 1 (below the layer, downward sweep), 1 = level lev (above, upward sweep)
+    // (rows as scalar offsets - bload_*'s soff - in the two-stream phases, which are bound by instruction issue: -1.5 %.  The downward
+    // phase above the clouds streams at the memory pipeline's rate and lives by WHERE its code loads sit in the level body; with the
+    // lighter address arithmetic the scheduler gathers them at the end of the body, the prefetch distance shrinks and the phase takes 3 %
+    // longer (profiles/round5_instruction_diet.md): it keeps the row addresses it had.)
+    constexpr bool SOFF = PHASE != 1;
+    const unsigned ncb32 = (unsigned)ncb, tstr32 = (unsigned)tstride;
     auto fill_t = [&](auto bin_tag, int lev, int zoff, SweepcLev<G> &q) {
         const int l = min(max(lev, 1), nlay);
-        q.tl = bload_f64(tlay + tstride * (l - 1), off8p);
-        q.tz = bload_f64(tlev + tstride * (l - 1 + zoff), off8p);
-        if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
+        if constexpr (SOFF) {
+            const unsigned r = (unsigned)(l - 1);
+            q.tl = bload_f64(row_ptr(tlay, r, tstr32), off8p);
+            q.tz = bload_f64(row_ptr(tlev, r + (unsigned)zoff, tstr32), off8p);
+            if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw, off4, r * ncb32 * 4u);
+        } else {
+            q.tl = bload_f64(tlay + tstride * (l - 1), off8p);
+            q.tz = bload_f64(tlev + tstride * (l - 1 + zoff), off8p);
+            if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
+        }
     };
     auto ld_c = [&](int lev, int k) -> pk4 {
         const int l = min(max(lev, 1), nlay);
-        return bload_pk4_nt(sC + ((size_t)k * qstride + (size_t)(l - 1) * ncb) * CODE_WORDS, offc);
+        if constexpr (SOFF) return bload_pk4_nt(sC + (size_t)k * qstride * CODE_WORDS, offc, (unsigned)(l - 1) * ncb32 * (unsigned)CODE_BYTES);
+        else return bload_pk4_nt(sC + ((size_t)k * qstride + (size_t)(l - 1) * ncb) * CODE_WORDS, offc);
     };
     // fraction rows of layer `lev`: first row and interpolation weight (taumol :556-561, :692-693)
     auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
@@ -3139,9 +3175,11 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     SweepcLev<G> cur;
     cur.w = 0u;
     pk4 cc[G][NC];
+    int ki = 0;
     auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) {
         constexpr bool BIN = decltype(bin_tag)::value, DN = decltype(dn_tag)::value;
         constexpr int dir = DN ? -1 : 1;
+        ki_salu(ki);
         double fpl;
         const double *row = frac_row(lev, cur.w, fpl);
         const double blay = planck_at(tp0, tp0, cur.tl);
@@ -3402,17 +3440,20 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     auto clampl = [&](int lev) { return min(max(lev, 1), nlay); };
     // the level's own inputs, one level ahead; zoff: 0 = interface below the layer (downward), 1 = above (upward)
     // (LITE: a level below the group's lowest cloud - no column of the workgroup is cloudy there: its cloud fraction and flag word are not read)
+    const unsigned ncb32 = (unsigned)ncb, tstr32 = (unsigned)tstride;
     auto fill_t = [&](auto bin_tag, auto lite_tag, int lev, int zoff, SweepzLev &q) {
-        const int l = clampl(lev);
-        q.tl = bload_f64(tlay + tstride * (l - 1), off8);
-        q.tz = bload_f64(tlev + tstride * (l - 1 + zoff), off8);
+        const unsigned r = (unsigned)(clampl(lev) - 1);
+        q.tl = bload_f64(row_ptr(tlay, r, tstr32), off8);
+        q.tz = bload_f64(row_ptr(tlev, r + (unsigned)zoff, tstr32), off8);
         if constexpr (!decltype(lite_tag)::value) {
-            q.cf = bload_f64(cldf + tstride * (l - 1), off8);
-            q.flag = bload_u32(sFlag + (size_t)l * ncb, off4);
+            q.cf = bload_f64(row_ptr(cldf, r, tstr32), off8);
+            q.flag = bload_u32(sFlag, off4, (r + 1u) * ncb32 * 4u);
         }
-        if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw + (size_t)(l - 1) * ncb, off4);
+        if constexpr (decltype(bin_tag)::value) q.w = bload_u32(sFw, off4, r * ncb32 * 4u);
     };
-    auto ld_c = [&](const unsigned *base, int lev, int k) -> pk4 { return bload_pk4_nt(base + ((size_t)k * qstride + (size_t)(clampl(lev) - 1) * ncb) * CODE_WORDS, offc); };
+    auto ld_c = [&](const unsigned *base, int lev, int k) -> pk4 {
+        return bload_pk4_nt(base + (size_t)k * qstride * CODE_WORDS, offc, (unsigned)(clampl(lev) - 1) * ncb32 * (unsigned)CODE_BYTES);
+    };
     auto frac_row = [&](int lev, unsigned fwv, double &fpl) -> const double * {
         const bool lower = lev <= laytrop;
         if (any_bin) {          // uniform
@@ -3492,24 +3533,28 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     pk4 cc[G][NC], ct[G][NCT];
     // One level.  DN: downward (Planck difference towards the interface below, partial of level lev - 1, istcldd = flag bit 1), else
     // upward (istcld = bit 2).  The overlap factors of the level are requested first and used last.
+    int ki = 0;
     auto level = [&](auto bin_tag, auto dn_tag, int lev, int slot) __attribute__((always_inline)) {
         constexpr bool BIN = decltype(bin_tag)::value, DN = decltype(dn_tag)::value;
         constexpr int dir = DN ? -1 : 1;
+        ki_salu(ki);
         double2 f0 = make_double2(0., 0.), f1 = f0, f2 = f0;
         double efcl = 0.0;
         unsigned mlo = 0u, mhi = 0u;
         float4 cf4[G], ef4[G];
         if constexpr (MODE == 2) {
-            const double2 *ov = W.ovl + ((size_t)((DN ? 0 : nlay + 1) + clampl(lev)) * 3) * ncb;
-            f0 = bload_f64x2(ov, off16); f1 = bload_f64x2(ov + ncb, off16); f2 = bload_f64x2(ov + 2 * ncb, off16);
+            const double2 *ov = W.ovl + (size_t)(DN ? 0 : nlay + 1) * 3 * ncb;            // (the direction's half: uniform, fixed)
+            const unsigned so = (unsigned)clampl(lev) * 3u * ncb32 * 16u;
+            f0 = bload_f64x2(ov, off16, so); f1 = bload_f64x2(ov, off16, so + ncb32 * 16u); f2 = bload_f64x2(ov, off16, so + ncb32 * 32u);
         } else {
-            if constexpr (MODE != 3) efcl = bload_f64(W.efcl + ((size_t)(B - 1) * nlay + (clampl(lev) - 1)) * ncb, off8);
+            if constexpr (MODE != 3) efcl = bload_f64(W.efcl + (size_t)(B - 1) * nlay * ncb, off8, (unsigned)(clampl(lev) - 1) * ncb32 * 8u);
             if constexpr (MODE == 3) {              // cloud fraction (0 / 1) and effective emissivity per g-point: 8 floats per quad
 #pragma unroll
                 for (int k = 0; k < G; k++) {
-                    const float *pc = W.cfef + ((size_t)(quad + k) * nlay + (clampl(lev) - 1)) * ncb * 8;
-                    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(pc), (int)((unsigned)colc * 32u), 0, 0);
-                    const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(pc), (int)((unsigned)colc * 32u + 16u), 0, 0);
+                    const float *pc = W.cfef + (size_t)(quad + k) * nlay * ncb * 8;
+                    const unsigned so = (unsigned)(clampl(lev) - 1) * ncb32 * 32u;
+                    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(pc), (int)((unsigned)colc * 32u), (int)so, 0);
+                    const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(sweep_rsrc(pc), (int)((unsigned)colc * 32u + 16u), (int)so, 0);
                     __builtin_memcpy(&cf4[k], &c, 16);
                     __builtin_memcpy(&ef4[k], &e, 16);
                 }

@@ -423,3 +423,94 @@ def test_column_mode_mcica_samples(hip, oracle):
             d = np.abs(got[key][k] - ref[key]).max()
             assert d <= tol and d <= TIGHT_FLUX, (ims, key, d)
     assert np.ptp(got["totdflux"][:, 0]) > 1.0          # the samples differ: different sub-columns
+
+
+def test_concurrent_fused_mcica_callers_are_combined(hip):
+    """The fused sub-column generator + McICA entry from several threads at once, in chunks of a few columns (an OpenMP host model): calls
+    with the kissvec generator that arrive while another is in flight are solved together in one device pass (driver.hip: comb_call, kind
+    1) - every column draws from its own stream (src/mcica_subcol_gen_lw.f90:463-474), so a chunk's fluxes equal those of the same columns
+    in one big call bit for bit; a chunk with a physics error fails alone with ITS text; calls with another permuteseed are not mixed in;
+    the Mersenne Twister (one stream per call) keeps to the lock and gives what a lone call gives."""
+    import threading
+    ncol, nlay, chunk, icld = 768, 40, 32, 2
+    d = make_gcm_inputs(ncol, nlay, "cloudy", col0=300)
+    whole = hip.rrtmg_lw_mcica_subcol_from_dict(d, 13, 0, icld=icld)
+    whole7 = hip.rrtmg_lw_mcica_subcol_from_dict(d, 7, 0, icld=icld)
+    keys = [k for k, v in d.items() if isinstance(v, np.ndarray)]
+
+    def part(c0, c1):
+        p = dict(d)
+        p["ncol"] = c1 - c0
+        for k in keys:
+            v = d[k]
+            if v.ndim == 1:
+                p[k] = np.ascontiguousarray(v[c0:c1])
+            elif k == "taucld":
+                p[k] = np.asfortranarray(v[:, c0:c1, :])
+            else:
+                p[k] = np.asfortranarray(v[c0:c1])
+        return p
+
+    chunks = [part(c0, min(ncol, c0 + chunk)) for c0 in range(0, ncol, chunk)]
+    bad = 5
+    r = np.array(chunks[bad]["reliq"]); r[3, 8] = 1.0
+    chunks[bad]["reliq"] = np.asfortranarray(r)
+    for k, v in (("cldfr", 0.5), ("cliqwp", 10.0)):
+        a = np.array(chunks[bad][k]); a[3, 8] = v; chunks[bad][k] = np.asfortranarray(a)
+    nthreads = 6
+    results, errors = [None] * len(chunks), [None] * len(chunks)
+    seeds = [7 if i % 5 == 0 else 13 for i in range(len(chunks))]
+
+    def worker(t):
+        for rep in range(2):
+            for i in range(t, len(chunks), nthreads):
+                try:
+                    results[i] = hip.rrtmg_lw_mcica_subcol_from_dict(chunks[i], seeds[i], 0, icld=icld)
+                except hip.RrtmgLwError as e:
+                    errors[i] = str(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for i, c0 in enumerate(range(0, ncol, chunk)):
+        if i == bad:
+            assert errors[i] and "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS" in errors[i]
+            continue
+        assert errors[i] is None, (i, errors[i])
+        ref = whole7 if seeds[i] == 7 else whole
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+            assert np.array_equal(results[i][k], ref[k][c0:c0 + chunk]), (i, k)
+    # combined for certain: one large call holds the turn while ten small ones arrive (three attempts on a loaded machine)
+    big = part(0, ncol)
+    small = [c for i, c in enumerate(chunks[6:18])][:10]
+    combined = False
+    for attempt in range(3):
+        c0_, p0_ = hip.combine_stats()
+        started = threading.Event()
+
+        def lead():
+            started.set()
+            hip.rrtmg_lw_mcica_subcol_from_dict(big, 13, 0, icld=icld)
+
+        def follow(c):
+            started.wait()
+            hip.rrtmg_lw_mcica_subcol_from_dict(c, 13, 0, icld=icld)
+
+        th = [threading.Thread(target=lead)] + [threading.Thread(target=follow, args=(c,)) for c in small]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        c1_, p1_ = hip.combine_stats()
+        print(f"  fused McICA: {c1_ - c0_} calls in {p1_ - p0_} passes")
+        if p1_ - p0_ < c1_ - c0_:
+            combined = True
+            break
+    assert combined
+    # the Mersenne Twister keeps to the lock: a chunk alone, whatever else is going on, gives what it gives alone
+    mt1 = hip.rrtmg_lw_mcica_subcol_from_dict(chunks[2], 13, 1, icld=icld)
+    mt2 = hip.rrtmg_lw_mcica_subcol_from_dict(chunks[2], 13, 1, icld=icld)
+    for k in ("uflx", "dflx", "hr"):
+        assert np.array_equal(mt1[k], mt2[k]), k

@@ -212,6 +212,68 @@ def test_device_entry_with_caller_stream(hip, oracle):
     _compare(got, ref, dn["idrv"], "device entry, 6 batches")
 
 
+@pytest.mark.parametrize("config,ncol,nlay", [("cloudy", 1000, 72), ("clear", 3000, 40), ("aer_idrv", 700, 60)])
+def test_small_calls_replayed_as_a_graph(hip, oracle, config, ncol, nlay):
+    """A device-resident call of one batch is captured as a graph the second time it comes with the same arguments and replayed from then on
+    (rrtmg_lw_hip_set_graph_max; driver.hip: run_pipelined): the outputs equal those of the plain launches bit for bit, a call with another
+    output array gets a graph of its own, a larger call in between (the workspace grows: every graph is dropped) does no harm, and new
+    input VALUES in the same arrays are what the replay computes with."""
+    import torch
+    from rrtmg_lw_amd.shard import output_rows, output_views
+    dev = torch.device("cuda", 0)
+    d = make_gcm_inputs(ncol, nlay, config, col0=77, backend="torch", device=dev)
+    idrv = d["idrv"]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(n, buf):
+        o = output_views(buf, nlay, idrv)
+        for _ in range(n):
+            hip.rrtmg_lw_device(d, o, stream=stream)
+        hip.check(stream)
+        return buf.clone()
+
+    bufs = [torch.zeros((output_rows(nlay, idrv), ncol), dtype=torch.float64, device=dev) for _ in range(2)]
+    prev = hip.set_graph_max(0)
+    try:
+        plain = run(2, bufs[0])
+        hip.set_graph_max(1 << 20)
+        c0, r0 = hip.graph_stats()
+        got = run(5, bufs[0])                               # plain, captured, replayed x 3
+        c1, r1 = hip.graph_stats()
+        assert (c1 - c0, r1 - r0) == (1, 3)
+        assert torch.equal(got.view(torch.int64), plain.view(torch.int64))
+        got2 = run(3, bufs[1])                              # another output array: another key
+        c2, r2 = hip.graph_stats()
+        assert (c2 - c1, r2 - r1) == (1, 1)
+        assert torch.equal(got2.view(torch.int64), plain.view(torch.int64))
+        # new values in the same input arrays: the replay reads the arrays, not a copy
+        tlay0 = d["tlay"].clone()
+        d["tlay"] += 1.5
+        warm = run(2, bufs[0])
+        c3, r3 = hip.graph_stats()
+        assert (c3 - c2, r3 - r2) == (0, 2)
+        hip.set_graph_max(0)
+        assert torch.equal(run(1, bufs[0]).view(torch.int64), warm.view(torch.int64))
+        assert not torch.equal(warm, plain)
+        d["tlay"].copy_(tlay0)
+        # a larger call makes the workspace grow: the graphs go, the next small call starts over and still agrees
+        hip.set_graph_max(1 << 20)
+        big = make_gcm_inputs(4 * ncol + 333, nlay, config, col0=5, backend="torch", device=dev)
+        bigbuf = torch.zeros((output_rows(nlay, idrv), 4 * ncol + 333), dtype=torch.float64, device=dev)
+        hip.rrtmg_lw_device(big, output_views(bigbuf, nlay, idrv), stream=stream)
+        hip.check(stream)
+        again = run(4, bufs[0])
+        assert torch.equal(again.view(torch.int64), plain.view(torch.int64))
+    finally:
+        hip.set_graph_max(prev)
+    dn = make_gcm_inputs(ncol, nlay, config, col0=77)
+    ref = oracle.rrtmg_lw(ncol, nlay, dn["icld"], idrv, dn)
+    o = output_views(plain, nlay, idrv)
+    gotd = {k: o[k].T.cpu().numpy() for k in o}
+    gotd["icld"] = ref["icld"]
+    _compare(gotd, ref, idrv, f"graph {config}")
+
+
 def test_calls_from_several_threads(hip, oracle):
     """Concurrent callers get correct results (SURVEY.md 8b threading): calls of up to 8192 columns that arrive while another is in flight
     are solved together in one device pass (driver.hip: comb_call), larger ones and the other entries take turns at the entry lock."""
@@ -573,6 +635,73 @@ def test_several_devices_from_one_process(hip, oracle):
         assert np.array_equal(one_small[k], three_small[k]), k
         assert np.array_equal(one_mc[k], three_mc[k]), k
     _compare(three, oracle.rrtmg_lw(ncol, nlay, 2, 1, d), 1, "three virtual devices")
+
+
+def test_device_entries_run_on_the_state_of_their_arrays(hip, oracle):
+    """After rrtmg_lw_hip_init_devices the device-pointer entries pick the library state of the device their arrays live on
+    (hipPointerGetAttributes).  One GPU is reachable here, so the three states are virtual devices on GPU 0, which take such calls in turn:
+    three calls run on three different states (each with its own workspace, streams and tables) and give the one-device call's numbers bit
+    for bit - non-McICA with d/dT over several batches, and the fused sub-column generator + McICA solver; a physics error raised on a
+    state other than the first reaches rrtmg_lw_hip_check."""
+    import torch
+    from rrtmg_lw_amd.shard import output_rows, output_views
+    dev = torch.device("cuda", 0)
+    ncol, nlay = 900, 45
+    d = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=21, backend="torch", device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def solve(mc):
+        buf = torch.zeros((output_rows(nlay, d["idrv"]), ncol), dtype=torch.float64, device=dev)
+        o = output_views(buf, nlay, d["idrv"])
+        if mc:
+            hip.rrtmg_lw_mcica_subcol_device(d, o, 5, 0, icld=3, stream=stream)
+        else:
+            hip.rrtmg_lw_device(d, o, stream=stream)
+        hip.check(stream)
+        return buf.clone(), hip.last_device_state()
+
+    one, st = solve(False)
+    one_mc, _ = solve(True)
+    assert st == 0
+    prev_graph = hip.set_graph_max(0)
+    try:
+        hip.init_devices([0, 0, 0], kdata=hip.STANDIN_KDATA)
+        hip.set_batch(256)
+        seen = set()
+        for _ in range(3):
+            got, st = solve(False)
+            seen.add(st)
+            assert torch.equal(got.view(torch.int64), one.view(torch.int64))
+        assert seen == {0, 1, 2}
+        seen = set()
+        for _ in range(3):
+            got, st = solve(True)
+            seen.add(st)
+            assert torch.equal(got.view(torch.int64), one_mc.view(torch.int64))
+        assert seen == {0, 1, 2}
+        # an error on whichever state takes the call is found by check()
+        bad = dict(d)
+        r = d["reice"].clone(); r[800, 8] = 500.0
+        bad["reice"] = r
+        for k, v in (("cldfr", 0.5), ("cicewp", 10.0)):
+            a = d[k].clone(); a[800, 8] = v; bad[k] = a
+        for _ in range(2):
+            buf = torch.zeros((output_rows(nlay, d["idrv"]), ncol), dtype=torch.float64, device=dev)
+            hip.rrtmg_lw_device(bad, output_views(buf, nlay, d["idrv"]), stream=stream)
+            with pytest.raises(hip.RrtmgLwError, match="ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS"):
+                hip.check(stream)
+        got, _ = solve(False)
+        assert torch.equal(got.view(torch.int64), one.view(torch.int64))
+    finally:
+        hip.rrtmg_lw_ini(1004.0, kdata=hip.STANDIN_KDATA, device=0)
+        hip.set_batch(0)
+        hip.set_graph_max(prev_graph)
+    dn = make_gcm_inputs(ncol, nlay, "aer_idrv", col0=21)
+    ref = oracle.rrtmg_lw(ncol, nlay, dn["icld"], dn["idrv"], dn)
+    o = output_views(one, nlay, dn["idrv"])
+    gotd = {k: o[k].T.cpu().numpy() for k in o}
+    gotd["icld"] = ref["icld"]
+    _compare(gotd, ref, dn["idrv"], "device entries by pointer")
 
 
 @pytest.mark.parametrize("icld,idrv,ncol", [(2, 1, 70), (0, 0, 65), (1, 0, 64)])
