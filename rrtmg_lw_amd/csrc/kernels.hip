@@ -1834,6 +1834,38 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
     const double amd = 28.9660, amw = 18.0160, avogad = 6.02214199e+23, grav = 9.8066;
     const double stpfac = 296. / 1013.;
 
+    // The narrow launch decides FIRST whether the workgroup's cells fit its window - from the layer's pressures and temperatures alone -
+    // and a workgroup that leaves for the wide launch has then read two of its fifteen input rows and computed nothing else (on a
+    // terrain-following grid nine workgroups in ten leave: profiles/round5_orography.md).  The others go on as before; what they have found
+    // of the window stays in s_wg.
+    bool early = false;
+    if constexpr (WIDE == 0 && GCM && HAVE_WIDE) {
+        if (W.wide) {           // (uniform)
+            early = true;
+            const size_t ro = (size_t)a.col0 + (size_t)nct * (lay - 1);
+            const double pe = col_load(g.play + ro, (unsigned)pc * 8u), te = col_load(g.tlay + ro, (unsigned)pc * 8u);
+            const int jpe = clampi((int)(36. - 5 * (log(pe) + 0.04)), 1, 58);
+            const int ime = min(18, max(1, (int)fdiv(te - 180.8, 7.2)));
+            const bool lowe = lay <= W.laytrop[col];
+            if (threadIdx.x == 0) { s_wg[0] = lowe ? 1 : 0; s_wg[1] = 99; s_wg[2] = 99; s_wg[3] = 0; s_wg[4] = 0; }
+            __syncthreads();
+            const bool in = lowe == (s_wg[0] != 0);
+            int jlo = in ? jpe : 99, ilo = in ? ime : 99, jhi = in ? jpe : 0, ihi = in ? ime : 0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                jlo = min(jlo, __shfl_xor(jlo, o, 64)); ilo = min(ilo, __shfl_xor(ilo, o, 64));
+                jhi = max(jhi, __shfl_xor(jhi, o, 64)); ihi = max(ihi, __shfl_xor(ihi, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0) { atomicMin(&s_wg[1], jlo); atomicMin(&s_wg[2], ilo); atomicMax(&s_wg[3], jhi); atomicMax(&s_wg[4], ihi); }
+            __syncthreads();
+            const int jp0 = s_wg[1], im0 = min(s_wg[2], 20 - WinNarrow::MW);
+            if (s_wg[3] - jp0 > WinNarrow::NPL - 2 || s_wg[4] - im0 > WinNarrow::MW - 2) {
+                if (threadIdx.x == 0) W.wide[2 + atomicAdd(&W.wide[0], 1)] = by * ((a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK) + bx;
+                return;
+            }
+        }
+    }
+
     double pavel, tavel, coldry, wbrodl, w1, w2, w3, w4, w5, w6, w7;
     LayerCoef C;
     if (GCM) {
@@ -1940,13 +1972,15 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
 #endif
     // staging window of the workgroup: the region of its first thread, the smallest jp and the smallest indminor among the cells of that region
     for (int i = threadIdx.x; i < NRATCHI; i += LAYER_BLOCK) s_ratchi[i] = S[T.sl.rat + i];
-    if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; s_wg[2] = 99; s_wg[3] = 0; s_wg[4] = 0; }
-    __syncthreads();
+    if (!early) {
+        if (threadIdx.x == 0) { s_wg[0] = lower ? 1 : 0; s_wg[1] = 99; s_wg[2] = 99; s_wg[3] = 0; s_wg[4] = 0; }
+        __syncthreads();
+    }
     LayerWg wg;
     wg.lds = s_tab; wg.tid = threadIdx.x; wg.nth = blockDim.x; wg.pc = pc;
     wg.lower = s_wg[0] != 0;
     // (one wave-level reduction per quantity, then one LDS atomic per wave: 256 atomics on one address serialise)
-    {
+    if (!early) {
         const bool in = lower == wg.lower;
         int jlo = in ? jp : 99, ilo = in ? indminor : 99, jhi = in ? jp : 0, ihi = in ? indminor : 0;
 #pragma unroll
@@ -1960,14 +1994,6 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
     wg.jp0 = s_wg[1];
     using WN = std::conditional_t<WIDE != 0, WinWide, WinNarrow>;
     wg.im0 = min(s_wg[2], 20 - WN::MW);                     // (the window ends with the table's last slice at the latest)
-    if constexpr (WIDE == 0 && HAVE_WIDE) {
-        // where the workgroup's cells do not fit the narrow window (uniform over the workgroup) and a wide pass follows (W.wide; GCM
-        // entry): the (window, layer) goes to its list
-        if (W.wide && (s_wg[3] - wg.jp0 > WN::NPL - 2 || s_wg[4] - wg.im0 > WN::MW - 2)) {
-            if (threadIdx.x == 0) W.wide[2 + atomicAdd(&W.wide[0], 1)] = by * ((a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK) + bx;
-            return;
-        }
-    }
     wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= (unsigned)(WN::NPL - 2) && (unsigned)(indminor - wg.im0) <= (unsigned)(WN::MW - 2);
     STAMP(5);                       // set-up of the workgroup's staging window
     passes_run<CLOUD, WN>(static_cast<std::conditional_t<WIDE != 0, LayerPassesWide, LayerPasses> *>(nullptr), T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
