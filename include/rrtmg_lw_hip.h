@@ -263,6 +263,11 @@ int rrtmg_lw_hip_cu_partition(void);
  * above the clouds).  Batches of up to `ncol` columns (default 4096; RRTMG_LW_ONE_SWEEP_MAX) take ONE sweep launch per band group instead:
  * the cloud-zone kernel walks all levels.  0 = never.  Results do not depend on it (bit for bit).  Returns the previous value. */
 int rrtmg_lw_hip_set_one_sweep_max(int ncol);
+/* ... and its sweeps put twelve waves on each of a few CUs: 1 024 columns are 16 blocks of 64, i.e. 16 workgroups per group of bands.
+ * Batches of up to `ncol` columns (default 768: sixteen bands x twelve blocks still find a CU each; RRTMG_LW_SPLIT_MAX) are swept ONE band
+ * per workgroup instead - one to four waves - and leave a flux partial per band; k_flux adds the bands of a group first, in the order the group's workgroup adds them,
+ * so the results do not depend on it (bit for bit).  0 = never.  Returns the previous value. */
+int rrtmg_lw_hip_set_split_max(int ncol);
 /* A device-resident call of one batch that does not fill the chip is a chain of a dozen dependent launches on four streams.  The second
  * call with the same arguments (shape, flags, every array pointer - a host model hands over the same arrays step after step) is
  * captured as a graph, later ones are ONE hipGraphLaunch on the caller's stream (up to 8 graphs are kept).  Calls of up to `ncol`

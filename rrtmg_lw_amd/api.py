@@ -182,6 +182,11 @@ def set_one_sweep_max(ncol):
     return int(lib().rrtmg_lw_hip_set_one_sweep_max(C.c_int(int(ncol))))
 
 
+def set_split_max(ncol):
+    """batches of up to `ncol` columns are swept one band per workgroup (rrtmg_lw_hip_set_split_max; 0 = never); returns the previous value"""
+    return int(lib().rrtmg_lw_hip_set_split_max(C.c_int(int(ncol))))
+
+
 def set_graph_max(ncol):
     """device-resident one-batch calls of up to `ncol` columns are replayed as one graph (rrtmg_lw_hip_set_graph_max; 0 = never); returns the previous value"""
     return int(lib().rrtmg_lw_hip_set_graph_max(C.c_int(int(ncol))))

@@ -57,6 +57,8 @@ struct State {
     int ws_nlay = 0, ws_ncolb = 0;
     bool ws_cloud = false, ws_mc = false, ws_gdp = false, ws_efcl = false, ws_ovl = false;
     int ws_groups = 0;
+    size_t ws_slabcols = 0;      // capacity of each partial slab array (gdn1 ..) in columns x slabs: ws_groups wide slabs, or - a small batch whose bands
+                                 // leave a slab each (split sweeps) - sixteen narrow ones
     int *d_err = nullptr;
     // per-column / cloud-property arrays exist twice: k_colprep + k_cloudscan / k_cloudlay of batch i+1 run on `aux` while batch i is in k_layer/k_sweep
     struct PrepSet { double *percol; int *laytrop, *ncbands; double *odcld, *efcl; int *cflag; int *btop, *order, *hgrp, *hblk, *bbot, *hbot; double2 *ovl; int *perm, *wsort; double *tlayc, *tlevc, *cldfc; int *wide; } prep[2] = {};
@@ -382,14 +384,24 @@ bool make_groups(int mode, int idrv, int istart, int iend, SweepGroups &fg)
 // band groups as the sweeps form (4 without d/dT, up to NGROUP_MAX with), the d/dT slab only for idrv = 1, rtrn's / rtrnmc's emissivity
 // term only for modes 1 and 3, rtrnmr's overlap factors only for mode 2.  mode: 0 clear, 1 rtrn, 2 rtrnmr, 3 rtrnmc; -1 = everything.
 void graphs_clear();      // (the graphs of small calls hold workspace addresses)
+// Batches of up to this many columns are swept ONE band per workgroup (SweepArgs::split; rrtmg_lw_hip_set_split_max / RRTMG_LW_SPLIT_MAX):
+// 1 024 columns are 16 blocks of 64 - as groups of bands 16 workgroups of twelve waves on 16 of the 256 CUs, as single bands 256
+// workgroups of one to four waves on all of them.  A level of a sweep then costs the dependent issue of ONE wave per SIMD instead of
+// three; results bit-identical (k_flux adds a group's bands first).  0 = never.
+// Default 768: sixteen bands x twelve blocks = 192 workgroups, each of which wants a CU to itself (the transmittance table takes half of the
+// LDS) - at 1 024 columns the 256 workgroups no longer all find one at once, some wait for a second round and the gain is gone; at 4 096
+// the rounds make the sweeps 1.6 x slower (profiles/round5_small_calls.md).
+int g_split_max = []() { const char *e = getenv("RRTMG_LW_SPLIT_MAX"); return e ? std::max(0, atoi(e)) : 768; }();
 int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv = 1, int mode = -1)
 {
     SweepGroups fgw;
     int groups = NGROUP_MAX;
     if (mode >= 0 && make_groups(mode, idrv, 1, NBND, fgw)) groups = fgw.n;
     const bool gdp = idrv == 1, efcl = cloud && (mode < 0 || mode == 1 || mode == 3), ovl = cloud && (mode < 0 || mode == 2);
+    // (a batch small enough for the split sweeps - one band per workgroup, a slab per band - needs room for sixteen slabs of its own width)
+    const size_t split_cols = ncolb <= g_split_max ? (size_t)NBND * align_up((size_t)ncolb, 64) : 0;
     if (G.ws_base && G.ws_nlay == nlay && G.ws_ncolb >= ncolb && (G.ws_cloud || !cloud) && (G.ws_mc || !mc) && (G.ws_two_scr || !G.split_sweep) &&
-        G.ws_groups >= groups && (G.ws_gdp || !gdp) && (G.ws_efcl || !efcl) && (G.ws_ovl || !ovl)) return 0;
+        G.ws_groups >= groups && G.ws_slabcols >= split_cols && (G.ws_gdp || !gdp) && (G.ws_efcl || !efcl) && (G.ws_ovl || !ovl)) return 0;
     if (G.ws_base) { HIP_TRY(hipDeviceSynchronize()); graphs_clear(); HIP_TRY(hipFree(G.ws_base)); G.ws_base = nullptr; }
     const bool same = G.ws_nlay == nlay;
     ncolb = std::max(ncolb, same ? G.ws_ncolb : 0);
@@ -398,16 +410,17 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
     const int ng = std::max(groups, G.ws_groups);
     const bool want_gdp = gdp || G.ws_gdp, want_efcl = efcl || G.ws_efcl, want_ovl = ovl || G.ws_ovl;
     const size_t n = (size_t)ncolb, L = (size_t)nlay;
+    const size_t slabcols = std::max((size_t)ng * n, (size_t)NBND * align_up(std::min(n, (size_t)std::max(g_split_max, 0)), 64));
     struct Item { void **p; size_t bytes; };
     Workspace &W = G.W;
     W = Workspace{};
     std::vector<Item> items = {
-        {(void **)&W.gdn1, (size_t)ng * (L + 1) * n * sizeof(double)},
-        {(void **)&W.gup1, (size_t)ng * (L + 1) * n * sizeof(double)},
-        {(void **)&W.gup, (size_t)ng * (L + 1) * n * sizeof(Part2)},
-        {(void **)&W.gdn, (size_t)ng * (L + 1) * n * sizeof(Part2)},
+        {(void **)&W.gdn1, slabcols * (L + 1) * sizeof(double)},
+        {(void **)&W.gup1, slabcols * (L + 1) * sizeof(double)},
+        {(void **)&W.gup, slabcols * (L + 1) * sizeof(Part2)},
+        {(void **)&W.gdn, slabcols * (L + 1) * sizeof(Part2)},
     };
-    if (want_gdp) items.push_back({(void **)&W.gdp, (size_t)ng * (L + 1) * n * sizeof(Part2)});
+    if (want_gdp) items.push_back({(void **)&W.gdp, slabcols * (L + 1) * sizeof(Part2)});
     const bool two_scr = G.split_sweep;
     G.scrset[1] = State::ScrSet{};
     for (int k = 0; k < (two_scr ? 2 : 1); k++) {
@@ -458,6 +471,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
     for (auto &it : items) { *it.p = (char *)G.ws_base + off; off += align_up(it.bytes, 256); }
     for (auto &ps : G.prep) HIP_TRY(hipMemset(ps.wide, 0, 8));         // the count of k_layer's wide-window list (kernels.hip: k_layer)
     W.ncolb = ncolb;
+    W.pcb = ncolb;
     W.nlay = nlay;
     W.err = G.d_err;
     for (int a = 0; a < NSCR; a++) W.scr[a] = G.scrset[0].scr[a];
@@ -474,7 +488,7 @@ int ensure_workspace(int nlay, int ncolb, bool cloud, bool mc = false, int idrv 
     G.ws_cloud = cloud;
     G.ws_mc = mc;
     G.ws_two_scr = two_scr;
-    G.ws_groups = ng; G.ws_gdp = want_gdp; G.ws_efcl = want_efcl; G.ws_ovl = want_ovl;
+    G.ws_groups = ng; G.ws_slabcols = slabcols; G.ws_gdp = want_gdp; G.ws_efcl = want_efcl; G.ws_ovl = want_ovl;
     return 0;
 }
 
@@ -645,9 +659,15 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 
 // vertical part of one batch: the sweep launches and k_flux
 template <bool GCM>
-int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
+int run_sweep(hipStream_t s, const Workspace &Wk_, int nb, int col0, int nct, int nlay, int mode, int idrv, int istart, int iend,
               const GcmIn &g, const ColIn &c, const FluxOut &out, const McIn *mc = nullptr, int sset = 0)
 {
+    Workspace Wk = Wk_;
+    // a batch that does not fill the chip: one band per workgroup, a slab per band (g_split_max, SweepArgs::split) - where the slab arrays hold
+    // sixteen slabs of the batch's width
+    const size_t pcb_split = align_up((size_t)nb, 64);
+    const bool split = nb <= g_split_max && (size_t)NBND * pcb_split <= G.ws_slabcols && pcb_split <= (size_t)Wk.ncolb;
+    Wk.pcb = split ? (int)pcb_split : Wk.ncolb;
     const dim3 block(BLOCK);
     if (int rc = ensure_sweep_attrs()) return rc;
     // The four sweep launches of a batch (bands of 4, 3, 2, 1 quads) are independent.  Each workgroup owns a CU, so a launch ends with
@@ -681,6 +701,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
 #endif
     SweepArgs sa;
     sa.ncol = nb; sa.col0 = col0; sa.nct = nct; sa.idrv = idrv; sa.istart = istart; sa.iend = iend;
+    sa.split = split ? 1 : 0;
     sa.emis = GCM ? g.emis : c.semiss;
     sa.cldfrac = GCM ? g.cldfr : c.cldfrac;
     sa.tlay = GCM ? g.tlay : c.tavel;
@@ -692,15 +713,20 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     // launches never wait for each other's last workgroups.
     SweepGroups fg;
     if (!make_groups(mode, idrv, istart, iend, fg)) return fail(RRTMG_LW_HIP_EARG, "internal: more than %d sweep groups", NGROUP_MAX);
-    if (fg.n > G.ws_groups || (idrv == 1 && !G.ws_gdp)) return fail(RRTMG_LW_HIP_EARG, "internal: workspace holds %d band groups, the call needs %d", G.ws_groups, fg.n);
+    if ((!split && fg.n > G.ws_groups) || (idrv == 1 && !G.ws_gdp)) return fail(RRTMG_LW_HIP_EARG, "internal: workspace holds %d band groups, the call needs %d", G.ws_groups, fg.n);
     const int *gq = fg.gq;
+    // first slab of every group, slabs per group (k_flux)
+    int slab0[NGROUP_MAX];
+    unsigned long long gsz = 0ull;
+    { int sl = 0; for (int g = 0; g < fg.n; g++) { slab0[g] = sl; const int n = split ? fg.nb[g] : 1; gsz |= (unsigned long long)n << (4 * g); sl += n; } }
 #define SWEEPC_I(Q, PH, I)                                                                                           \
     do {                                                                                                             \
         constexpr int nt = sweepc_nt(Q, PH, I);                                                                      \
-        const int nsb = sweepc_nsb(Q, PH, I, sa.nbands);                                                             \
+        const int wnb = split ? 1 : sa.nbands;              /* bands of a workgroup */                               \
+        const int nsb = split ? 1 : sweepc_nsb(Q, PH, I, sa.nbands);                                                 \
         sa.ncb = (nb + 64 * nsb - 1) / (64 * nsb);                                                                   \
-        const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands * nt, nsb);                                         \
-        LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I, nt>), sgrid, sblock, sweepc_lds_bytes(PH, I, sa.nbands, nsb, nt), s, G.D, Wk, sa); \
+        const dim3 sgrid((unsigned)sa.ncb, split ? sa.nbands : 1), sblock(64, wnb * nt, nsb);                        \
+        LAUNCH_LDS("k_sweepc<" #Q "," #PH ">", (k_sweepc<Q, PH, I, nt>), sgrid, sblock, sweepc_lds_bytes(PH, I, wnb, nsb, nt), s, G.D, Wk, sa); \
     } while (0)
 #ifdef RRLW_TUNE
 #define SWEEPC(Q, PH) do { if (idrv == 1) return fail(RRTMG_LW_HIP_EARG, "tuning build: idrv = 0 only"); else SWEEPC_I(Q, PH, false); } while (0)
@@ -715,15 +741,16 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
                 const int nq = gq[g];
                 sa.bands = fg.bands[g];
                 sa.nbands = fg.nb[g];
-                sa.group = g;
+                sa.group = slab0[g];
                 const hipStream_t s = (fan && nq < 4) ? SS.q[3 - nq] : s_main;
 #define SWEEPZ_I(Q, M, I)                                                                                            \
     do {                                                                                                             \
         constexpr int nt = sweepz_nt(Q);                                                                             \
-        const int nsb = sweepz_nsb(Q, sa.nbands, I);                                                                 \
+        const int wnb = split ? 1 : sa.nbands;                                                                       \
+        const int nsb = split ? 1 : sweepz_nsb(Q, sa.nbands, I);                                                     \
         sa.ncb = (nb + 64 * nsb - 1) / (64 * nsb);                                                                   \
-        const dim3 sgrid((unsigned)sa.ncb), sblock(64, sa.nbands * nt, nsb);                                         \
-        LAUNCH_LDS("k_sweepz<" #Q "," #M ">", (k_sweepz<Q, M, I>), sgrid, sblock, sweepz_lds_bytes(sa.nbands, nsb, nt, I), s, G.D, Wk, sa); \
+        const dim3 sgrid((unsigned)sa.ncb, split ? sa.nbands : 1), sblock(64, wnb * nt, nsb);                        \
+        LAUNCH_LDS("k_sweepz<" #Q "," #M ">", (k_sweepz<Q, M, I>), sgrid, sblock, sweepz_lds_bytes(wnb, nsb, nt, I), s, G.D, Wk, sa); \
     } while (0)
 #ifdef RRLW_TUNE
 #define SWEEPZ_M(Q, M) do { if (idrv == 1) return fail(RRTMG_LW_HIP_EARG, "tuning build: idrv = 0 only"); else SWEEPZ_I(Q, M, false); } while (0)
@@ -745,7 +772,7 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
             const int nq = gq[g];
             sa.bands = fg.bands[g];
             sa.nbands = fg.nb[g];
-            sa.group = g;
+            sa.group = slab0[g];
             const hipStream_t s = (fan && nq < 4) ? SS.q[3 - nq] : s_main;
 #ifdef RRLW_TUNE
             if (mode == 0) return fail(RRTMG_LW_HIP_EARG, "tuning build: cloudy calls only");
@@ -768,8 +795,8 @@ int run_sweep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     {
         const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN, (nlay + 1 + FLUX_LV - 1) / FLUX_LV), wblock(COLSORT_WIN, FLUX_TY);
         const double *pz = GCM ? g.plev : c.pz;
-        if (idrv == 1) LAUNCH_LDS("k_flux", (k_flux<true>), wgrid, wblock, FLUX_LDS_BYTES, s, G.D, Wk, out, pz, nb, col0, nct, mode == 0 ? 1 : 0, fg.n);
-        else LAUNCH_LDS("k_flux", (k_flux<false>), wgrid, wblock, FLUX_LDS_BYTES, s, G.D, Wk, out, pz, nb, col0, nct, mode == 0 ? 1 : 0, fg.n);
+        if (idrv == 1) LAUNCH_LDS("k_flux", (k_flux<true>), wgrid, wblock, FLUX_LDS_BYTES, s, G.D, Wk, out, pz, nb, col0, nct, mode == 0 ? 1 : 0, fg.n, gsz);
+        else LAUNCH_LDS("k_flux", (k_flux<false>), wgrid, wblock, FLUX_LDS_BYTES, s, G.D, Wk, out, pz, nb, col0, nct, mode == 0 ? 1 : 0, fg.n, gsz);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(RRTMG_LW_HIP_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -865,7 +892,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         key_put(key, gp);
         // (what else decides which kernels run with which arguments: the workspace, the tuning switches)
         key_put(key, G.ws_base); key_put(key, G.ws_bytes); key_put(key, g_colsort); key_put(key, g_colsort_min); key_put(key, g_one_sweep_max);
-        key_put(key, g_wide_window); key_put(key, G.sweep_fanout); key_put(key, eff_batch(nlay));
+        key_put(key, g_wide_window); key_put(key, G.sweep_fanout); key_put(key, eff_batch(nlay)); key_put(key, g_split_max);
         for (auto &e : G.graphs) if (e.key == key) { gent = &e; break; }
         if (!gent) {
             if (G.graphs.size() >= GRAPH_CACHE) {           // the entry used longest ago makes room
@@ -1875,7 +1902,7 @@ static int init_state(const char *static_tables_path, const char *kdata_path, do
     D.absice0[0] = G.H.absice0[0]; D.absice0[1] = G.H.absice0[1];
     D.abscld1 = G.H.abscld1; D.absliq0 = G.H.absliq0;
     D.heatfac = G.H.heatfac; D.fluxfac = G.H.fluxfac; D.oneminus = G.H.oneminus; D.bpade = G.H.bpade;
-    if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; G.ws_mc = false; G.ws_groups = 0; G.ws_gdp = G.ws_efcl = G.ws_ovl = false; }
+    if (G.ws_base) { (void)hipDeviceSynchronize(); (void)hipFree(G.ws_base); G.ws_base = nullptr; G.ws_nlay = 0; G.ws_ncolb = 0; G.ws_cloud = false; G.ws_mc = false; G.ws_groups = 0; G.ws_slabcols = 0; G.ws_gdp = G.ws_efcl = G.ws_ovl = false; }
     G.device = device;
     G.n1 = false;
     G.init = true;
@@ -2055,6 +2082,16 @@ void rrtmg_lw_hip_graph_stats(long long *captures, long long *replays)
     ENTRY_LOCK;
     if (captures) *captures = g_states[0].graph_captures;
     if (replays) *replays = g_states[0].graph_replays;
+}
+
+// Batches of up to `ncol` columns are swept one band per workgroup (g_split_max); 0 = never.  Results do not depend on it.  Returns the
+// previous value.
+int rrtmg_lw_hip_set_split_max(int ncol)
+{
+    ENTRY_LOCK;
+    const int prev = g_split_max;
+    g_split_max = ncol < 0 ? 0 : ncol;
+    return prev;
 }
 
 // k_layer's second pass with the wide staging window for (window, layer) pairs whose columns lie more than one reference-pressure plane

@@ -36,7 +36,7 @@
 // library whose results differ from the product's (knock-out or numerics variant) unless RRTMG_LW_ALLOW_TUNE_BUILD=1, and a knock-out
 // does not compile outside a tuning build (-DRRLW_TUNE: the benchmark's kernels only).
 // ------------------------------------------------------------------------------------------------
-#if (defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG)) && !defined(RRLW_TUNE)
+#if (defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG) || defined(RRLW_KO_STORES)) && !defined(RRLW_TUNE)
 #error "RRLW_KO_* knock-outs give wrong results: tuning builds (-DRRLW_TUNE) only"
 #endif
 #ifdef RRLW_TUNE
@@ -44,7 +44,7 @@
 #else
 #define RRLW_BF_TUNE 0u
 #endif
-#if defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG)
+#if defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG) || defined(RRLW_KO_STORES)
 #define RRLW_BF_KNOCKOUT 2u
 #else
 #define RRLW_BF_KNOCKOUT 0u
@@ -152,6 +152,9 @@ struct Workspace {
     // batch's highest cloud, both directions of a cloud-free call); gup / gdp {total, clear}: upward above the clouds, d(flux)/dT
     double *gdn1, *gup1;
     Part2 *gup, *gdp, *gdn;     // gdn {total, clear}: downward inside the cloud zone (k_sweepz)
+    // column stride of those slabs: ncolb - or, for a batch too small to fill the chip, whose bands are swept ONE per workgroup and leave a
+    // slab each (SweepArgs::split), the batch's own width (the slabs' memory then holds sixteen narrow slabs instead of four wide ones)
+    int pcb;
     int *err;           // [1] first physics error code
     // McICA (rtrnmc): per-g-point cloud terms, written by k_cloudmc
     double *odg;        // [NQUAD][nlay][ncolb][4]     secdiff(band) * taucmc(g)
@@ -1497,6 +1500,12 @@ __device__ __forceinline__ void scr_store(unsigned *base, size_t cell, const scr
     pk_vec x;
 #pragma unroll
     for (int k = 0; k < CODE_WORDS; k++) x[k] = p.w[k];
+#ifdef RRLW_KO_STORES       // knock-out (timing only, wrong results): the codes are formed - the empty asm keeps every one alive - and not stored
+    (void)base; (void)cell;
+#pragma unroll
+    for (int k = 0; k < CODE_WORDS; k++) asm volatile("" :: "v"(x[k]));
+    return;
+#endif
 #ifdef RRLW_NO_NT
     __builtin_memcpy(base + cell * CODE_WORDS, &x, CODE_BYTES);
 #else
@@ -2730,7 +2739,11 @@ __global__ __launch_bounds__(256) void k_alpha(int ncol, int nlay, int icld, int
 struct SweepArgs {
     unsigned long long bands;  // the group's bands (all with the same number of quads), one nibble (band - 1) each
     int nbands, ncb;           // number of those bands, number of column blocks (= workgroups)
-    int group;                 // index of the group's partial slabs (W.gdn1 ..)
+    int group;                 // index of the group's partial slabs (W.gdn1 ..); split: of its first band's
+    int split;                 // 1: a batch that does not fill the chip - grid.y = the group's bands, ONE band per workgroup (a quarter of the
+                               // waves per CU, four times the CUs: a level's latency is the dependent issue of one wave, not of three), a slab
+                               // per band; k_flux adds the bands of a group first, in the list's order - what the group's workgroup does in LDS
+                               // otherwise - so the fluxes do not depend on it
     int ncol, col0, nct, idrv;
     int istart, iend;          // only bands in [istart, iend] are swept
     const double *emis;        // semiss (nct,16)
@@ -3071,7 +3084,9 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     const int slot = blockIdx.x * nsb + sub;
     const int cblock = PHASE == 0 ? slot : __builtin_amdgcn_readfirstlane(W.order[slot]);
     const int col = cblock * 64 + tx;
-    const int B = (int)((a.bands >> (4 * bi)) & 15ull) + 1;
+    const int bsel = a.split ? (int)blockIdx.y : 0;                             // split: this workgroup's band of the group
+    const unsigned long long bands = a.bands >> (4 * bsel);
+    const int B = (int)((bands >> (4 * bi)) & 15ull) + 1;
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;
     const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B) + part * G);
@@ -3098,7 +3113,8 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
     const double *__restrict__ tlev = moved ? W.tlevc : a.tlev + a.col0;
     const size_t tstride = moved ? ncb : (size_t)nct;
     const unsigned offc = (unsigned)colc * (unsigned)CODE_BYTES, off8p = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
-    const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;        // (uniform: the group's slabs; a lane's column is the 32-bit offset of a buffer store)
+    const size_t pcb = (size_t)W.pcb;
+    const size_t gslab = (size_t)(a.group + bsel) * (nlay + 1) * pcb;        // (uniform: the group's slabs; a lane's column is the 32-bit offset of a buffer store)
     double *__restrict__ gdn1 = W.gdn1 + gslab;
     double *__restrict__ gup1 = W.gup1 + gslab;
     Part2 *__restrict__ gup = W.gup + gslab;
@@ -3173,18 +3189,18 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
                     double pq = r[(unsigned)(q * NT * NC * ncw)];            // (the band's parts in the order one thread adds its quads: pairs first)
                     if constexpr (NT >= 2) pq = pq + r[(unsigned)((q * NT + 1) * NC * ncw)];
                     if constexpr (NT == 3) pq = pq + r[(unsigned)((q * NT + 2) * NC * ncw)];
-                    double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
+                    double v = (pq * 0.5) * T.delwave[(int)((bands >> (4 * q)) & 15ull)];
                     if (deriv) v = v * T.fluxfac;
                     sum = q == 0 ? v : sum + v;
                 }
                 sv[val] = sum;
             }
             if (incol) {
-                if constexpr (DN) bstore_f64(gdn1 + (size_t)lvl * ncb, so8, sv[0]);
+                if constexpr (DN) bstore_f64(gdn1 + (size_t)lvl * pcb, so8, sv[0]);
                 else {
-                    if constexpr (TWO) bstore_f64x2(gup + (size_t)lvl * ncb, so16, sv[0], sv[1]);
-                    else bstore_f64(gup1 + (size_t)lvl * ncb, so8, sv[0]);
-                    if constexpr (IDRV) bstore_f64x2(gdp + (size_t)lvl * ncb, so16, TWO ? sv[2] : sv[1], TWO ? sv[3] : sv[1]);
+                    if constexpr (TWO) bstore_f64x2(gup + (size_t)lvl * pcb, so16, sv[0], sv[1]);
+                    else bstore_f64(gup1 + (size_t)lvl * pcb, so8, sv[0]);
+                    if constexpr (IDRV) bstore_f64x2(gdp + (size_t)lvl * pcb, so16, TWO ? sv[2] : sv[1], TWO ? sv[3] : sv[1]);
                 }
             }
         }
@@ -3295,7 +3311,7 @@ __global__ __launch_bounds__(256 * sweepc_waves(NQ / NT, PHASE, IDRV), sweepc_wa
 
     if constexpr (DOWN) {
         // ------------------------------------------------------------------ downward: layers nlay .. lo
-        if (incol && ty == 0) bstore_f64(gdn1 + (size_t)nlay * ncb, so8, 0.0);
+        if (incol && ty == 0) bstore_f64(gdn1 + (size_t)nlay * pcb, so8, 0.0);
         if (any_bin) sweep(true_type{}, true_type{}); else sweep(false_type{}, true_type{});
     }
     if constexpr (PHASE == 1) {                     // downward radiances at level ltop for k_sweepz
@@ -3421,7 +3437,9 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     double *red = reinterpret_cast<double *>(smem + SWEEP_LUT_BYTES + nb * SWEEPC_BAND_BYTES);      // [2][NVAL][ny][NC][ncw]
     const int cblock = __builtin_amdgcn_readfirstlane(W.order[blockIdx.x * nsb + sub]);       // the wave's 64-column block (see k_sweepc)
     const int col = cblock * 64 + tx;
-    const int B = (int)((a.bands >> (4 * bi)) & 15ull) + 1;
+    const int bsel = a.split ? (int)blockIdx.y : 0;                             // (see k_sweepc)
+    const unsigned long long bands = a.bands >> (4 * bsel);
+    const int B = (int)((bands >> (4 * bi)) & 15ull) + 1;
     const bool incol = col < a.ncol;
     const int colc = incol ? col : a.ncol - 1;
     const int quad = __builtin_amdgcn_readfirstlane(band_qstart(B) + part * G);
@@ -3449,7 +3467,8 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
     const double *__restrict__ cldf = moved ? W.cldfc : a.cldfrac + a.col0;
     const size_t tstride = moved ? ncb : (size_t)nct;
     const unsigned off16 = (unsigned)colc * 16u, offc = (unsigned)colc * (unsigned)CODE_BYTES, off8 = (unsigned)colc * 8u, off4 = (unsigned)colc * 4u;
-    const size_t gslab = (size_t)a.group * (nlay + 1) * ncb;
+    const size_t pcb = (size_t)W.pcb;
+    const size_t gslab = (size_t)(a.group + bsel) * (nlay + 1) * pcb;
     Part2 *__restrict__ gdn = W.gdn + gslab;
     Part2 *__restrict__ gup = W.gup + gslab;
     Part2 *__restrict__ gdp = W.gdp + gslab;
@@ -3516,15 +3535,15 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
                     if constexpr (NT >= 2) pq = pq + r[(unsigned)((q * NT + 1) * NC * ncw)];
                     if constexpr (NT == 3) pq = pq + r[(unsigned)((q * NT + 2) * NC * ncw)];
                     if constexpr (NT == 4) pq = pq + (r[(unsigned)((q * NT + 2) * NC * ncw)] + r[(unsigned)((q * NT + 3) * NC * ncw)]);
-                    double v = (pq * 0.5) * T.delwave[(int)((a.bands >> (4 * q)) & 15ull)];
+                    double v = (pq * 0.5) * T.delwave[(int)((bands >> (4 * q)) & 15ull)];
                     if (val >= 2) v = v * T.fluxfac;
                     sum = q == 0 ? v : sum + v;
                 }
                 sv[val] = sum;
             }
             if (incol) {
-                bstore_f64x2((DN ? gdn : gup) + (size_t)lvl * ncb, so16, sv[0], sv[1]);
-                if constexpr (IDRV && !DN) bstore_f64x2(gdp + (size_t)lvl * ncb, so16, sv[2], sv[3]);
+                bstore_f64x2((DN ? gdn : gup) + (size_t)lvl * pcb, so16, sv[0], sv[1]);
+                if constexpr (IDRV && !DN) bstore_f64x2(gdp + (size_t)lvl * pcb, so16, sv[2], sv[3]);
             }
         }
         bufoff = bufoff ? 0u : NVAL * vstride;
@@ -3543,7 +3562,7 @@ __global__ __launch_bounds__(256 * sweepz_waves(NQ, IDRV), sweepz_waves(NQ, IDRV
         if (ltop == nlay) {         // the zone reaches the top of the column: nothing comes down into it (rtrn :352 radld = 0); with the zone
 #pragma unroll                      // kernel walking all levels (k_blocksort, force_top) no clear-sky launch has written the hand-off array
             for (int j = 0; j < NG; j++) rad[j] = 0.0;
-            if (incol && ty == 0) bstore_f64(W.gdn1 + gslab + (size_t)nlay * ncb, (unsigned)col * 8u, 0.0);      // downward flux at the top level
+            if (incol && ty == 0) bstore_f64(W.gdn1 + gslab + (size_t)nlay * pcb, (unsigned)col * 8u, 0.0);      // downward flux at the top level
         }
 #pragma unroll
         for (int j = 0; j < NG; j++) radc[j] = rad[j];
@@ -4038,8 +4057,8 @@ static_assert(COLSORT_WIN * FLUX_TY <= 1024, "k_flux: a window x FLUX_TY threads
 constexpr int FLUX_LDS_BYTES = (FLUX_LV + 1) * 4 * COLSORT_WIN * 8;       // 72 KB: two workgroups per CU
 template <bool IDRV>
 __global__ __launch_bounds__(COLSORT_WIN * FLUX_TY) void k_flux(DevTables T, Workspace W, FluxOut out, const double *pz, int ncol, int col0, int nct,
-                                                                int clear_from_total, int ngroups)
-{
+                                                                int clear_from_total, int ngroups, unsigned long long gsz)
+{   // gsz: slabs per group, a nibble each (1, or - SweepArgs::split - the group's bands: added first, in their order, like the group's workgroup does)
     constexpr int NV = 4, NL = (FLUX_LV + FLUX_TY) / FLUX_TY;      // values that change places at a time; levels per thread
     extern __shared__ __align__(16) unsigned char smem_f[];
     double (*s_v)[NV][COLSORT_WIN] = reinterpret_cast<double (*)[NV][COLSORT_WIN]>(smem_f);      // [FLUX_LV + 1]
@@ -4061,12 +4080,20 @@ __global__ __launch_bounds__(COLSORT_WIN * FLUX_TY) void k_flux(DevTables T, Wor
         if (lc <= FLUX_LV && son && lev <= nlay) {
             const bool dn1 = clear_from_total || lev >= ltop;
             double u = 0.0, d = 0.0, uc = 0.0, dc = 0.0, du = 0.0, duc = 0.0;
+            const size_t pcb = (size_t)W.pcb;
+            int slab = 0;
             for (int g = 0; g < ngroups; g++) {
-                const size_t go = ((size_t)g * (nlay + 1) + lev) * ncb + slot;
-                Part2 su, sd, sq{0.0, 0.0};
-                if (dn1) { sd.a = W.gdn1[go]; sd.b = sd.a; } else sd = W.gdn[go];
-                if (up1) { su.a = W.gup1[go]; su.b = su.a; } else su = W.gup[go];
-                if constexpr (IDRV) sq = W.gdp[go];
+                const int n = (int)((gsz >> (4 * g)) & 15ull);
+                Part2 su{0.0, 0.0}, sd{0.0, 0.0}, sq{0.0, 0.0};
+                for (int q = 0; q < n; q++, slab++) {
+                    const size_t go = ((size_t)slab * (nlay + 1) + lev) * pcb + slot;
+                    Part2 tu, td, tq{0.0, 0.0};
+                    if (dn1) { td.a = W.gdn1[go]; td.b = td.a; } else td = W.gdn[go];
+                    if (up1) { tu.a = W.gup1[go]; tu.b = tu.a; } else tu = W.gup[go];
+                    if constexpr (IDRV) tq = W.gdp[go];
+                    if (q == 0) { su = tu; sd = td; sq = tq; }
+                    else { su.a = su.a + tu.a; su.b = su.b + tu.b; sd.a = sd.a + td.a; sd.b = sd.b + td.b; sq.a = sq.a + tq.a; sq.b = sq.b + tq.b; }
+                }
                 u = u + su.a; uc = uc + su.b;
                 d = d + sd.a; dc = dc + sd.b;
                 du = du + sq.a; duc = duc + sq.b;

@@ -52,7 +52,10 @@ def test_shipped_libraries_are_built_without_tuning_switches():
             if len(lines) > 1 and lines[1].strip():
                 assert set(re.findall(r"-DRRLW_\w+", lines[1])) == allowed, lines[1]
     k = open(os.path.join(ROOT, "rrtmg_lw_amd", "csrc", "kernels.hip")).read()
-    assert re.search(r"#if \(defined\(RRLW_KO_LDS_UNIFORM\) \|\| defined\(RRLW_KO_HALFG\)\) && !defined\(RRLW_TUNE\)\s*\n#error", k)
+    assert re.search(r"#if \(defined\(RRLW_KO_\w+\)( \|\| defined\(RRLW_KO_\w+\))*\) && !defined\(RRLW_TUNE\)\s*\n#error", k)
+    guard = k[:k.index("#error")]
+    for ko in set(re.findall(r"RRLW_KO_\w+", k)):
+        assert ko in guard, f"{ko} is not fenced"
     d = open(os.path.join(ROOT, "rrtmg_lw_amd", "csrc", "driver.hip")).read()
     assert "RRTMG_LW_ALLOW_TUNE_BUILD" in d and "RRLW_BF_KNOCKOUT | RRLW_BF_NUMERICS" in d
     # every -D switch the sources test for is either a product configuration or named in the build-flags section

@@ -40,9 +40,10 @@ def test_config2_replicated_columns(hip, oracle):
             assert np.abs(got[k][0] - ref[k][0]).max() <= 5e-5
 
 
-@pytest.mark.parametrize("config", ["cloudy"])
+@pytest.mark.parametrize("config", ["cloudy", "cloudy_orography"])
 def test_config3_million_columns(hip, oracle, config):
-    """1e6 synthetic 72-layer cloudy columns, maximum-random overlap, device resident (BASELINE configs[2])."""
+    """1e6 synthetic 72-layer cloudy columns, maximum-random overlap, device resident (BASELINE configs[2]); and the same on a
+    terrain-following pressure grid (k_layer's second launch with the wide staging window takes nine workgroups in ten there)."""
     import torch
     ncol, nlay = 1_000_000, 72
     dev = torch.device("cuda", 0)
@@ -78,6 +79,10 @@ def test_config3_million_columns(hip, oracle, config):
     for c0 in (0, 40_000, 65_536 - 100, 999_000):
         n = 300
         dn = make_gcm_inputs(n, nlay, config, col0=c0)
+        if config == "cloudy_orography":       # (the torch backend's log / interpolation differ from numpy's in the last bits: the call's own columns)
+            for k, v in d.items():
+                if torch.is_tensor(v):
+                    dn[k] = np.asfortranarray((v[:, c0:c0 + n] if k == "taucld" else v[c0:c0 + n]).cpu().numpy())
         alone = hip.rrtmg_lw_from_dict(dn)
         for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
             assert np.array_equal(out[k][:, c0:c0 + n].t().cpu().numpy(), alone[k]), (k, c0)

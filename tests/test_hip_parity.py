@@ -822,6 +822,41 @@ def test_one_sweep_launch_is_transparent(hip, oracle, config, icld, idrv, mcica)
         assert np.array_equal(three[k], one[k]), k
 
 
+@pytest.mark.parametrize("config,icld,idrv,mcica,one", [("cloudy", 2, 0, 0, True), ("cloudy_deep", 1, 1, 0, False), ("aer_idrv", 2, 1, 0, True),
+                                                        ("clear", 0, 0, 0, False), ("clear", 0, 1, 0, False), ("cloudy", 2, 0, 5, True), ("cloudy_scatter", 2, 1, 2, False)])
+def test_one_band_per_workgroup_is_transparent(hip, oracle, config, icld, idrv, mcica, one):
+    """Batches too small to fill the chip are swept one band per workgroup, a flux partial per band (rrtmg_lw_hip_set_split_max); k_flux adds
+    the bands of a group first, in the order the group's workgroup adds them in LDS otherwise: the outputs equal those of the grouped
+    sweeps bit for bit - cloud-free, rtrn / rtrnmr with and without d/dT, the fused McICA entry; with the one sweep launch and with the
+    three; a column count that ends inside a block; and batches of a call that are small enough next to the call's first, larger one."""
+    ncol, nlay = 700 + 37, 72
+    d = make_gcm_inputs(ncol, nlay, config, col0=3)
+
+    def run():
+        if mcica:
+            dz = np.full((ncol, nlay), 400.0)
+            alpha = oracle.get_alpha(ncol, nlay, mcica, 0, 2500.0, dz, np.zeros(ncol), 100, d["cldfr"])
+            return hip.rrtmg_lw_mcica_subcol_from_dict(d, 3, 0, icld=mcica, alpha=alpha, idrv=idrv)
+        return hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+
+    prev_one = hip.set_one_sweep_max((1 << 30) if one else 0)
+    prev = hip.set_split_max(0)
+    try:
+        grouped = run()
+        assert hip.set_split_max(1 << 20) == 0
+        split = run()
+        hip.set_batch(512)                  # two batches: 512 columns, then 225
+        split2 = run()
+    finally:
+        hip.set_batch(0)
+        hip.set_split_max(prev)
+        hip.set_one_sweep_max(prev_one)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if idrv else ()):
+        assert np.array_equal(grouped[k], split[k]), k
+        assert np.array_equal(grouped[k], split2[k]), (k, "two batches")
+    assert np.abs(grouped["uflx"]).max() > 100.0
+
+
 @pytest.mark.parametrize("config,icld,idrv", [("cloudy_scatter", 2, 0), ("cloudy_deep", 2, 0), ("cloudy_deep", 1, 0), ("aer_idrv", 2, 1), ("cloudy", 2, 0)])
 def test_column_order_is_transparent(hip, oracle, config, icld, idrv):
     """k_colsort takes the columns of a cloudy batch by cloud top within windows of 256 where that pays (rrtmg_lw_hip_set_column_sort): the

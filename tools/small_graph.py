@@ -9,6 +9,7 @@ ap.add_argument("--cases", default="cloudy:256,cloudy:1024,cloudy:4096,cloudy:16
 ap.add_argument("--nlay", type=int, default=72)
 ap.add_argument("--reps", type=int, default=200)
 ap.add_argument("--side-stream", action="store_true", help="call on a non-default torch stream instead of the null stream")
+ap.add_argument("--ab", default="graph", choices=["graph", "split"], help="what the two columns compare: plain launches / one graph, or bands in groups / one band per workgroup (both as graphs)")
 args = ap.parse_args()
 import torch
 from rrtmg_lw_amd import api
@@ -18,7 +19,8 @@ dev = torch.device("cuda", 0)
 api.rrtmg_lw_ini(1004.0, kdata=api.REAL_KDATA if os.path.exists(api.REAL_KDATA) else api.STANDIN_KDATA, device=0)
 side = torch.cuda.Stream(device=dev) if args.side_stream else None
 stream = side.cuda_stream if side else torch.cuda.current_stream().cuda_stream
-print("| call | plain launches, ms | one graph, ms | M columns/s (plain / graph) | bit-identical | graphs captured / replays |")
+print("| call | plain launches, ms | one graph, ms | M columns/s (plain / graph) | bit-identical | graphs captured / replays |" if args.ab == "graph" else
+      "| call | bands in groups, ms | one band per workgroup, ms | M columns/s | bit-identical | graphs captured / replays |")
 print("|---|---|---|---|---|---|")
 for case in args.cases.split(","):
     cfg, ncol = case.split(":"); ncol = int(ncol)
@@ -27,7 +29,10 @@ for case in args.cases.split(","):
     res, ms = [], []
     c0, r0 = api.graph_stats()
     for mx in (0, 1 << 20):
-        api.set_graph_max(mx)
+        if args.ab == "graph":
+            api.set_graph_max(mx)
+        else:
+            api.set_split_max(mx)
         buf = torch.zeros((output_rows(args.nlay, idrv), ncol), dtype=torch.float64, device=dev)
         o = output_views(buf, args.nlay, idrv)
         torch.cuda.synchronize()

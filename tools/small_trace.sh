@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 export RRTMG_LW_ALLOW_STANDIN=1
 [ -n "$LIB" ] && export RRTMG_LW_HIP_LIB=$R/$LIB
-rocprofv3 --kernel-trace -d $O/trace -f csv -- python3 tools/small_graph.py --cases $CASE --reps 10 > $O/run.log 2>&1
+rocprofv3 --kernel-trace -d $O/trace -f csv -- python3 tools/small_graph.py --cases $CASE --reps 10 $SMALL_ARGS > $O/run.log 2>&1
 python3 - $O <<'PY'
 import csv, glob, sys
 rows = []
