@@ -36,7 +36,7 @@
 // library whose results differ from the product's (knock-out or numerics variant) unless RRTMG_LW_ALLOW_TUNE_BUILD=1, and a knock-out
 // does not compile outside a tuning build (-DRRLW_TUNE: the benchmark's kernels only).
 // ------------------------------------------------------------------------------------------------
-#if (defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG) || defined(RRLW_KO_STORES)) && !defined(RRLW_TUNE)
+#if (defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG) || defined(RRLW_KO_STORES) || defined(RRLW_KO_HALFSTORE)) && !defined(RRLW_TUNE)
 #error "RRLW_KO_* knock-outs give wrong results: tuning builds (-DRRLW_TUNE) only"
 #endif
 #ifdef RRLW_TUNE
@@ -44,7 +44,7 @@
 #else
 #define RRLW_BF_TUNE 0u
 #endif
-#if defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG) || defined(RRLW_KO_STORES)
+#if defined(RRLW_KO_LDS_UNIFORM) || defined(RRLW_KO_HALFG) || defined(RRLW_KO_STORES) || defined(RRLW_KO_HALFSTORE)
 #define RRLW_BF_KNOCKOUT 2u
 #else
 #define RRLW_BF_KNOCKOUT 0u
@@ -1505,6 +1505,14 @@ __device__ __forceinline__ void scr_store(unsigned *base, size_t cell, const scr
 #pragma unroll
     for (int k = 0; k < CODE_WORDS; k++) asm volatile("" :: "v"(x[k]));
     return;
+#endif
+#ifdef RRLW_KO_HALFSTORE    // knock-out (timing only, wrong results): half of every record is stored - as many store instructions, half the bytes
+    {
+        typedef unsigned v2h __attribute__((ext_vector_type(2)));
+        v2h lo = {p.w[0] ^ p.w[2], p.w[1] ^ p.w[3 % CODE_WORDS]};
+        __builtin_nontemporal_store(lo, reinterpret_cast<v2h *>(base + cell * 2));       // (contiguous: whole lines are written)
+        return;
+    }
 #endif
 #ifdef RRLW_NO_NT
     __builtin_memcpy(base + cell * CODE_WORDS, &x, CODE_BYTES);
