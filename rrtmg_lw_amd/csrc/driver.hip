@@ -2035,6 +2035,23 @@ int rrtmg_lw_hip_set_batch(int ncol_batch)
     return 0;
 }
 
+#ifdef RRLW_DBG_DUMP
+#ifndef RRLW_TUNE
+#error "RRLW_DBG_DUMP belongs to tuning builds (-DRRLW_TUNE)"
+#endif
+// debugging build only (tools/dbg_codes.py): the cell codes / binary-key words k_layer left in the scratch set 0 (which: 0 gas codes, 1 total codes, 2 fw); info = {ncolb, nlay}
+int rrtmg_lw_hip_debug_scratch(int which, void *dst, size_t bytes, int *info)
+{
+    ENTRY_LOCK;
+    HIP_TRY(hipDeviceSynchronize());
+    info[0] = G.ws_ncolb; info[1] = G.ws_nlay;
+    const void *src = which == 2 ? (const void *)G.scrset[0].fw : (const void *)G.scrset[0].scr[which == 1 ? S_CODET : S_CODE];
+    const size_t have = which == 2 ? (size_t)NFW * G.ws_nlay * G.ws_ncolb * 4 : (size_t)NQUAD * G.ws_nlay * G.ws_ncolb * CODE_BYTES;
+    HIP_TRY(hipMemcpy(dst, src, std::min(bytes, have), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 #ifdef RRLW_LAYER_STAMPS
 // diagnostic build only: the cycle sums of k_layer's segments (kernels.hip, STAMP) since the last call; out[NSTAMP] = waves counted
 int rrtmg_lw_hip_debug_stamps(unsigned long long *out, int n)

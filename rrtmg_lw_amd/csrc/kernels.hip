@@ -65,7 +65,8 @@
     defined(RRLW_LAYER_SYNCTHREADS) || defined(RRLW_LAYER_STAMPS) || defined(RRLW_NO_NT) || defined(RRLW_SWEEPC_P0) || defined(RRLW_SWEEPC_P2D) || \
     defined(RRLW_SWEEPC_WAVES_CAP) || defined(RRLW_SWEEPC_QUAD_BARRIER) || defined(RRLW_SWEEPC_CODES) || defined(RRLW_SWEEPC_SPLIT) || defined(RRLW_SWEEPC_SPLIT3) || \
     defined(RRLW_SWEEPC_SPLIT_P1) || defined(RRLW_SWEEPZ_CT_SLOTS) || defined(RRLW_SWEEPZ_G2) || defined(RRLW_SWEEPZ_WAVES_G2) || defined(RRLW_SWEEPZ_WAVES_G1) || \
-    defined(RRLW_SWEEPZ_WAVES_IDRV) || defined(RRLW_GEN_BESIDE_SWEEP) || defined(RRLW_FANOUT_MAX) || defined(RRLW_KI_SALU)
+    defined(RRLW_SWEEPZ_WAVES_IDRV) || defined(RRLW_GEN_BESIDE_SWEEP) || defined(RRLW_FANOUT_MAX) || defined(RRLW_KI_SALU) || \
+    defined(RRLW_DBG_DUMP)      /* (driver.hip: one more entry, rrtmg_lw_hip_debug_scratch - reads k_layer's cell codes back; tuning builds only) */
 #define RRLW_BF_GEOMETRY 16u
 #else
 #define RRLW_BF_GEOMETRY 0u
@@ -1979,7 +1980,9 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
     // "lower atmosphere" for taumol is lay <= laytrop (the count of layers with ln p > 4.56), :312-313
     const bool lower = lay <= W.laytrop[col];
     int cloudy = 0;
-    if (CLOUD) cloudy = W.cflag[(size_t)lay * W.ncolb + col] & 1;
+    // (threads past the last column never take the cloudy branches: nothing of theirs is stored, and with them no lane of a divergent
+    // region skips the `if (incol)` at its end - the construct of profiles/round5_exec_hazard.md)
+    if (CLOUD) cloudy = incol ? (W.cflag[(size_t)lay * W.ncolb + col] & 1) : 0;
     // wave-uniform descriptor of the packed k tables (built from kernel arguments only)
     const __amdgpu_buffer_rsrc_t kt = __builtin_amdgcn_make_buffer_rsrc((void *)T.ktab, 0, a.ktab_bytes, 0x00020000);
     const unsigned mw[MASK_WORDS] = {};

@@ -121,3 +121,35 @@ def test_output_arrays_are_checked_not_converted():
     from rrtmg_lw_amd.synth import make_gcm_inputs
     with pytest.raises(ValueError, match="'hr'"):
         api.rrtmg_lw_from_dict(make_gcm_inputs(ncol, nlay, "clear"), out=o)
+
+
+def test_shipped_code_objects_keep_every_exec_restore():
+    """The libraries are compiled with -mllvm -amdgpu-remove-redundant-endcf=0 (__graft_entry__.CODEGEN_FLAGS): without it LLVM merges the end
+    of an inner `if` with the end of the enclosing divergent region - the inner `if` then opens with a plain `s_and_b64 exec, exec, sN` -
+    and copies the register allocator places behind the inner `if` run under its mask; k_layer's threads past the last column lost
+    registers that way and whole waves of a ragged last window came out wrong (profiles/round5_exec_hazard.md).  Checked on what ships:
+    the gfx950 code object inside each library, disassembled, holds no such narrowing; and the recorded compile command has the flag."""
+    import shutil, subprocess, tempfile
+    from rrtmg_lw_amd import api
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not installed")
+    for path in (api.LIB_PATH, api.LIB_PATH_G256):
+        info = path + ".buildinfo"
+        if os.path.exists(info):
+            lines = open(info).read().split("\n")
+            if len(lines) > 1 and lines[1].strip():
+                assert "-amdgpu-remove-redundant-endcf=0" in lines[1], lines[1]
+        tmp = tempfile.mkdtemp()
+        try:
+            fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+            subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", path, os.path.join(tmp, "unused.so")], check=True, capture_output=True)
+            subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                           check=True, capture_output=True)
+            asm = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        assert asm.count("s_and_saveexec_b64") > 1000, "disassembly looks empty"
+        n = len(re.findall(r"\bs_and_b64 exec, exec, s\[", asm))
+        assert n == 0, f"{os.path.basename(path)}: {n} inner branches whose exec restore was merged away - built without {' '.join(('-mllvm', '-amdgpu-remove-redundant-endcf=0'))}?"

@@ -1066,6 +1066,39 @@ def test_orography_spread_of_pressure_levels(hip, oracle, icld, lo):
     assert (jp.max(axis=0) - jp.min(axis=0)).max() >= 3        # the spread the staging window cannot hold
 
 
+@pytest.mark.parametrize("col0,ncol", [(844914, 117), (282237, 341), (903511, 237), (662926, 103), (959099, 417)])
+def test_last_window_with_a_cloudy_last_column(hip, oracle, col0, ncol):
+    """Regression (round 5, profiles/round5_exec_hazard.md): a ragged last window whose LAST column is cloudy in some layer.  k_layer's
+    threads past the last column shadow it; compiled without -mllvm -amdgpu-remove-redundant-endcf=0 their registers were left
+    clobbered behind the cloudy branch (copies of the register allocator ran under the `if (incol)` mask), the next staging pass copied
+    rows from wrong places, and whole waves of the window came out with band 5's optical depths wrong (up to 0.6 W m-2).  The five calls
+    are the ones a random sweep over terrain-following grids found; each must agree with the narrow-window run bit for bit, in every
+    cloud mode, and with the oracle."""
+    nlay = 72
+    d = make_gcm_inputs(ncol, nlay, "cloudy_orography", col0=col0)
+    assert (np.array(d["cldfr"])[-1] > 0).any()
+    for icld in (1, 2, 3):
+        outs = {}
+        for on in (1, 0):
+            prev = hip.set_wide_window(on)
+            try:
+                outs[on] = hip.rrtmg_lw_from_dict(d, icld=icld, idrv=0)
+            finally:
+                hip.set_wide_window(prev)
+        for k in outs[1]:
+            assert np.array_equal(outs[1][k], outs[0][k]), (k, icld)
+        _compare(outs[1], oracle.rrtmg_lw(ncol, nlay, icld, 0, d), 0, f"ragged cloudy last window icld={icld}")
+    outs = {}
+    for on in (1, 0):       # the mask flavour of the McICA kernels (k_layer<mcmask>)
+        prev = hip.set_wide_window(on)
+        try:
+            outs[on] = hip.rrtmg_lw_mcica_subcol_from_dict(d, 7, 0, icld=2, idrv=0)
+        finally:
+            hip.set_wide_window(prev)
+    for k in outs[1]:
+        assert np.array_equal(outs[1][k], outs[0][k]), (k, "mcica")
+
+
 @pytest.mark.parametrize("icld,idrv,mcica", [(0, 0, 0), (2, 1, 0), (1, 0, 0), (2, 0, 2)])
 def test_wide_window_is_transparent(hip, oracle, icld, idrv, mcica):
     """k_layer takes a workgroup whose 256 columns lie more than one reference-pressure plane apart (a terrain-following grid: synth
