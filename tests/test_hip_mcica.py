@@ -153,9 +153,11 @@ def _with_subcolumns(oracle, d, icld, irng=0, permuteseed=140, alpha=None):
     ("aer_idrv", 137, 2, 130, None),          # aerosol + dF/dT, 137 layers
     ("aer_idrv", 33, 1, 64, (2, 3, 1)),
     ("cloudy", 72, 9, 65, None),              # out-of-range icld is reset to 2 (src/rrtmg_lw_rad.f90:469)
+    ("cloudy_orography", 72, 2, 341, None),   # terrain-following grid, ragged last window with a cloudy last column (k_layer<mcica, wide>)
+    ("cloudy_orography", 72, 3, 117, None),
 ])
 def test_mcica_entry_matches_oracle(hip, oracle, config, nlay, icld, ncol, flags, sweeps):
-    d = make_gcm_inputs(ncol, nlay, config, col0=77)
+    d = make_gcm_inputs(ncol, nlay, config, col0={341: 282237, 117: 844914}.get(ncol, 77))
     if flags is not None:
         d["inflglw"], d["iceflglw"], d["liqflglw"] = flags
         if flags[1] == 0:
