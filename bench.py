@@ -80,6 +80,7 @@ def main():
                     help="columns of the end-to-end (host-pointer, PCIe-inclusive) measurement after the timed region; 0 = skip")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: what RCCL needs on this pool; already exported by the image)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
