@@ -283,6 +283,11 @@ void rrtmg_lw_hip_graph_stats(long long *captures, long long *replays);
  * the cells outside it read the tables through the vector L1 - 1.6x the kernel's time on such a grid).  Results do not depend on it
  * (bit for bit).  Returns the previous value. */
 int rrtmg_lw_hip_set_wide_window(int on);
+
+/* k_layer takes the sixteen bands of a (window of 256 columns, layer) in ONE workgroup - a 100 us chain; a batch with too few such pairs to
+ * fill the chip (up to ~2 000 columns of 72 layers) spreads them over two or four workgroups along the staging passes (default on,
+ * RRTMG_LW_LAYER_SPLIT=0 to switch off).  Results do not depend on it (bit for bit).  Returns the previous value. */
+int rrtmg_lw_hip_set_layer_split(int on);
 /* The sweeps decide per wavefront - 64 consecutive columns of a batch - where the clouds end; one deep tower among 64 shallow columns sends
  * all of them through the cloud-zone sweep up to its top.  By default (RRTMG_LW_COLSORT=0 to switch off) the columns of a cloudy batch
  * - rtrn, rtrnmr and the McICA entries, where the key is the grid-mean cloud fraction the sub-columns are drawn from - are therefore

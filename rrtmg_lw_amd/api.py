@@ -182,6 +182,11 @@ def set_one_sweep_max(ncol):
     return int(lib().rrtmg_lw_hip_set_one_sweep_max(C.c_int(int(ncol))))
 
 
+def set_layer_split(on):
+    """k_layer's bands of a (window, layer) over several workgroups where the batch does not fill the chip (rrtmg_lw_hip_set_layer_split); returns the previous value"""
+    return int(lib().rrtmg_lw_hip_set_layer_split(C.c_int(1 if on else 0)))
+
+
 def set_split_max(ncol):
     """batches of up to `ncol` columns are swept one band per workgroup (rrtmg_lw_hip_set_split_max; 0 = never); returns the previous value"""
     return int(lib().rrtmg_lw_hip_set_split_max(C.c_int(int(ncol))))

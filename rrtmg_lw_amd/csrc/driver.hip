@@ -76,6 +76,7 @@ struct State {
     int cu_total = 0;
     bool sweep_fanout = true;
     hipEvent_t ev_last = nullptr;           // end of the previous device-entry call (calls on different streams share the workspace)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // run_prep: k_colprep beside k_cloudscan in a single-batch call
     bool ev_last_valid = false;
     hipEvent_t ev_in = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_layer[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     // McICA sub-column masks of all columns of the current call
@@ -572,6 +573,10 @@ bool one_sweep(int nb, int mode) { return mode != 0 && nb <= g_one_sweep_max; }
 // k_layer's second pass with the wide staging window (terrain-following pressure grids; kernels.hip: StageWin).  rrtmg_lw_hip_set_wide_window /
 // RRTMG_LW_WIDE_WINDOW=0 switch it off (measurement: every workgroup then keeps the narrow window, as before round 5); same results either way.
 bool g_wide_window = []() { const char *e = getenv("RRTMG_LW_WIDE_WINDOW"); return !e || atoi(e) != 0; }();
+// k_layer's bands of a (window, layer) over several workgroups where the batch does not fill the chip (run_layer).  rrtmg_lw_hip_set_layer_split /
+// RRTMG_LW_LAYER_SPLIT=0.  Results do not depend on it.
+bool g_prep_fork = []() { const char *e = getenv("RRTMG_LW_PREP_FORK"); return !e || atoi(e) != 0; }();     // (run_prep: k_colprep beside k_cloudscan; measurement switch)
+bool g_layer_split = []() { const char *e = getenv("RRTMG_LW_LAYER_SPLIT"); return !e || atoi(e) != 0; }();
 // (a batch that takes one sweep launch walks every level in the cloud-zone kernel whatever its blocks hold: nothing to gain from an order)
 // (McICA, mode 3: with the generator's mask - the grid-mean cloud fraction gives the key; the sub-column ARRAYS of the reference's McICA
 // argument list come without one and keep their order: the call sites pass `!mc`)
@@ -581,7 +586,7 @@ bool use_colsort(bool gcm, int mode, int nb) { return g_colsort && gcm && (mode 
 // auxiliary stream one batch ahead of the heavy kernels (run_pipelined).
 template <bool GCM>
 int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int mode, int idrv, int istart,
-             const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag)
+             const GcmIn &g, const ColIn &c, int inflag, int iceflag, int liqflag, hipStream_t side = nullptr)
 {
     // thread-per-column kernels: one wave per workgroup so that a batch (one wave per 64 columns) spreads over all 256 CUs
     const dim3 cgrid1((nb + 63) / 64), cblock1(64);
@@ -589,9 +594,18 @@ int run_prep(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int 
         const dim3 wgrid((nb + COLSORT_WIN - 1) / COLSORT_WIN);
         LAUNCH("k_colsort", (k_colsort<GCM>), wgrid, dim3(COLSORT_WIN, COLSORT_TY), s, Wk, g, c, nb, col0, nct, g_colsort_min);
     }
-    LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, s, G.D, Wk, g, c, nb, col0, nct, idrv, istart);
-    if (mode == 1 || mode == 2) {
+    // (k_cloudscan needs nothing of k_colprep - k_cloudlay does: the secants - and both are one dependent walk over a column's layers: with a
+    // side stream, a call that is a single batch, they run side by side: -30 us of its 0.5 ms)
+    const bool scan = mode == 1 || mode == 2, fork = scan && side && side != s;
+    if (fork) {
+        HIP_TRY(hipEventRecord(G.ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(side, G.ev_fork, 0));
+    }
+    LAUNCH("k_colprep", (k_colprep<GCM>), cgrid1, cblock1, fork ? side : s, G.D, Wk, g, c, nb, col0, nct, idrv, istart, scan ? 0 : 1);
+    if (fork) HIP_TRY(hipEventRecord(G.ev_join, side));
+    if (scan) {
         LAUNCH("k_cloudscan", (k_cloudscan<GCM>), cgrid1, cblock1, s, Wk, g, c, nb, col0, nct, inflag, iceflag, liqflag, mode);
+        if (fork) HIP_TRY(hipStreamWaitEvent(s, G.ev_join, 0));
         const dim3 lgrid((nb + BLOCK - 1) / BLOCK, Wk.nlay), lblock(BLOCK);
         LAUNCH("k_cloudlay", (k_cloudlay<GCM>), lgrid, lblock, s, G.D, Wk, g, c, nb, col0, nct, mode, inflag, iceflag, liqflag);
         LAUNCH("k_blocksort", k_blocksort, dim3(1), dim3(256), s, Wk, (nb + 63) / 64, one_sweep(nb, mode) ? 1 : 0);      // the blocks by cloud top, hand-off levels
@@ -619,12 +633,20 @@ int run_layer(hipStream_t s, const Workspace &Wk, int nb, int col0, int nct, int
     la.ktab_bytes = (int)(G.H.ktab.size() * 8);
     la.tauaer = GCM ? g.tauaer : c.taua;
     const unsigned gx = (nb + LAYER_BLOCK - 1) / LAYER_BLOCK;
-    const dim3 lgrid(gx, nlay), lblock(LAYER_BLOCK);
+    // A batch whose (window, layer) pairs do not fill the chip - 768 workgroups at three per CU - spreads the bands of a pair over two or
+    // four workgroups (k_layer: LayerArgs::partmask): a workgroup's sixteen bands are a 100 us chain, and a small call waits for ONE round
+    // of them.  The parts follow the staging passes (a workgroup stages only the passes it has a band of).
+    const auto bits = [](std::initializer_list<int> bands) { unsigned m = 0; for (int b : bands) m |= 1u << (b - 1); return m; };
+    const unsigned quarter[4] = {bits({1, 2, 11, 15, 6}), bits({8, 10, 14, 16, 12, 13}), bits({4, 9, 7}), bits({3, 5})};
+    const unsigned pairs_ = gx * (unsigned)nlay;
+    la.nparts = !g_layer_split ? 1 : (pairs_ * 4 <= 1152 ? 4 : (pairs_ * 2 <= 1152 ? 2 : 1));
+    for (int p = 0; p < 4; p++) la.partmask[p] = la.nparts == 4 ? quarter[p] : (la.nparts == 2 && p < 2 ? (quarter[2 * p] | quarter[2 * p + 1]) : 0xffffu);
+    const dim3 lgrid(gx, nlay, la.nparts), lblock(LAYER_BLOCK);
     // the wide-window pass over the (window, layer) pairs the narrow launch could not take (GCM entry; kernels.hip: StageWin): as many
     // workgroups as fit the chip at once, which leave at once when the list is empty
     Workspace Wn = Wk;
     if (!GCM || !HAVE_WIDE || !g_wide_window) Wn.wide = nullptr;
-    const dim3 wgrid(gx * nlay);
+    const dim3 wgrid(gx * nlay, la.nparts);
     // (the list's count: cleared on the stream in front of the narrow launch - a memset node when the call is captured as a graph)
     if (Wn.wide) HIP_TRY(hipMemsetAsync(Wn.wide, 0, sizeof(int), s));
 #ifdef RRLW_TUNE
@@ -821,6 +843,8 @@ int ensure_pipeline()
     HIP_TRY(hipStreamCreateWithFlags(&G.aux, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&G.ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&G.ev_last, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&G.ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&G.ev_join, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
         HIP_TRY(hipEventCreateWithFlags(&G.ev_ready[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&G.ev_layer[k], hipEventDisableTiming));
@@ -892,7 +916,7 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         key_put(key, gp);
         // (what else decides which kernels run with which arguments: the workspace, the tuning switches)
         key_put(key, G.ws_base); key_put(key, G.ws_bytes); key_put(key, g_colsort); key_put(key, g_colsort_min); key_put(key, g_one_sweep_max);
-        key_put(key, g_wide_window); key_put(key, G.sweep_fanout); key_put(key, eff_batch(nlay)); key_put(key, g_split_max);
+        key_put(key, g_wide_window); key_put(key, g_layer_split); key_put(key, g_prep_fork); key_put(key, G.sweep_fanout); key_put(key, eff_batch(nlay)); key_put(key, g_split_max);
         for (auto &e : G.graphs) if (e.key == key) { gent = &e; break; }
         if (!gent) {
             if (G.graphs.size() >= GRAPH_CACHE) {           // the entry used longest ago makes room
@@ -940,12 +964,12 @@ int run_pipelined(hipStream_t s, int ncol, int nlay, int mode, int idrv, const G
         if (capture) {
             // (one batch, one stream: the batch's launches, the fork to the sweep streams and their join become the graph; an error ends
             // the capture before it is reported)
-            rc_cap = run_prep<true>(s, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag);
+            rc_cap = run_prep<true>(s, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag, g_prep_fork ? G.aux : nullptr);
             if (rc_cap == 0) rc_cap = run_layer<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, inflag, iceflag, liqflag, mc);
             if (rc_cap == 0) rc_cap = run_sweep<true>(s, Wk, nb, col0, ncol, nlay, mode, idrv, 1, 16, g, c, out, mc);
             continue;
         }
-        if (int rc = run_prep<true>(aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag)) return rc;
+        if (int rc = run_prep<true>(aux, Wk, nb, col0, ncol, mode, idrv, 1, g, c, inflag, iceflag, liqflag, single && g_prep_fork ? G.aux : nullptr)) return rc;
         if (gen.on) {
 #if RRLW_GEN_BESIDE_SWEEP
             if (i >= 1 && !split) HIP_TRY(hipStreamWaitEvent(aux, G.ev_layer[(i - 1) & 1], 0));
@@ -2008,6 +2032,8 @@ static void finalize_state()
         (void)hipStreamDestroy(G.aux);
         (void)hipEventDestroy(G.ev_in);
         (void)hipEventDestroy(G.ev_last);
+        (void)hipEventDestroy(G.ev_fork);
+        (void)hipEventDestroy(G.ev_join);
         for (int k = 0; k < 2; k++) { (void)hipEventDestroy(G.ev_ready[k]); (void)hipEventDestroy(G.ev_layer[k]); (void)hipEventDestroy(G.ev_done[k]); }
     }
     drop_sweep_set(0);
@@ -2118,6 +2144,16 @@ int rrtmg_lw_hip_set_wide_window(int on)
     ENTRY_LOCK;
     const int prev = g_wide_window ? 1 : 0;
     g_wide_window = on != 0;
+    return prev;
+}
+
+// k_layer's sixteen bands of a (window of 256 columns, layer) over two or four workgroups where the batch has too few such pairs to fill the
+// chip (up to ~2 000 columns of 72 layers): on = 1 (default) / off = 0.  Results do not depend on it.  Returns the previous value.
+int rrtmg_lw_hip_set_layer_split(int on)
+{
+    ENTRY_LOCK;
+    const int prev = g_layer_split ? 1 : 0;
+    g_layer_split = on != 0;
     return prev;
 }
 

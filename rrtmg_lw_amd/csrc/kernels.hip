@@ -332,7 +332,7 @@ __global__ __launch_bounds__(COLSORT_WIN * COLSORT_TY) void k_colsort(Workspace 
 //             :312-313) and the diffusivity secants (src/rrtmg_lw_rtrn.f90:265-288).
 // ------------------------------------------------------------------------------------------------
 template <bool GCM>
-__global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int idrv, int istart)
+__global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int idrv, int istart, int init_cloud)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncol) return;
@@ -399,9 +399,13 @@ __global__ __launch_bounds__(256) void k_colprep(DevTables T, Workspace W, GcmIn
         }
         W.percol[(size_t)(PC_SECDIFF + b) * W.ncolb + col] = sd;
     }
-    W.ncbands[col] = 1;
-    W.cflag[col] = 0;
-    if ((col & 63) == 0) { W.btop[col >> 6] = 0; W.bbot[col >> 6] = nlay + 1; }          // (k_cloudscan / k_cloudmc of the same batch follow on the same stream)
+    // (the cloud-free defaults, and the block tops k_cloudmc raises with atomics; k_cloudscan writes all of these itself and may run BESIDE
+    // this kernel - run_prep - so they are left alone for it: init_cloud = 0)
+    if (init_cloud) {
+        W.ncbands[col] = 1;
+        W.cflag[col] = 0;
+        if ((col & 63) == 0) { W.btop[col >> 6] = 0; W.bbot[col >> 6] = nlay + 1; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,12 +488,13 @@ template <bool GCM>
 __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c, int ncol, int col0, int nct, int inflag, int iceflag, int liqflag, int mode)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncol) return;
-    const size_t gc = (size_t)col0 + pcol(W, col);
     const int nlay = W.nlay;
+    int top = 0, bot = nlay + 1;
+    if (col < ncol) {
+    const size_t gc = (size_t)col0 + pcol(W, col);
     const double *cldfr = GCM ? g.cldfr : c.cldfrac;
     const double *ciwp_ = GCM ? g.cicewp : c.ciwp, *clwp_ = GCM ? g.cliqwp : c.clwp;
-    int ncbands = 1, anycloud = 0, top = 0, bot = nlay + 1;
+    int ncbands = 1, anycloud = 0;
     const size_t ncb = W.ncolb;
     bool prevcld = false, rat1 = false, rat2 = false;       // upward sweep order = this loop's order
     double cfprev = 0.0;
@@ -542,10 +547,15 @@ __global__ __launch_bounds__(256) void k_cloudscan(Workspace W, GcmIn g, ColIn c
             } else prevcld = false;
         }
     }
-    if (top > 0) { atomicMax(&W.btop[col >> 6], top); atomicMin(&W.bbot[col >> 6], bot); }       // (the 64 columns of a block are one wave of this kernel)
     W.ncbands[col] = ncbands;
     W.cflag[col] = anycloud ? 8 : 0;
     W.cflag[(size_t)(nlay + 1) * W.ncolb + col] = 0;
+    }
+    // highest and lowest cloudy layer of the block: the 64 columns of a block are one workgroup (one wave) of this kernel (a cloud-free
+    // column holds 0 / nlay + 1); written, not raised with atomics: nothing has to initialise them in front of this kernel
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { top = max(top, __shfl_xor(top, o, 64)); bot = min(bot, __shfl_xor(bot, o, 64)); }
+    if (threadIdx.x == 0 && col < ncol) { W.btop[col >> 6] = top; W.bbot[col >> 6] = bot; }
 }
 
 // k_cloudlay : cldprop for one (column, layer) (src/rrtmg_lw_cldprop.f90:173-293) and the cloud optical depth along the diffusivity
@@ -1431,6 +1441,10 @@ __device__ __forceinline__ void rows_eval_band(__amdgpu_buffer_rsrc_t kt, const 
 // ------------------------------------------------------------------------------------------------
 struct LayerArgs {
     int ncol, col0, nct, idrv, istart, iend;
+    // a batch that does not fill the chip: the bands of a (window, layer) over `nparts` workgroups (grid.z, or grid.y of the wide launch),
+    // workgroup p takes the bands of partmask[p] (bit B - 1); 0 / 1: one workgroup takes them all
+    int nparts;
+    unsigned partmask[4];
     int ktab_bytes;            // size of the packed k-table buffer (buffer descriptor range)
     const double *tauaer;      // (nct,nlay,16)
 };
@@ -1810,8 +1824,11 @@ using LayerPassesWide = std::tuple<BandList<1, 2, 11, 15, 6, 8, 10, 14, 16, 13>,
 template <class PL, class WN, int CLOUD, int... I>
 __device__ __forceinline__ void pass_run(std::integer_sequence<int, I...>, const DevTables &T, const Workspace &W, const LayerArgs &a,
                                          const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
-                                         int cloudy, const unsigned (&mw)[MASK_WORDS])
+                                         int cloudy, const unsigned (&mw)[MASK_WORDS], unsigned bmask)
 {
+    // (a workgroup that holds none of the pass's bands - the bands of a small batch spread over several - leaves the pass alone: uniform)
+    constexpr unsigned passmask = ((1u << (PL::b[I] - 1)) | ...);
+    if ((bmask & passmask) == 0u) return;
     // the pass's tables -> LDS; the barriers are reached by every thread of the workgroup
     STAMP(4);
     lds_barrier();                      // the previous pass's readers are done with the staging buffer
@@ -1820,16 +1837,16 @@ __device__ __forceinline__ void pass_run(std::integer_sequence<int, I...>, const
     else stage_pass<PL, false, WN>(T, kt, wg.lds, wg.jp0, wg.im0, wg.tid);
     lds_barrier();
     STAMP(1);
-    ((PL::b[I] >= a.istart && PL::b[I] <= a.iend
+    (((bmask >> (PL::b[I] - 1)) & 1u
           ? layer_band<PL::b[I], CLOUD, WN, pass_base<PL, true, WN, I>(), pass_base<PL, false, WN, I>()>(T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw)
           : (void)0), ...);
 }
 template <int CLOUD, class WN, class... PLs>
 __device__ __forceinline__ void passes_run(std::tuple<PLs...> *, const DevTables &T, const Workspace &W, const LayerArgs &a,
                                            const LayerCoef &C, __amdgpu_buffer_rsrc_t kt, const LayerWg &wg, bool lower, int lay, int col, bool incol,
-                                           int cloudy, const unsigned (&mw)[MASK_WORDS])
+                                           int cloudy, const unsigned (&mw)[MASK_WORDS], unsigned bmask)
 {
-    (pass_run<PLs, WN, CLOUD>(std::make_integer_sequence<int, PLs::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw), ...);
+    (pass_run<PLs, WN, CLOUD>(std::make_integer_sequence<int, PLs::n>{}, T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw, bmask), ...);
 }
 
 // One workgroup's work: the cells of window `bx` (256 consecutive positions) in layer `by` + 1.  WIDE = 0: the narrow staging window; a
@@ -1837,7 +1854,7 @@ __device__ __forceinline__ void passes_run(std::tuple<PLs...> *, const DevTables
 // that list).
 template <bool GCM, int CLOUD, int WIDE>
 __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace &W, const GcmIn &g, const ColIn &c, const LayerArgs &a, double2 *s_tab, int *s_wg,
-                                            int bx, int by)
+                                            int bx, int by, unsigned bmask, bool lists)
 {
     const int colr = bx * LAYER_BLOCK + threadIdx.x;
     const bool incol = colr < a.ncol;
@@ -1878,7 +1895,7 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
             __syncthreads();
             const int jp0 = s_wg[1], im0 = min(s_wg[2], 20 - WinNarrow::MW);
             if (s_wg[3] - jp0 > WinNarrow::NPL - 2 || s_wg[4] - im0 > WinNarrow::MW - 2) {
-                if (threadIdx.x == 0) W.wide[2 + atomicAdd(&W.wide[0], 1)] = by * ((a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK) + bx;
+                if (threadIdx.x == 0 && lists) W.wide[2 + atomicAdd(&W.wide[0], 1)] = by * ((a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK) + bx;     // (one of the pair's workgroups lists it)
                 return;
             }
         }
@@ -2016,7 +2033,7 @@ __device__ __forceinline__ void layer_cells(const DevTables &T, const Workspace 
     wg.im0 = min(s_wg[2], 20 - WN::MW);                     // (the window ends with the table's last slice at the latest)
     wg.ok = lower == wg.lower && (unsigned)(jp - wg.jp0) <= (unsigned)(WN::NPL - 2) && (unsigned)(indminor - wg.im0) <= (unsigned)(WN::MW - 2);
     STAMP(5);                       // set-up of the workgroup's staging window
-    passes_run<CLOUD, WN>(static_cast<std::conditional_t<WIDE != 0, LayerPassesWide, LayerPasses> *>(nullptr), T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw);
+    passes_run<CLOUD, WN>(static_cast<std::conditional_t<WIDE != 0, LayerPassesWide, LayerPasses> *>(nullptr), T, W, a, C, kt, wg, lower, lay, col, incol, cloudy, mw, bmask);
 #ifdef RRLW_LAYER_STAMPS
     STAMP(4);
     if ((threadIdx.x & 63) == 0) {
@@ -2036,13 +2053,17 @@ __global__ __launch_bounds__(LAYER_BLOCK, RRLW_LAYER_WAVES) void k_layer(DevTabl
 {
     __shared__ double2 s_tab[STAGE_DOUBLES / 2];
     __shared__ int s_wg[5];
+    // the bands this workgroup takes: those of the call's range, of its part where the bands of a small batch are spread over several workgroups
+    const int part = WIDE == 0 ? blockIdx.z : blockIdx.y;
+    unsigned bmask = ((a.iend >= 32 ? 0u : (1u << a.iend)) - 1u) & ~((1u << (a.istart - 1)) - 1u);
+    if (a.nparts > 1) bmask &= a.partmask[part];
     if constexpr (WIDE == 0) {
-        layer_cells<GCM, CLOUD, 0>(T, W, g, c, a, s_tab, s_wg, blockIdx.x, blockIdx.y);
+        layer_cells<GCM, CLOUD, 0>(T, W, g, c, a, s_tab, s_wg, blockIdx.x, blockIdx.y, bmask, part == 0);
     } else {
         const int n = __builtin_amdgcn_readfirstlane(W.wide[0]), gx = (a.ncol + LAYER_BLOCK - 1) / LAYER_BLOCK;
         if ((int)blockIdx.x >= n) return;
         const int item = __builtin_amdgcn_readfirstlane(W.wide[2 + blockIdx.x]);
-        layer_cells<GCM, CLOUD, 1>(T, W, g, c, a, s_tab, s_wg, item % gx, item / gx);
+        layer_cells<GCM, CLOUD, 1>(T, W, g, c, a, s_tab, s_wg, item % gx, item / gx, bmask, false);
     }
 }
 

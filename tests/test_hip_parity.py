@@ -857,6 +857,57 @@ def test_one_band_per_workgroup_is_transparent(hip, oracle, config, icld, idrv, 
     assert np.abs(grouped["uflx"]).max() > 100.0
 
 
+@pytest.mark.parametrize("config,ncol,nlay,icld,idrv,mcica", [("cloudy", 300, 72, 2, 0, 0), ("cloudy", 1024, 72, 1, 1, 0), ("clear", 700, 51, 0, 0, 0),
+                                                              ("cloudy_orography", 341, 72, 2, 0, 0), ("cloudy_orography", 117, 72, 3, 0, 0),
+                                                              ("aer_idrv", 130, 137, 2, 1, 0), ("cloudy", 200, 72, 2, 0, 5), ("cloudy", 1900, 40, 2, 0, 0)])
+def test_bands_over_several_workgroups_are_transparent(hip, oracle, config, ncol, nlay, icld, idrv, mcica):
+    """A batch whose (window, layer) pairs do not fill the chip spreads k_layer's sixteen bands of a pair over two or four workgroups along the
+    staging passes (rrtmg_lw_hip_set_layer_split; both launches, narrow and wide - the terrain cases): same cells, same arithmetic, the
+    outputs bit for bit those of one workgroup per pair - rtrn / rtrnmr / clear, d/dT, 137 layers, the fused McICA entry, a layer count that
+    gives two parts instead of four; and against the oracle."""
+    d = make_gcm_inputs(ncol, nlay, config, col0={341: 282237, 117: 844914}.get(ncol, 9))
+
+    def run():
+        if mcica:
+            dz = np.full((ncol, nlay), 400.0)
+            alpha = oracle.get_alpha(ncol, nlay, mcica, 0, 2500.0, dz, np.zeros(ncol), 100, d["cldfr"])
+            return hip.rrtmg_lw_mcica_subcol_from_dict(d, 3, 0, icld=mcica, alpha=alpha, idrv=idrv)
+        return hip.rrtmg_lw_from_dict(d, icld=icld, idrv=idrv)
+
+    prev = hip.set_layer_split(0)
+    try:
+        one = run()
+        assert hip.set_layer_split(1) == 0
+        parts = run()
+    finally:
+        hip.set_layer_split(prev)
+    for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if idrv else ()):
+        assert np.array_equal(one[k], parts[k]), k
+    if not mcica:
+        _compare(parts, oracle.rrtmg_lw(ncol, nlay, icld, idrv, d), idrv, f"bands over several workgroups {config} {ncol}x{nlay}")
+
+
+def test_band_ranges_with_bands_over_several_workgroups(hip, oracle):
+    """The prepared-column entry with a band range (istart .. iend) on a batch small enough for the split: a workgroup takes the bands of its
+    part that lie in the range."""
+    import os
+    from rrtmg_lw_amd.io_rrtm import read_input_rrtm
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    col = read_input_rrtm(os.path.join(G, "input_rrtm_MLS-cld-imca0-icld2"), os.path.join(G, "in_cld_rrtm-cld5"))
+    for a, b in ((1, 16), (1, 7), (5, 5), (16, 16), (1, 12)):
+        outs = []
+        for on in (0, 1):
+            prev = hip.set_layer_split(on)
+            try:
+                outs.append(hip.run_columns([col] * 70, a, b, icld=2))
+            finally:
+                hip.set_layer_split(prev)
+        for k in ("totuflux", "totdflux", "htr"):
+            assert np.array_equal(outs[0][k], outs[1][k]), (a, b, k)
+        ref = oracle.column(col, a, b, 99 if a == b else 0, icld=2)
+        assert np.abs(outs[1]["totuflux"] - ref["totuflux"][None, :]).max() <= 5e-5, (a, b)
+
+
 @pytest.mark.parametrize("config,icld,idrv", [("cloudy_scatter", 2, 0), ("cloudy_deep", 2, 0), ("cloudy_deep", 1, 0), ("aer_idrv", 2, 1), ("cloudy", 2, 0)])
 def test_column_order_is_transparent(hip, oracle, config, icld, idrv):
     """k_colsort takes the columns of a cloudy batch by cloud top within windows of 256 where that pays (rrtmg_lw_hip_set_column_sort): the
