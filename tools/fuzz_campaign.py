@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Exploratory fuzz (not a test): random GCM-entry calls - field, layer count, column count, cloud mode, idrv, batch size and the library's
-transparent switches (wide window, column sort, one band per workgroup, one-sweep launch) - against the oracle with the bars of tests/test_fuzz.py.
+transparent switches (wide window, column sort, one band per workgroup, k_layer's bands over several workgroups) - against the oracle with the bars of tests/test_fuzz.py.
 usage: python tools/fuzz_campaign.py [--n 300] [--seed 1] [--mcica]      prints every failing case; exit code 1 if any"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,10 +24,10 @@ for t in range(args.n):
     c = dict(config=configs[rng.integers(0, len(configs))], nlay=int(rng.integers(4, 160)), ncol=int(rng.integers(1, 2500)),
              icld=int(rng.integers(0, 4)), idrv=int(rng.integers(0, 2)), batch=int((64, 256, 1024, 4096, 0)[rng.integers(0, 5)]),
              col0=int(rng.integers(0, 10 ** 6)), wide=int(rng.integers(0, 2)), sort=int(rng.integers(0, 2)), gain=int((0, 1, 8, 1 << 24)[rng.integers(0, 4)]),
-             split=int((0, 768, 1 << 20)[rng.integers(0, 3)]), seed=int(rng.integers(0, 5000)), mc_icld=int(rng.integers(1, 6)))
+             split=int((0, 768, 1 << 20)[rng.integers(0, 3)]), seed=int(rng.integers(0, 5000)), mc_icld=int(rng.integers(1, 6)), lsplit=int(rng.integers(0, 2)))
     d = make_gcm_inputs(c["ncol"], c["nlay"], c["config"], col0=c["col0"])
     d["idrv"] = c["idrv"]
-    hip.set_batch(c["batch"]); pw = hip.set_wide_window(c["wide"]); ps = hip.set_column_sort(c["sort"], c["gain"]); pp = hip.set_split_max(c["split"])
+    hip.set_batch(c["batch"]); pw = hip.set_wide_window(c["wide"]); ps = hip.set_column_sort(c["sort"], c["gain"]); pp = hip.set_split_max(c["split"]); pl = hip.set_layer_split(c["lsplit"])
     try:
         if args.mcica:
             alpha = np.asfortranarray(rng.random((c["ncol"], c["nlay"])))
@@ -39,7 +39,7 @@ for t in range(args.n):
             got = hip.rrtmg_lw_from_dict(d, icld=c["icld"], idrv=c["idrv"])
             ref = oracle.rrtmg_lw(c["ncol"], c["nlay"], c["icld"], c["idrv"], d)
     finally:
-        hip.set_batch(0); hip.set_wide_window(pw); hip.set_column_sort(ps, 24); hip.set_split_max(pp)
+        hip.set_batch(0); hip.set_wide_window(pw); hip.set_column_sort(ps, 24); hip.set_split_max(pp); hip.set_layer_split(pl)
     keys = ("uflx", "dflx", "uflxc", "dflxc") + (("duflx_dt", "duflxc_dt") if c["idrv"] else ())
     dflux = max(np.abs(got[k] - ref[k]).max() for k in keys)
     scale = max(np.abs(ref[k]).max() for k in ("uflx", "dflx"))
