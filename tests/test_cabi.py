@@ -153,3 +153,31 @@ def test_shipped_code_objects_keep_every_exec_restore():
         assert asm.count("s_and_saveexec_b64") > 1000, "disassembly looks empty"
         n = len(re.findall(r"\bs_and_b64 exec, exec, s\[", asm))
         assert n == 0, f"{os.path.basename(path)}: {n} inner branches whose exec restore was merged away - built without {' '.join(('-mllvm', '-amdgpu-remove-redundant-endcf=0'))}?"
+
+
+def test_exec_hazard_scanner_recognises_the_construct(tmp_path):
+    """tools/exec_hazard.py on two hand-made listings: the merged end-cf of profiles/round5_exec_hazard.md (an inner `if` opened with a plain
+    s_and_b64 on exec, the register allocator's copies behind it) is counted, the same code with its own saveexec / restore is not."""
+    import subprocess, sys
+    bad = """_Z1kv:
+	s_and_saveexec_b64 s[28:29], vcc
+	s_cbranch_execz .LBB0_5
+	v_mov_b32_e32 v38, v162
+	v_add_f64 v[162:163], v[56:57], v[116:117]
+	s_and_b64 exec, exec, s[0:1]
+	s_cbranch_execz .LBB0_4
+	global_store_dwordx4 v[164:165], v[160:163], off nt
+.LBB0_4:
+	v_mov_b32_e32 v162, v38
+.LBB0_5:
+	s_or_b64 exec, exec, s[28:29]
+	s_endpgm
+"""
+    good = bad.replace("\ts_and_b64 exec, exec, s[0:1]\n", "\ts_and_saveexec_b64 s[2:3], s[0:1]\n").replace(".LBB0_4:\n", ".LBB0_4:\n\ts_or_b64 exec, exec, s[2:3]\n")
+    (tmp_path / "bad.s").write_text(bad)
+    (tmp_path / "good.s").write_text(good)
+    tool = os.path.join(ROOT, "tools", "exec_hazard.py")
+    r = subprocess.run([sys.executable, tool, str(tmp_path / "bad.s")], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 plain exec narrowings, 1 with vector writes" in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, tool, str(tmp_path / "good.s")], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 plain exec narrowings" in r.stdout, r.stdout
